@@ -1,0 +1,223 @@
+// Shared device/host helpers for the henbun_amd HIP kernels (gfx950 / CDNA4 only).
+//
+// Everything here is wave64: reductions use 64-lane shuffles, MFMA fragments
+// follow the gfx950 lane maps (32x32x2 f32, 16x16x4 f64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#define HB_WAVE 64
+#define HB_MAX_DIMS 6
+
+// ---------------------------------------------------------------------------
+// error plumbing (host side).  Entry points return 0 on success, <0 for a bad
+// argument, >0 for a HIP runtime failure (hipError_t value).
+// ---------------------------------------------------------------------------
+void hb_set_error(const char* fmt, ...);
+
+#define HB_REQUIRE(cond, ...)                                   \
+  do {                                                          \
+    if (!(cond)) {                                              \
+      hb_set_error(__VA_ARGS__);                                \
+      return -1;                                                \
+    }                                                           \
+  } while (0)
+
+#define HB_LAUNCH_CHECK()                                                   \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      hb_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return (int)e__;                                                      \
+    }                                                                       \
+  } while (0)
+
+#define HB_HIP(call)                                                        \
+  do {                                                                      \
+    hipError_t e__ = (call);                                                \
+    if (e__ != hipSuccess) {                                                \
+      hb_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return (int)e__;                                                      \
+    }                                                                       \
+  } while (0)
+
+static inline int hb_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// grid size for grid-stride memory-bound kernels: cap at 8 blocks per CU.
+static inline int hb_stream_grid(long n, int block) {
+  long g = (n + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------
+// wave / block reductions (sum, max).  Deterministic (no atomics).
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    T o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64).  `smem` needs
+// 16 elements.  Result valid in every thread.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();  // protect smem reuse across consecutive calls
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  T r = (lane < nw) ? smem[lane] : T(0);
+  r = wave_sum(r);
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ T block_max(T v, T* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  T r = smem[lane < nw ? lane : 0];
+  r = wave_max(r);
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// MFMA abstraction.  One wave computes a TM x TN tile, consuming TK of the
+// contraction per instruction.  Lane l supplies A[row = l % TM][k = l / TM]
+// and B[k = l / TN][col = l % TN]; accumulator register r of lane l holds
+// C[acc_row(l, r)][acc_col(l)].
+// ---------------------------------------------------------------------------
+template <typename T>
+struct Mma;
+
+template <>
+struct Mma<float> {
+  static constexpr int TM = 32, TN = 32, TK = 2, NACC = 16;
+  typedef float Acc __attribute__((ext_vector_type(16)));
+  __device__ static __forceinline__ Acc mma(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ int acc_row(int lane, int r) {
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  }
+  __device__ static __forceinline__ int acc_col(int lane) { return lane & 31; }
+};
+
+template <>
+struct Mma<double> {
+  static constexpr int TM = 16, TN = 16, TK = 4, NACC = 4;
+  typedef double Acc __attribute__((ext_vector_type(4)));
+  __device__ static __forceinline__ Acc mma(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ int acc_row(int lane, int r) {
+    return (lane >> 4) + 4 * r;
+  }
+  __device__ static __forceinline__ int acc_col(int lane) { return lane & 15; }
+};
+
+// ---------------------------------------------------------------------------
+// math helpers that pick the right precision overload
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T hb_exp(T x);
+template <> __device__ __forceinline__ float hb_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double hb_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T hb_log(T x);
+template <> __device__ __forceinline__ float hb_log<float>(float x) { return logf(x); }
+template <> __device__ __forceinline__ double hb_log<double>(double x) { return log(x); }
+template <typename T> __device__ __forceinline__ T hb_sqrt(T x);
+template <> __device__ __forceinline__ float hb_sqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double hb_sqrt<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T hb_abs(T x) { return x < T(0) ? -x : x; }
+template <typename T> __device__ __forceinline__ T hb_sign(T x) {
+  return x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0));
+}
+template <typename T> __device__ __forceinline__ T hb_log1p(T x);
+template <> __device__ __forceinline__ float hb_log1p<float>(float x) { return log1pf(x); }
+template <> __device__ __forceinline__ double hb_log1p<double>(double x) { return log1p(x); }
+template <typename T> __device__ __forceinline__ T hb_tanh(T x);
+template <> __device__ __forceinline__ float hb_tanh<float>(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ double hb_tanh<double>(double x) { return tanh(x); }
+template <typename T> __device__ __forceinline__ T hb_lgamma(T x);
+template <> __device__ __forceinline__ float hb_lgamma<float>(float x) { return lgammaf(x); }
+template <> __device__ __forceinline__ double hb_lgamma<double>(double x) { return lgamma(x); }
+template <typename T> __device__ __forceinline__ T hb_pow(T x, T y);
+template <> __device__ __forceinline__ float hb_pow<float>(float x, float y) { return powf(x, y); }
+template <> __device__ __forceinline__ double hb_pow<double>(double x, double y) { return pow(x, y); }
+
+// numerically stable softplus log(1+e^x) (tf.nn.softplus)
+template <typename T>
+__device__ __forceinline__ T hb_softplus(T x) {
+  return (x > T(0) ? x : T(0)) + hb_log1p(hb_exp(-hb_abs(x)));
+}
+template <typename T>
+__device__ __forceinline__ T hb_sigmoid(T x) {
+  if (x >= T(0)) {
+    return T(1) / (T(1) + hb_exp(-x));
+  } else {
+    T e = hb_exp(x);
+    return e / (T(1) + e);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// xoroshiro128+ per-lane generator.  The state array holds two uint64 per
+// lane, structure-of-arrays: s0[nlanes] then s1[nlanes] (coalesced).
+// ---------------------------------------------------------------------------
+struct HbRng {
+  uint64_t s0, s1;
+  __device__ __forceinline__ uint64_t next() {
+    const uint64_t a = s0;
+    uint64_t b = s1;
+    const uint64_t r = a + b;
+    b ^= a;
+    s0 = ((a << 24) | (a >> 40)) ^ b ^ (b << 16);
+    s1 = (b << 37) | (b >> 27);
+    return r;
+  }
+  // uniform in (0, 1]
+  __device__ __forceinline__ double uniform_pos() {
+    return ((double)(next() >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+  }
+  // uniform in [0, 1)
+  __device__ __forceinline__ double uniform() {
+    return (double)(next() >> 11) * (1.0 / 9007199254740992.0);
+  }
+  // a pair of independent standard normals (Box-Muller, evaluated in double
+  // so the f32 and f64 instantiations draw the same variates from one state).
+  __device__ __forceinline__ void normal2(double& z0, double& z1) {
+    const double u1 = uniform_pos();
+    const double u2 = uniform();
+    const double r = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    z0 = r * cs;
+    z1 = r * sn;
+  }
+};
+
+__host__ __device__ static inline uint64_t hb_splitmix64(uint64_t& x) {
+  uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}

@@ -1,0 +1,515 @@
+// Generic tensor plumbing kernels: n-ary broadcast elementwise, reductions,
+// strided copies, row gather, small matrix utilities.
+//
+// These replace the ~10^2 tiny TensorFlow elementwise ops the reference builds
+// per step; they are launch-bound at the sizes on the path and
+// are written for correctness + coalescing, not for a roofline.
+#include "common.cuh"
+#include "../../include/henbun_hip.h"
+
+// ---------------------------------------------------------------------------
+// n-ary broadcast elementwise
+// ---------------------------------------------------------------------------
+struct EwArgs {
+  int ndim;
+  int nin, nout;
+  int op;
+  long n;
+  int shape[HB_MAX_DIMS];
+  long istride[4][HB_MAX_DIMS];
+  const void* in[4];
+  void* out[3];
+  double p[4];
+};
+
+template <typename T>
+__device__ __forceinline__ T hb_digamma(T x) {
+  // recurrence up to x >= 6, then asymptotic series
+  T r = T(0);
+  while (x < T(6)) {
+    r -= T(1) / x;
+    x += T(1);
+  }
+  const T f = T(1) / (x * x);
+  return r + hb_log(x) - T(0.5) / x -
+         f * (T(1.0 / 12) - f * (T(1.0 / 120) - f * (T(1.0 / 252) - f * (T(1.0 / 240) - f * T(1.0 / 132)))));
+}
+
+template <typename T>
+__device__ __forceinline__ void ew_apply(int op, T a, T b, T c, T d, const double* p,
+                                         T& o0, T& o1, T& o2) {
+  switch (op) {
+    // ---- unary ----
+    case HB_EW_NEG: o0 = -a; break;
+    case HB_EW_EXP: o0 = hb_exp(a); break;
+    case HB_EW_LOG: o0 = hb_log(a); break;
+    case HB_EW_SQRT: o0 = hb_sqrt(a); break;
+    case HB_EW_SQUARE: o0 = a * a; break;
+    case HB_EW_ABS: o0 = hb_abs(a); break;
+    case HB_EW_SIGN: o0 = hb_sign(a); break;
+    case HB_EW_SIGMOID: o0 = hb_sigmoid(a); break;
+    case HB_EW_RELU: o0 = a > T(0) ? a : T(0); break;
+    case HB_EW_SOFTPLUS: o0 = hb_softplus(a); break;
+    case HB_EW_TANH: o0 = hb_tanh(a); break;
+    case HB_EW_RECIP: o0 = T(1) / a; break;
+    case HB_EW_RSQRT: o0 = T(1) / hb_sqrt(a); break;
+    case HB_EW_STEP: o0 = a > T(0) ? T(1) : T(0); break;
+    case HB_EW_AFFINE: o0 = T(p[0]) * a + T(p[1]); break;
+    case HB_EW_CLIP: o0 = a < T(p[0]) ? T(p[0]) : (a > T(p[1]) ? T(p[1]) : a); break;
+    case HB_EW_CLIPMASK: o0 = (a >= T(p[0]) && a <= T(p[1])) ? T(1) : T(0); break;
+    case HB_EW_LGAMMA: o0 = hb_lgamma(a); break;
+    case HB_EW_POWC: o0 = hb_pow(a, T(p[0])); break;
+    case HB_EW_LOG1P: o0 = hb_log1p(a); break;
+    case HB_EW_COPY: o0 = a; break;
+    case HB_EW_DIGAMMA: o0 = hb_digamma(a); break;
+    // ---- binary ----
+    case HB_EW_ADD: o0 = a + b; break;
+    case HB_EW_SUB: o0 = a - b; break;
+    case HB_EW_MUL: o0 = a * b; break;
+    case HB_EW_DIV: o0 = a / b; break;
+    case HB_EW_MAX: o0 = a > b ? a : b; break;
+    case HB_EW_MIN: o0 = a < b ? a : b; break;
+    case HB_EW_POW: o0 = hb_pow(a, b); break;
+    case HB_EW_GT: o0 = a > b ? T(1) : T(0); break;
+    case HB_EW_GE: o0 = a >= b ? T(1) : T(0); break;
+    case HB_EW_LT: o0 = a < b ? T(1) : T(0); break;
+    case HB_EW_LE: o0 = a <= b ? T(1) : T(0); break;
+    case HB_EW_EQ: o0 = a == b ? T(1) : T(0); break;
+    case HB_EW_SIGMOID_GRAD: o0 = b * a * (T(1) - a); break;           // a = y, b = g
+    case HB_EW_TANH_GRAD: o0 = b * (T(1) - a * a); break;              // a = y, b = g
+    case HB_EW_RELU_GRAD: o0 = a > T(0) ? b : T(0); break;             // a = x, b = g
+    case HB_EW_SOFTPLUS_GRAD: o0 = b * hb_sigmoid(a); break;           // a = x, b = g
+    case HB_EW_CLIP_GRAD: o0 = (a >= T(p[0]) && a <= T(p[1])) ? b : T(0); break;  // a = x, b = g
+    // ---- ternary ----
+    case HB_EW_WHERE: o0 = a != T(0) ? b : c; break;
+    case HB_EW_FMA: o0 = a * b + c; break;
+    case HB_EW_GAUSS_LOGPDF: {
+      // densities.gaussian(x=a, mu=b, var=c)   (reference densities.py:25-27)
+      const T dlt = b - a;
+      o0 = T(-0.91893853320467274178) - T(0.5) * hb_log(c) - T(0.5) * dlt * dlt / c;
+    } break;
+    // ---- 4 in, 3 out ----
+    case HB_EW_GAUSS_LOGPDF_GRAD: {
+      // a = x, b = mu, c = var, d = upstream g
+      const T dlt = b - a;  // mu - x
+      const T iv = T(1) / c;
+      o0 = d * dlt * iv;                                   // d/dx
+      o1 = -d * dlt * iv;                                  // d/dmu
+      o2 = d * (T(-0.5) * iv + T(0.5) * dlt * dlt * iv * iv);  // d/dvar
+    } break;
+    default: o0 = T(0); break;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += stride) {
+    long off[4] = {0, 0, 0, 0};
+    long r = i;
+#pragma unroll
+    for (int d = HB_MAX_DIMS - 1; d >= 0; --d) {
+      if (d < A.ndim) {
+        const long q = r / A.shape[d];
+        const long c = r - q * A.shape[d];
+        r = q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) off[k] += c * A.istride[k][d];
+      }
+    }
+    T v[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < A.nin) v[k] = ((const T*)A.in[k])[off[k]];
+    T o0 = T(0), o1 = T(0), o2 = T(0);
+    ew_apply<T>(A.op, v[0], v[1], v[2], v[3], A.p, o0, o1, o2);
+    ((T*)A.out[0])[i] = o0;
+    if (A.nout > 1) ((T*)A.out[1])[i] = o1;
+    if (A.nout > 2) ((T*)A.out[2])[i] = o2;
+  }
+}
+
+template <typename T>
+static int ew_launch(int op, int nin, const void* const* in, const long* istrides, int nout,
+                     void* const* out, int ndim, const long* shape, const double* params,
+                     hipStream_t stream) {
+  HB_REQUIRE(nin >= 1 && nin <= 4, "hb_ewise: nin=%d out of range", nin);
+  HB_REQUIRE(nout >= 1 && nout <= 3, "hb_ewise: nout=%d out of range", nout);
+  HB_REQUIRE(ndim >= 0 && ndim <= HB_MAX_DIMS, "hb_ewise: ndim=%d out of range", ndim);
+  EwArgs A;
+  A.op = op;
+  A.nin = nin;
+  A.nout = nout;
+  long n = 1;
+  // collapse dims: merge dim d into d-1 when every input is mergeable
+  // (stride[d-1] == stride[d]*shape[d], which also covers 0/0 broadcast).
+  long shp[HB_MAX_DIMS];
+  long st[4][HB_MAX_DIMS];
+  int nd = 0;
+  for (int d = 0; d < ndim; ++d) {
+    HB_REQUIRE(shape[d] >= 0, "hb_ewise: negative dim");
+    n *= shape[d];
+    if (shape[d] == 1) continue;  // size-1 dims carry no information
+    bool merge = nd > 0;
+    if (merge) {
+      for (int k = 0; k < nin; ++k)
+        if (st[k][nd - 1] != istrides[k * ndim + d] * shape[d]) merge = false;
+    }
+    if (merge) {
+      shp[nd - 1] *= shape[d];
+      for (int k = 0; k < nin; ++k) st[k][nd - 1] = istrides[k * ndim + d];
+    } else {
+      shp[nd] = shape[d];
+      for (int k = 0; k < nin; ++k) st[k][nd] = istrides[k * ndim + d];
+      ++nd;
+    }
+  }
+  if (n == 0) return 0;
+  A.ndim = nd;
+  A.n = n;
+  for (int d = 0; d < HB_MAX_DIMS; ++d) {
+    A.shape[d] = d < nd ? (int)shp[d] : 1;
+    for (int k = 0; k < 4; ++k) A.istride[k][d] = (k < nin && d < nd) ? st[k][d] : 0;
+  }
+  for (int k = 0; k < 4; ++k) A.in[k] = k < nin ? in[k] : nullptr;
+  for (int k = 0; k < 3; ++k) A.out[k] = k < nout ? out[k] : nullptr;
+  for (int k = 0; k < 4; ++k) A.p[k] = params ? params[k] : 0.0;
+  hipLaunchKernelGGL(ew_kernel<T>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, A);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hb_ewise_f32(int op, int nin, const void* const* in, const long* istrides, int nout,
+                            void* const* out, int ndim, const long* shape, const double* params,
+                            void* stream) {
+  return ew_launch<float>(op, nin, in, istrides, nout, out, ndim, shape, params, (hipStream_t)stream);
+}
+extern "C" int hb_ewise_f64(int op, int nin, const void* const* in, const long* istrides, int nout,
+                            void* const* out, int ndim, const long* shape, const double* params,
+                            void* stream) {
+  return ew_launch<double>(op, nin, in, istrides, nout, out, ndim, shape, params, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// reductions over the middle axis of a contiguous [K1, R, K2] view
+// ---------------------------------------------------------------------------
+template <typename T, int OP>
+__device__ __forceinline__ T red_combine(T a, T b) {
+  if (OP == HB_RED_SUM) return a + b;
+  return a > b ? a : b;
+}
+template <typename T, int OP>
+__device__ __forceinline__ T red_identity() {
+  if (OP == HB_RED_SUM) return T(0);
+  return -INFINITY;
+}
+
+// K2 == 1: one block per (k1, split); threads stride over R (coalesced).
+template <typename T, int OP>
+__global__ void __launch_bounds__(256) reduce_rows_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                          long R, int S) {
+  __shared__ T smem[16];
+  const long k1 = blockIdx.x;
+  const int s = blockIdx.y;
+  const long chunk = (R + S - 1) / S;
+  const long beg = s * chunk;
+  long end = beg + chunk;
+  if (end > R) end = R;
+  const T* row = in + k1 * R;
+  T acc = red_identity<T, OP>();
+  for (long i = beg + threadIdx.x; i < end; i += blockDim.x) acc = red_combine<T, OP>(acc, row[i]);
+  if (OP == HB_RED_SUM)
+    acc = block_sum(acc, smem);
+  else
+    acc = block_max(acc, smem);
+  if (threadIdx.x == 0) out[k1 * S + s] = acc;
+}
+
+// K2 > 1: block = 64 columns x 4 row-lanes; grid (ceil(K2/64), K1, S).
+template <typename T, int OP>
+__global__ void __launch_bounds__(256) reduce_cols_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                          long K1, long R, long K2, int S) {
+  __shared__ T smem[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const long col = (long)blockIdx.x * 64 + cx;
+  const long k1 = blockIdx.y;
+  const int s = blockIdx.z;
+  const long chunk = (R + S - 1) / S;
+  const long beg = s * chunk;
+  long end = beg + chunk;
+  if (end > R) end = R;
+  T acc = red_identity<T, OP>();
+  if (col < K2) {
+    const T* base = in + k1 * R * K2 + col;
+    for (long r = beg + ry; r < end; r += 4) acc = red_combine<T, OP>(acc, base[r * K2]);
+  }
+  smem[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < K2) {
+    T v = smem[0][cx];
+    v = red_combine<T, OP>(v, smem[1][cx]);
+    v = red_combine<T, OP>(v, smem[2][cx]);
+    v = red_combine<T, OP>(v, smem[3][cx]);
+    // partial layout [S, K1, K2] so that a second pass is again a column reduce
+    out[((long)s * K1 + k1) * K2 + col] = v;
+  }
+}
+
+template <typename T, int OP>
+static int reduce_launch(const T* in, T* out, long K1, long R, long K2, T* ws, long ws_elems,
+                         hipStream_t stream) {
+  if (K1 * K2 == 0) return 0;
+  if (R == 0) {
+    // empty reduction: fill identity (sum -> 0) through a trivial launch
+    hipMemsetAsync(out, 0, sizeof(T) * K1 * K2, stream);
+    return 0;
+  }
+  if (K2 == 1) {
+    int S = 1;
+    if (K1 < 64 && R > 16384) {
+      S = (int)(R / 4096);
+      long cap = 256 / (K1 > 0 ? K1 : 1);
+      if (cap < 1) cap = 1;
+      if (S > cap) S = (int)cap;
+      if ((long)S * K1 > ws_elems) S = 1;
+    }
+    if (S > 1) {
+      HB_REQUIRE(ws != nullptr, "hb_reduce: workspace required");
+      hipLaunchKernelGGL((reduce_rows_kernel<T, OP>), dim3(K1, S), dim3(256), 0, stream, in, ws, R, S);
+      HB_LAUNCH_CHECK();
+      hipLaunchKernelGGL((reduce_rows_kernel<T, OP>), dim3(K1, 1), dim3(256), 0, stream, ws, out, (long)S, 1);
+    } else {
+      hipLaunchKernelGGL((reduce_rows_kernel<T, OP>), dim3(K1, 1), dim3(256), 0, stream, in, out, R, 1);
+    }
+    HB_LAUNCH_CHECK();
+    return 0;
+  }
+  const int gx = hb_cdiv(K2, 64);
+  int S = 1;
+  const long blocks = (long)gx * K1;
+  if (blocks < 128 && R > 2048) {
+    S = (int)(R / 512);
+    long cap = 512 / blocks;
+    if (cap < 1) cap = 1;
+    if (S > cap) S = (int)cap;
+    if ((long)S * K1 * K2 > ws_elems) S = 1;
+  }
+  HB_REQUIRE(K1 <= 65535, "hb_reduce: K1=%ld too large for grid.y", K1);
+  if (S > 1) {
+    HB_REQUIRE(ws != nullptr, "hb_reduce: workspace required");
+    hipLaunchKernelGGL((reduce_cols_kernel<T, OP>), dim3(gx, K1, S), dim3(256), 0, stream, in, ws, K1, R, K2, S);
+    HB_LAUNCH_CHECK();
+    // second pass: [S, K1*K2] column reduce over S
+    const long KK = K1 * K2;
+    hipLaunchKernelGGL((reduce_cols_kernel<T, OP>), dim3(hb_cdiv(KK, 64), 1, 1), dim3(256), 0, stream, ws, out,
+                       1L, (long)S, KK, 1);
+  } else {
+    hipLaunchKernelGGL((reduce_cols_kernel<T, OP>), dim3(gx, K1, 1), dim3(256), 0, stream, in, out, K1, R, K2, 1);
+  }
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static int reduce_dispatch(int op, const T* in, T* out, long K1, long R, long K2, T* ws, long ws_elems,
+                           hipStream_t stream) {
+  HB_REQUIRE(K1 >= 0 && R >= 0 && K2 >= 0, "hb_reduce: negative extent");
+  if (op == HB_RED_SUM) return reduce_launch<T, HB_RED_SUM>(in, out, K1, R, K2, ws, ws_elems, stream);
+  if (op == HB_RED_MAX) return reduce_launch<T, HB_RED_MAX>(in, out, K1, R, K2, ws, ws_elems, stream);
+  HB_REQUIRE(false, "hb_reduce: unknown op %d", op);
+}
+
+extern "C" int hb_reduce_f32(int op, const float* in, float* out, long K1, long R, long K2, float* ws,
+                             long ws_elems, void* stream) {
+  return reduce_dispatch<float>(op, in, out, K1, R, K2, ws, ws_elems, (hipStream_t)stream);
+}
+extern "C" int hb_reduce_f64(int op, const double* in, double* out, long K1, long R, long K2, double* ws,
+                             long ws_elems, void* stream) {
+  return reduce_dispatch<double>(op, in, out, K1, R, K2, ws, ws_elems, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// strided n-d copy (transpose / slice / broadcast / concat placement)
+// ---------------------------------------------------------------------------
+struct CopyArgs {
+  int ndim;
+  long n;
+  int shape[HB_MAX_DIMS];
+  long is[HB_MAX_DIMS], os[HB_MAX_DIMS];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) copy_nd_kernel(const T* __restrict__ in, T* __restrict__ out, CopyArgs A) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += stride) {
+    long r = i, io = 0, oo = 0;
+#pragma unroll
+    for (int d = HB_MAX_DIMS - 1; d >= 0; --d) {
+      if (d < A.ndim) {
+        const long q = r / A.shape[d];
+        const long c = r - q * A.shape[d];
+        r = q;
+        io += c * A.is[d];
+        oo += c * A.os[d];
+      }
+    }
+    out[oo] = in[io];
+  }
+}
+
+template <typename T>
+static int copy_nd_launch(const T* in, const long* istr, T* out, const long* ostr, int ndim, const long* shape,
+                          hipStream_t stream) {
+  HB_REQUIRE(ndim >= 0 && ndim <= HB_MAX_DIMS, "hb_copy_nd: ndim=%d out of range", ndim);
+  CopyArgs A;
+  long n = 1;
+  int nd = 0;
+  for (int d = 0; d < ndim; ++d) {
+    HB_REQUIRE(shape[d] >= 0, "hb_copy_nd: negative dim");
+    n *= shape[d];
+    if (shape[d] == 1) continue;
+    if (nd > 0 && A.is[nd - 1] == istr[d] * shape[d] && A.os[nd - 1] == ostr[d] * shape[d]) {
+      A.shape[nd - 1] *= (int)shape[d];
+      A.is[nd - 1] = istr[d];
+      A.os[nd - 1] = ostr[d];
+    } else {
+      A.shape[nd] = (int)shape[d];
+      A.is[nd] = istr[d];
+      A.os[nd] = ostr[d];
+      ++nd;
+    }
+  }
+  if (n == 0) return 0;
+  for (int d = nd; d < HB_MAX_DIMS; ++d) {
+    A.shape[d] = 1;
+    A.is[d] = A.os[d] = 0;
+  }
+  A.ndim = nd;
+  A.n = n;
+  hipLaunchKernelGGL(copy_nd_kernel<T>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, in, out, A);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hb_copy_nd_f32(const float* in, const long* istr, float* out, const long* ostr, int ndim,
+                              const long* shape, void* stream) {
+  return copy_nd_launch<float>(in, istr, out, ostr, ndim, shape, (hipStream_t)stream);
+}
+extern "C" int hb_copy_nd_f64(const double* in, const long* istr, double* out, const long* ostr, int ndim,
+                              const long* shape, void* stream) {
+  return copy_nd_launch<double>(in, istr, out, ostr, ndim, shape, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// fill
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) fill_kernel(T* out, long n, T v) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = v;
+}
+extern "C" int hb_fill_f32(float* out, long n, double v, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(fill_kernel<float>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, out, n, (float)v);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_fill_f64(double* out, long n, double v, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(fill_kernel<double>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, out, n, v);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// K0: device-resident minibatch gather  dst[i,:] = src[perm[idx[i]],:]
+// (replaces the host fancy-index + H2D of reference param.py:733-739)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) gather_rows_kernel(const T* __restrict__ src, const long* __restrict__ idx,
+                                                          const long* __restrict__ perm, T* __restrict__ dst,
+                                                          long n, long row, long nsrc, int* __restrict__ err) {
+  const long total = n * row;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long r = i / row, c = i - r * row;
+    long j = idx[r];
+    if (perm) j = perm[j];
+    if (j < 0 || j >= nsrc) {
+      if (err) *err = 1;
+      dst[i] = T(0);
+    } else {
+      dst[i] = src[j * row + c];
+    }
+  }
+}
+extern "C" int hb_gather_rows_f32(const float* src, long nsrc, long row, const long* idx, const long* perm, long n,
+                                  float* dst, int* err, void* stream) {
+  HB_REQUIRE(n >= 0 && row >= 0 && nsrc >= 0, "hb_gather_rows: negative extent");
+  if (n * row == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(hb_stream_grid(n * row, 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, idx, perm, dst, n, row, nsrc, err);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_gather_rows_f64(const double* src, long nsrc, long row, const long* idx, const long* perm, long n,
+                                  double* dst, int* err, void* stream) {
+  HB_REQUIRE(n >= 0 && row >= 0 && nsrc >= 0, "hb_gather_rows: negative extent");
+  if (n * row == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel<double>, dim3(hb_stream_grid(n * row, 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, idx, perm, dst, n, row, nsrc, err);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// small matrix utilities on batched row-major [B, R, C]
+// ---------------------------------------------------------------------------
+// mode 0: band part   out = in where (lower<0 || i-j<=lower) && (upper<0 || j-i<=upper) else 0
+// mode 1: add alpha to the diagonal (out = in + alpha*I)
+// mode 2: Cholesky-gradient Phi: lower triangle with halved diagonal
+// mode 3: symmetrise 0.5*(in + in^T) (square only)
+template <typename T>
+__global__ void __launch_bounds__(256) matutil_kernel(const T* __restrict__ in, T* __restrict__ out, long B, long R,
+                                                      long C, int mode, long lower, long upper, T alpha) {
+  const long total = B * R * C;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long b = t / (R * C);
+    const long rem = t - b * R * C;
+    const long i = rem / C, j = rem - i * C;
+    T v = in[t];
+    if (mode == 0) {
+      const bool keep = (lower < 0 || i - j <= lower) && (upper < 0 || j - i <= upper);
+      v = keep ? v : T(0);
+    } else if (mode == 1) {
+      if (i == j) v += alpha;
+    } else if (mode == 2) {
+      v = (i > j) ? v : (i == j ? T(0.5) * v : T(0));
+    } else if (mode == 3) {
+      v = T(0.5) * (v + in[b * R * C + j * C + i]);
+    }
+    out[t] = v;
+  }
+}
+template <typename T>
+static int matutil_launch(const T* in, T* out, long B, long R, long C, int mode, long lower, long upper, double alpha,
+                          hipStream_t stream) {
+  HB_REQUIRE(B >= 0 && R >= 0 && C >= 0, "hb_matutil: negative extent");
+  HB_REQUIRE(mode >= 0 && mode <= 3, "hb_matutil: bad mode %d", mode);
+  HB_REQUIRE(mode != 3 || (R == C && in != out), "hb_matutil: symmetrise needs square, out-of-place");
+  const long n = B * R * C;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(matutil_kernel<T>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, in, out, B, R, C, mode,
+                     lower, upper, (T)alpha);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_matutil_f32(const float* in, float* out, long B, long R, long C, int mode, long lower, long upper,
+                              double alpha, void* stream) {
+  return matutil_launch<float>(in, out, B, R, C, mode, lower, upper, alpha, (hipStream_t)stream);
+}
+extern "C" int hb_matutil_f64(const double* in, double* out, long B, long R, long C, int mode, long lower, long upper,
+                              double alpha, void* stream) {
+  return matutil_launch<double>(in, out, B, R, C, mode, lower, upper, alpha, (hipStream_t)stream);
+}

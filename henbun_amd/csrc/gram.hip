@@ -1,0 +1,195 @@
+// K3: stationary Gram matrices and their VJP.
+//
+// Reference: Henbun/gp/kernels.py:54-84 (square_dist: |a|^2+|b|^2-2ab^T on
+// X/ell), :110-111 (UnitRBF.K = exp(-r2/2)), :122-131 (UnitCsymRBF).  The
+// squared distance is formed directly as sum_d((x_id-x2_jd)/ell_d)^2: same
+// value, better conditioned, inside the reference's own atol.
+// These kernels serve the small M x M (and test-sized) Grams; the M x n block
+// on the hot path is built inside sgp.hip and never written to memory.
+#include "common.cuh"
+#include "../../include/henbun_hip.h"
+
+template <typename T>
+__device__ __forceinline__ T gram_value(int kind, const T* __restrict__ xi, const T* __restrict__ xj,
+                                        const T* __restrict__ ell, long dl, long d) {
+  T r2 = T(0), r2m = T(0);
+  for (long k = 0; k < d; ++k) {
+    const T il = T(1) / ell[dl == 1 ? 0 : k];
+    const T a = xi[k] * il, b = xj[k] * il;
+    r2 += (a - b) * (a - b);
+    r2m += (a + b) * (a + b);
+  }
+  T v = hb_exp(T(-0.5) * r2);
+  if (kind == HB_KERN_CSYM_RBF) v += hb_exp(T(-0.5) * r2m);
+  return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gram_fwd_kernel(int kind, const T* __restrict__ X, long sX,
+                                                       const T* __restrict__ X2, long sX2, const T* __restrict__ ell,
+                                                       long dl, T* __restrict__ K, long B, long n, long n2, long d) {
+  const long total = B * n * n2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long b = t / (n * n2);
+    const long rem = t - b * n * n2;
+    const long i = rem / n2, j = rem - i * n2;
+    K[t] = gram_value<T>(kind, X + b * sX + i * d, X2 + b * sX2 + j * d, ell, dl, d);
+  }
+}
+
+template <typename T>
+static int gram_fwd(int kind, const T* X, long sX, const T* X2, long sX2, const T* ell, long dl, T* K, long B, long n,
+                    long n2, long d, hipStream_t stream) {
+  HB_REQUIRE(kind == HB_KERN_RBF || kind == HB_KERN_CSYM_RBF, "hb_gram_fwd: unknown kernel kind %d", kind);
+  HB_REQUIRE(B >= 0 && n >= 0 && n2 >= 0 && d >= 1, "hb_gram_fwd: bad extents");
+  HB_REQUIRE(dl == 1 || dl == d, "hb_gram_fwd: lengthscales must have 1 or d=%ld entries, got %ld", d, dl);
+  HB_REQUIRE(X && X2 && ell && K, "hb_gram_fwd: NULL pointer");
+  const long total = B * n * n2;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(gram_fwd_kernel<T>, dim3(hb_stream_grid(total, 256)), dim3(256), 0, stream, kind, X, sX, X2, sX2,
+                     ell, dl, K, B, n, n2, d);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_gram_fwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
+                               long dl, float* K, long B, long n, long n2, long d, void* stream) {
+  return gram_fwd<float>(kind, X, sX, X2, sX2, ell, dl, K, B, n, n2, d, (hipStream_t)stream);
+}
+extern "C" int hb_gram_fwd_f64(int kind, const double* X, long sX, const double* X2, long sX2, const double* ell,
+                               long dl, double* K, long B, long n, long n2, long d, void* stream) {
+  return gram_fwd<double>(kind, X, sX, X2, sX2, ell, dl, K, B, n, n2, d, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// VJP.  With a = x/ell, b = x2/ell, E- = exp(-|a-b|^2/2), E+ = exp(-|a+b|^2/2):
+//   dK/dx_k  = [-(a_k-b_k) E-  - (a_k+b_k) E+] / ell_k
+//   dK/dx2_k = [+(a_k-b_k) E-  - (a_k+b_k) E+] / ell_k
+//   dK/dell_k= [ (a_k-b_k)^2 E- + (a_k+b_k)^2 E+] / ell_k   (summed over k when dl == 1)
+// (E+ only for the cylindrically symmetric kernel.)
+// One block per (b, row) of the side being differentiated; threads stride the
+// other side; deterministic block reductions, no atomics.
+// ---------------------------------------------------------------------------
+#define HB_GRAM_MAXD 8
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const T* __restrict__ X2, long sX2,
+                     const T* __restrict__ ell, long dl, const T* __restrict__ Kbar, T* __restrict__ out,
+                     T* __restrict__ ell_partial, long n, long n2, long d) {
+  // side 0: block row i of X, loop j over X2; side 1: block row j of X2, loop i over X.
+  __shared__ T smem[16];
+  const long b = blockIdx.y;
+  const long row = blockIdx.x;
+  const long nother = side == 0 ? n2 : n;
+  const T* xs = side == 0 ? X + b * sX + row * d : X2 + b * sX2 + row * d;
+  for (long k0 = 0; k0 < d; k0 += HB_GRAM_MAXD) {
+    T gacc[HB_GRAM_MAXD], lacc[HB_GRAM_MAXD];
+#pragma unroll
+    for (int k = 0; k < HB_GRAM_MAXD; ++k) gacc[k] = lacc[k] = T(0);
+    for (long o = threadIdx.x; o < nother; o += blockDim.x) {
+      const long i = side == 0 ? row : o;
+      const long j = side == 0 ? o : row;
+      const T* xi = X + b * sX + i * d;
+      const T* xj = X2 + b * sX2 + j * d;
+      T r2 = T(0), r2m = T(0);
+      for (long k = 0; k < d; ++k) {
+        const T il = T(1) / ell[dl == 1 ? 0 : k];
+        const T a = xi[k] * il, bb = xj[k] * il;
+        r2 += (a - bb) * (a - bb);
+        r2m += (a + bb) * (a + bb);
+      }
+      const T kb = Kbar[(b * n + i) * n2 + j];
+      const T em = kb * hb_exp(T(-0.5) * r2);
+      const T ep = kind == HB_KERN_CSYM_RBF ? kb * hb_exp(T(-0.5) * r2m) : T(0);
+#pragma unroll
+      for (int k = 0; k < HB_GRAM_MAXD; ++k) {
+        if (k0 + k < d) {
+          const T il = T(1) / ell[dl == 1 ? 0 : k0 + k];
+          const T a = xi[k0 + k] * il, bb = xj[k0 + k] * il;
+          const T dm = a - bb, dp = a + bb;
+          if (side == 0)
+            gacc[k] += (-dm * em - dp * ep) * il;
+          else
+            gacc[k] += (dm * em - dp * ep) * il;
+          lacc[k] += (dm * dm * em + dp * dp * ep) * il;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < HB_GRAM_MAXD; ++k) {
+      if (k0 + k < d) {
+        const T g = block_sum(gacc[k], smem);
+        if (out && threadIdx.x == 0) out[(b * (side == 0 ? n : n2) + row) * d + k0 + k] = g;
+        if (ell_partial) {
+          const T l = block_sum(lacc[k], smem);
+          // partial layout [B*rows, d]; reduced (and folded to dl) afterwards
+          if (threadIdx.x == 0) ell_partial[(b * (side == 0 ? n : n2) + row) * d + k0 + k] = l;
+        }
+      }
+    }
+  }
+}
+
+// ellbar[c] = sum_r partial[r, c (or all columns when dl == 1)]
+template <typename T>
+__global__ void __launch_bounds__(256) gram_ell_finish_kernel(const T* __restrict__ partial, long rows, long d, long dl,
+                                                              T* __restrict__ ellbar) {
+  __shared__ T smem[16];
+  const long c = blockIdx.x;  // < dl
+  T acc = T(0);
+  if (dl == 1) {
+    for (long t = threadIdx.x; t < rows * d; t += blockDim.x) acc += partial[t];
+  } else {
+    for (long r = threadIdx.x; r < rows; r += blockDim.x) acc += partial[r * d + c];
+  }
+  acc = block_sum(acc, smem);
+  if (threadIdx.x == 0) ellbar[c] = acc;
+}
+
+template <typename T>
+static int gram_bwd(int kind, const T* X, long sX, const T* X2, long sX2, const T* ell, long dl, const T* Kbar,
+                    T* Xbar, T* X2bar, T* ellbar, long B, long n, long n2, long d, T* ws, hipStream_t stream) {
+  HB_REQUIRE(kind == HB_KERN_RBF || kind == HB_KERN_CSYM_RBF, "hb_gram_bwd: unknown kernel kind %d", kind);
+  HB_REQUIRE(B >= 0 && n >= 0 && n2 >= 0 && d >= 1, "hb_gram_bwd: bad extents");
+  HB_REQUIRE(dl == 1 || dl == d, "hb_gram_bwd: lengthscales must have 1 or d entries");
+  HB_REQUIRE(X && X2 && ell && Kbar, "hb_gram_bwd: NULL pointer");
+  HB_REQUIRE(!ellbar || ws, "hb_gram_bwd: ellbar needs workspace");
+  HB_REQUIRE(B <= 65535, "hb_gram_bwd: batch too large");
+  if (B == 0) return 0;
+  if (n == 0 || n2 == 0) {
+    if (Xbar && n > 0) HB_HIP(hipMemsetAsync(Xbar, 0, sizeof(T) * B * n * d, stream));
+    if (X2bar && n2 > 0) HB_HIP(hipMemsetAsync(X2bar, 0, sizeof(T) * B * n2 * d, stream));
+    if (ellbar) HB_HIP(hipMemsetAsync(ellbar, 0, sizeof(T) * dl, stream));
+    return 0;
+  }
+  // side 0 pass also produces the lengthscale partials
+  if (Xbar || ellbar) {
+    hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n, B), dim3(256), 0, stream, kind, 0, X, sX, X2, sX2, ell, dl,
+                       Kbar, Xbar, ellbar ? ws : (T*)nullptr, n, n2, d);
+    HB_LAUNCH_CHECK();
+    if (ellbar) {
+      // d(K)/d(ell) = sum lacc (positive sign; see header comment)
+      hipLaunchKernelGGL(gram_ell_finish_kernel<T>, dim3(dl), dim3(256), 0, stream, ws, B * n, d, dl, ellbar);
+      HB_LAUNCH_CHECK();
+    }
+  }
+  if (X2bar) {
+    hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n2, B), dim3(256), 0, stream, kind, 1, X, sX, X2, sX2, ell, dl,
+                       Kbar, X2bar, (T*)nullptr, n, n2, d);
+    HB_LAUNCH_CHECK();
+  }
+  return 0;
+}
+extern "C" int hb_gram_bwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
+                               long dl, const float* Kbar, float* Xbar, float* X2bar, float* ellbar, long B, long n,
+                               long n2, long d, float* ws, void* stream) {
+  return gram_bwd<float>(kind, X, sX, X2, sX2, ell, dl, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws,
+                         (hipStream_t)stream);
+}
+extern "C" int hb_gram_bwd_f64(int kind, const double* X, long sX, const double* X2, long sX2, const double* ell,
+                               long dl, const double* Kbar, double* Xbar, double* X2bar, double* ellbar, long B,
+                               long n, long n2, long d, double* ws, void* stream) {
+  return gram_bwd<double>(kind, X, sX, X2, sX2, ell, dl, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws,
+                          (hipStream_t)stream);
+}

@@ -1,0 +1,542 @@
+// K5/K6: fused sparse-GP conditional  A = L^{-1} K(z,x),  f = u A + sqrt|1 - colsum(A^2)| eps
+// and its VJP -- the M^2 n contraction that dominates the ELBO step.
+//
+// Reference: Henbun/gp/gp.py:99-143 (SparseGP.samples), :146-162
+// (_effective_LT = matrix_triangular_solve(Lm, K(z,x))), :177-189
+// (_additional_cov 'diagonal'), with K from gp/kernels.py:54-111.
+//
+// Formulation.  W = L^{-1} is formed once per step (linalg.hip, the reference's
+// own batched branch does the same, gp/gp.py:169), so the solve becomes the
+// triangular GEMM A = W Kmn.  The RBF block Kmn is synthesised in the B-operand
+// loader from x and z (exp on the VALU while the MFMA pipe runs) and is never
+// written to memory.  W is lower triangular, so output row-block rb only
+// contracts over k < (rb+1)*64; row-blocks rb and nRB-1-rb are paired in one
+// workgroup so every workgroup does the same (nRB+1)*64-deep work:
+// the kernel executes M^2 n flops, not 2 M^2 n.
+//
+// Algorithmic work per launch (E experts): flops = E * M^2 * n (fwd A),
+// E * M^2 * n (Kbar = W^T Abar), E * M^2 * n (Lbar = -tril(Kbar A^T)).
+// The roofline that bounds them is the f32 MFMA peak (v_mfma_f32_32x32x2_f32).
+#include "common.cuh"
+#include "gemm_tile.cuh"
+#include "rng_pairs.cuh"
+#include "../../include/henbun_hip.h"
+
+#define SGP_BM 64
+#define SGP_BN 128
+#define SGP_DREG 4  // input dims held in registers by the operand loaders
+
+// provided by linalg.hip / elementwise.hip (same shared object)
+extern "C" int hb_matmul_f32(const float*, const float*, float*, long, long, long, long, long, long, long, long, long,
+                             long, int, int, double, double, const float*, long, int, int, float*, long, void*);
+extern "C" int hb_matmul_f64(const double*, const double*, double*, long, long, long, long, long, long, long, long,
+                             long, long, int, int, double, double, const double*, long, int, int, double*, long,
+                             void*);
+
+template <typename T>
+struct SgpArgs {
+  const T* x;   // [E?, n, d]
+  long sx;      // expert stride of x (0 = shared)
+  const T* z;   // [E, M, d]
+  const T* ell; // [E, dl]
+  long dl;
+  const T* W;   // [E, M, M]
+  const T* u;   // [E, P, M]
+  T* A;         // [E, M, n]
+  long n, M, d, P;
+};
+
+// RBF value between inducing point zk and data point (registers or memory)
+template <typename T>
+__device__ __forceinline__ T rbf_pair(const T* __restrict__ zk, const T* __restrict__ xj, const T* __restrict__ ell,
+                                      long dl, long d) {
+  T r2 = T(0);
+  for (long q = 0; q < d; ++q) {
+    const T t = (zk[q] - xj[q]) / ell[dl == 1 ? 0 : q];
+    r2 += t * t;
+  }
+  return hb_exp(T(-0.5) * r2);
+}
+
+// ---------------------------------------------------------------------------
+// forward: A = W K(z,x)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
+  typedef TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2> G;
+  __shared__ T lds[G::LDS_ELEMS];
+  const long e = blockIdx.z;
+  const T* x = a.x + e * a.sx;
+  const T* z = a.z + e * a.M * a.d;
+  const T* ell = a.ell + e * a.dl;
+  const T* W = a.W + e * a.M * a.M;
+  T* A = a.A + e * a.M * a.n;
+  const long col0 = (long)blockIdx.x * SGP_BN;
+  const int nRB = (int)((a.M + SGP_BM - 1) / SGP_BM);
+
+  // this thread's operand column is fixed across k-steps (256 % SGP_BN == 0)
+  const long jcol = col0 + (threadIdx.x % SGP_BN);
+  const bool jok = jcol < a.n;
+  const bool dreg = a.d <= SGP_DREG;
+  T xr[SGP_DREG], il[SGP_DREG];
+#pragma unroll
+  for (int q = 0; q < SGP_DREG; ++q) {
+    xr[q] = (dreg && jok && q < a.d) ? x[jcol * a.d + q] : T(0);
+    il[q] = (dreg && q < a.d) ? T(1) / ell[a.dl == 1 ? 0 : q] : T(0);
+  }
+
+  for (int half = 0; half < 2; ++half) {
+    const int rb = half == 0 ? (int)blockIdx.y : nRB - 1 - (int)blockIdx.y;
+    if (half == 1 && rb <= (int)blockIdx.y) break;  // odd count: middle block handled once
+    const long row0 = (long)rb * SGP_BM;
+    long kend = row0 + SGP_BM;
+    if (kend > a.M) kend = a.M;
+    G g;
+    g.zero();
+    auto fa = [&](int m, long k) -> T {
+      const long r = row0 + m;
+      return (r < a.M && k <= r) ? W[r * a.M + k] : T(0);
+    };
+    auto fb = [&](long k, int nn) -> T {
+      if (!jok) return T(0);
+      if (dreg) {
+        T r2 = T(0);
+#pragma unroll
+        for (int q = 0; q < SGP_DREG; ++q) {
+          if (q < a.d) {
+            const T t = (z[k * a.d + q] - xr[q]) * il[q];
+            r2 += t * t;
+          }
+        }
+        return hb_exp(T(-0.5) * r2);
+      }
+      return rbf_pair<T>(z + k * a.d, x + jcol * a.d, ell, a.dl, a.d);
+    };
+    g.template run<true, false>(0, kend, fa, fb, lds, lds + G::BK * G::LDA);
+    g.for_each([&](int row, int col, T v) {
+      const long r = row0 + row, c = col0 + col;
+      if (r < a.M && c < a.n) A[r * a.n + c] = v;
+    });
+  }
+}
+
+// per column j: mean_p = sum_m u_pm A_mj ; s = sum_m A_mj^2 ; v = 1 - s ;
+// f_p = mean_p + sqrt|v| eps_j.   Block = 32 columns x 8 row groups.
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_finish_kernel(const T* __restrict__ A, const T* __restrict__ u,
+                                                         const T* __restrict__ eps, T* __restrict__ f,
+                                                         T* __restrict__ v, long n, long M, long P, int mode) {
+  __shared__ T red[8][33];
+  const long e = blockIdx.y;
+  A += e * M * n;
+  u += e * P * M;
+  f += e * P * n;
+  v += e * n;
+  if (eps) eps += e * n;
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const long j = (long)blockIdx.x * 32 + cx;
+  const bool ok = j < n;
+  // s first, then one pass per latent function p
+  T acc = T(0);
+  if (ok)
+    for (long m = ry; m < M; m += 8) {
+      const T av = A[m * n + j];
+      acc += av * av;
+    }
+  red[ry][cx] = acc;
+  __syncthreads();
+  T sq = T(0);
+  if (ry == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sq += red[q][cx];
+  }
+  T scale = T(0);
+  if (ry == 0 && ok) {
+    const T vv = T(1) - sq;
+    v[j] = vv;
+    if (mode == HB_SGP_DIAGONAL) scale = hb_sqrt(hb_abs(vv)) * eps[j];
+  }
+  for (long p = 0; p < P; ++p) {
+    __syncthreads();
+    T macc = T(0);
+    if (ok)
+      for (long m = ry; m < M; m += 8) macc += u[p * M + m] * A[m * n + j];
+    red[ry][cx] = macc;
+    __syncthreads();
+    if (ry == 0 && ok) {
+      T mean = T(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mean += red[q][cx];
+      f[p * n + j] = mean + scale;
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_rng_fill_kernel(uint64_t* state, long nlanes, T* out, long n) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long npairs = (n + 1) / 2;
+  if (t >= nlanes || t >= npairs) return;
+  HbRng g = rng_load(state, nlanes, t);
+  for (long p = t; p < npairs; p += nlanes) {
+    double z0, z1;
+    g.normal2(z0, z1);
+    out[2 * p] = (T)z0;
+    if (2 * p + 1 < n) out[2 * p + 1] = (T)z1;
+  }
+  rng_store(state, nlanes, t, g);
+}
+
+extern "C" long hb_sgp_ws_elems(long E, long n, long M, long d, long P) {
+  (void)P;
+  return E * n + E * M * d + 8 * E * M * M;
+}
+
+template <typename T>
+static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* u,
+                   const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* A, T* f, T* v, long E, long n,
+                   long M, long d, long P, T* ws, hipStream_t stream) {
+  (void)ws;
+  HB_REQUIRE(kind == HB_KERN_RBF, "hb_sgp_fwd: only the UnitRBF kernel is fused (kind=%d)", kind);
+  HB_REQUIRE(mode == HB_SGP_NEGLECTED || mode == HB_SGP_DIAGONAL, "hb_sgp_fwd: unknown mode %d", mode);
+  HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1 && P >= 0, "hb_sgp_fwd: bad extents");
+  HB_REQUIRE(dl == 1 || dl == d, "hb_sgp_fwd: lengthscales must have 1 or d entries");
+  HB_REQUIRE(x && z && ell && W && u && A && f && v, "hb_sgp_fwd: NULL pointer");
+  HB_REQUIRE(E <= 65535, "hb_sgp_fwd: too many experts");
+  if (E * n == 0) return 0;
+  const T* eps = eps_in;
+  if (mode == HB_SGP_DIAGONAL) {
+    if (!eps_in) {
+      HB_REQUIRE(rng && rng_lanes > 0 && eps_out, "hb_sgp_fwd: need eps_in, or rng and eps_out");
+      hipLaunchKernelGGL(sgp_rng_fill_kernel<T>, dim3(hb_cdiv(rng_lanes, 256)), dim3(256), 0, stream, rng, rng_lanes,
+                         eps_out, E * n);
+      HB_LAUNCH_CHECK();
+      eps = eps_out;
+    } else if (eps_out && eps_out != eps_in) {
+      HB_HIP(hipMemcpyAsync(eps_out, eps_in, sizeof(T) * E * n, hipMemcpyDeviceToDevice, stream));
+    }
+  }
+  if (M > 0) {
+    SgpArgs<T> a;
+    a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = u; a.A = A;
+    a.n = n; a.M = M; a.d = d; a.P = P;
+    const int nRB = hb_cdiv(M, SGP_BM);
+    dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
+    hipLaunchKernelGGL(sgp_A_kernel<T>, grid, dim3(256), 0, stream, a);
+    HB_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(sgp_finish_kernel<T>, dim3(hb_cdiv(n, 32), (unsigned)E), dim3(256), 0, stream, A, u, eps, f, v, n,
+                     M, P, mode);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hb_sgp_fwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell, long dl,
+                              const float* W, const float* u, const float* eps_in, uint64_t* rng, long rng_lanes,
+                              float* eps_out, float* A, float* f, float* v, long E, long n, long M, long d, long P,
+                              float* ws, void* stream) {
+  return sgp_fwd<float>(kind, mode, x, sx, z, ell, dl, W, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E, n, M, d, P,
+                        ws, (hipStream_t)stream);
+}
+extern "C" int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
+                              long dl, const double* W, const double* u, const double* eps_in, uint64_t* rng,
+                              long rng_lanes, double* eps_out, double* A, double* f, double* v, long E, long n, long M,
+                              long d, long P, double* ws, void* stream) {
+  return sgp_fwd<double>(kind, mode, x, sx, z, ell, dl, W, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E, n, M, d, P,
+                         ws, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+// c_j = -eps_j sign(v_j)/sqrt|v_j| * sum_p fbar_pj   (0 for NEGLECTED)
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_prep_kernel(const T* __restrict__ eps, const T* __restrict__ v,
+                                                       const T* __restrict__ fbar, T* __restrict__ c, long E, long n,
+                                                       long P, int mode) {
+  const long total = E * n;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    T out = T(0);
+    if (mode == HB_SGP_DIAGONAL) {
+      const long e = t / n, j = t - e * n;
+      T cs = T(0);
+      for (long p = 0; p < P; ++p) cs += fbar[(e * P + p) * n + j];
+      const T vv = v[t];
+      out = -eps[t] * hb_sign(vv) / hb_sqrt(hb_abs(vv)) * cs;
+    }
+    c[t] = out;
+  }
+}
+
+template <typename T>
+struct SgpBwdArgs {
+  const T* W;     // [E, M, M]
+  const T* u;     // [E, P, M]
+  const T* A;     // [E, M, n]
+  const T* fbar;  // [E, P, n]
+  const T* c;     // [E, n]
+  T* Kbar;        // [E, M, n]
+  long n, M, P;
+};
+
+// Kbar = W^T Abar,  Abar_kj = sum_p u_pk fbar_pj + A_kj c_j  (built in the loader)
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
+  typedef TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2> G;
+  __shared__ T lds[G::LDS_ELEMS];
+  const long e = blockIdx.z;
+  const T* W = a.W + e * a.M * a.M;
+  const T* u = a.u + e * a.P * a.M;
+  const T* A = a.A + e * a.M * a.n;
+  const T* fbar = a.fbar + e * a.P * a.n;
+  const T* c = a.c + e * a.n;
+  T* Kbar = a.Kbar + e * a.M * a.n;
+  const long col0 = (long)blockIdx.x * SGP_BN;
+  const int nRB = (int)((a.M + SGP_BM - 1) / SGP_BM);
+  const long jcol = col0 + (threadIdx.x % SGP_BN);
+  const bool jok = jcol < a.n;
+  const T cj = jok ? c[jcol] : T(0);
+  const bool preg = a.P == 1;
+  const T fb0 = (preg && jok) ? fbar[jcol] : T(0);
+
+  for (int half = 0; half < 2; ++half) {
+    const int rb = half == 0 ? (int)blockIdx.y : nRB - 1 - (int)blockIdx.y;
+    if (half == 1 && rb <= (int)blockIdx.y) break;
+    const long row0 = (long)rb * SGP_BM;
+    G g;
+    g.zero();
+    auto fa = [&](int m, long k) -> T {
+      const long r = row0 + m;
+      return (r < a.M && k >= r) ? W[k * a.M + r] : T(0);
+    };
+    auto fb = [&](long k, int nn) -> T {
+      if (!jok) return T(0);
+      T val = A[k * a.n + jcol] * cj;
+      if (preg) {
+        val += u[k] * fb0;
+      } else {
+        for (long p = 0; p < a.P; ++p) val += u[p * a.M + k] * fbar[p * a.n + jcol];
+      }
+      return val;
+    };
+    g.template run<false, false>(row0, a.M, fa, fb, lds, lds + G::BK * G::LDA);
+    g.for_each([&](int row, int col, T v) {
+      const long r = row0 + row, cc = col0 + col;
+      if (r < a.M && cc < a.n) Kbar[r * a.n + cc] = v;
+    });
+  }
+}
+
+// One block per inducing row m:  zbar_m, ell partial, ubar_pm  (deterministic
+// block reductions along the data axis).
+//   dK_mj/dz_mq   = -K_mj (z_mq - x_jq)/ell_q^2
+//   dK_mj/dell_q  =  K_mj (z_mq - x_jq)^2/ell_q^3
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_rowgrad_kernel(const T* __restrict__ x, long sx, const T* __restrict__ z,
+                                                          const T* __restrict__ ell, long dl,
+                                                          const T* __restrict__ Kbar, const T* __restrict__ A,
+                                                          const T* __restrict__ fbar, T* __restrict__ zbar,
+                                                          T* __restrict__ ellpart, T* __restrict__ ubar, long n,
+                                                          long M, long d, long P) {
+  __shared__ T smem[16];
+  const long e = blockIdx.y, m = blockIdx.x;
+  x += e * sx;
+  z += (e * M + m) * d;
+  ell += e * dl;
+  Kbar += (e * M + m) * n;
+  A += (e * M + m) * n;
+  fbar += e * P * n;
+  // ubar
+  for (long p = 0; p < P; ++p) {
+    T acc = T(0);
+    for (long j = threadIdx.x; j < n; j += blockDim.x) acc += fbar[p * n + j] * A[j];
+    acc = block_sum(acc, smem);
+    if (threadIdx.x == 0) ubar[(e * P + p) * M + m] = acc;
+  }
+  // zbar / ell partial, SGP_DREG input dims at a time
+  for (long q0 = 0; q0 < d; q0 += SGP_DREG) {
+    T zacc[SGP_DREG], lacc[SGP_DREG];
+#pragma unroll
+    for (int q = 0; q < SGP_DREG; ++q) zacc[q] = lacc[q] = T(0);
+    for (long j = threadIdx.x; j < n; j += blockDim.x) {
+      const T* xj = x + j * d;
+      T r2 = T(0);
+      for (long q = 0; q < d; ++q) {
+        const T t = (z[q] - xj[q]) / ell[dl == 1 ? 0 : q];
+        r2 += t * t;
+      }
+      const T gk = Kbar[j] * hb_exp(T(-0.5) * r2);
+#pragma unroll
+      for (int q = 0; q < SGP_DREG; ++q) {
+        if (q0 + q < d) {
+          const T il = T(1) / ell[dl == 1 ? 0 : q0 + q];
+          const T t = (z[q0 + q] - xj[q0 + q]) * il;
+          zacc[q] += -gk * t * il;
+          lacc[q] += gk * t * t * il;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < SGP_DREG; ++q) {
+      if (q0 + q < d) {
+        const T zs = block_sum(zacc[q], smem);
+        const T ls = block_sum(lacc[q], smem);
+        if (threadIdx.x == 0) {
+          zbar[(e * M + m) * d + q0 + q] = zs;
+          ellpart[(e * M + m) * d + q0 + q] = ls;
+        }
+      }
+    }
+  }
+}
+
+// ellbar[e, c] = sum_m ellpart[e, m, c] (all columns when dl == 1)
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_ell_finish_kernel(const T* __restrict__ part, long M, long d, long dl,
+                                                             T* __restrict__ ellbar) {
+  __shared__ T smem[16];
+  const long e = blockIdx.y, c = blockIdx.x;
+  part += e * M * d;
+  T acc = T(0);
+  if (dl == 1) {
+    for (long t = threadIdx.x; t < M * d; t += blockDim.x) acc += part[t];
+  } else {
+    for (long m = threadIdx.x; m < M; m += blockDim.x) acc += part[m * d + c];
+  }
+  acc = block_sum(acc, smem);
+  if (threadIdx.x == 0) ellbar[e * dl + c] = acc;
+}
+
+// xbar_jq = sum_m Kbar_mj K_mj (z_mq - x_jq)/ell_q^2 : one thread per (j), loop m
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_xbar_kernel(const T* __restrict__ x, long sx, const T* __restrict__ z,
+                                                       const T* __restrict__ ell, long dl, const T* __restrict__ Kbar,
+                                                       T* __restrict__ xbar, long n, long M, long d) {
+  const long e = blockIdx.y;
+  x += e * sx;
+  z += e * M * d;
+  ell += e * dl;
+  Kbar += e * M * n;
+  xbar += e * n * d;
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const T* xj = x + j * d;
+  for (long q0 = 0; q0 < d; q0 += SGP_DREG) {
+    T acc[SGP_DREG];
+#pragma unroll
+    for (int q = 0; q < SGP_DREG; ++q) acc[q] = T(0);
+    for (long m = 0; m < M; ++m) {
+      const T* zm = z + m * d;
+      T r2 = T(0);
+      for (long q = 0; q < d; ++q) {
+        const T t = (zm[q] - xj[q]) / ell[dl == 1 ? 0 : q];
+        r2 += t * t;
+      }
+      const T gk = Kbar[m * n + j] * hb_exp(T(-0.5) * r2);
+#pragma unroll
+      for (int q = 0; q < SGP_DREG; ++q) {
+        if (q0 + q < d) {
+          const T il = T(1) / ell[dl == 1 ? 0 : q0 + q];
+          acc[q] += gk * (zm[q0 + q] - xj[q0 + q]) * il * il;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < SGP_DREG; ++q)
+      if (q0 + q < d) xbar[j * d + q0 + q] = acc[q];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_tril_kernel(T* __restrict__ Lbar, long E, long M) {
+  const long total = E * M * M;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long rem = t % (M * M);
+    const long i = rem / M, j = rem - i * M;
+    if (j > i) Lbar[t] = T(0);
+  }
+}
+
+static inline int sgp_matmul(const float* A, const float* B, float* C, long batch, long M, long N, long K, long lda,
+                             long ldb, long ldc, long sA, long sB, long sC, int tA, int tB, double alpha, int flags,
+                             float* ws, long wse, void* stream) {
+  return hb_matmul_f32(A, B, C, batch, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, alpha, 0.0, nullptr, 0, HB_ACT_NONE,
+                       flags, ws, wse, stream);
+}
+static inline int sgp_matmul(const double* A, const double* B, double* C, long batch, long M, long N, long K, long lda,
+                             long ldb, long ldc, long sA, long sB, long sC, int tA, int tB, double alpha, int flags,
+                             double* ws, long wse, void* stream) {
+  return hb_matmul_f64(A, B, C, batch, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, alpha, 0.0, nullptr, 0, HB_ACT_NONE,
+                       flags, ws, wse, stream);
+}
+
+template <typename T>
+static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* u,
+                   const T* eps, const T* A, const T* v, const T* fbar, T* Kbar, T* Lbar, T* ubar, T* zbar, T* ellbar,
+                   T* xbar, long E, long n, long M, long d, long P, T* ws, hipStream_t stream) {
+  HB_REQUIRE(kind == HB_KERN_RBF, "hb_sgp_bwd: only the UnitRBF kernel is fused (kind=%d)", kind);
+  HB_REQUIRE(mode == HB_SGP_NEGLECTED || mode == HB_SGP_DIAGONAL, "hb_sgp_bwd: unknown mode %d", mode);
+  HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1 && P >= 0, "hb_sgp_bwd: bad extents");
+  HB_REQUIRE(dl == 1 || dl == d, "hb_sgp_bwd: lengthscales must have 1 or d entries");
+  HB_REQUIRE(x && z && ell && W && u && A && v && fbar && Kbar && Lbar && ubar && zbar && ellbar && ws,
+             "hb_sgp_bwd: NULL pointer");
+  HB_REQUIRE(mode == HB_SGP_NEGLECTED || eps, "hb_sgp_bwd: eps required for the diagonal mode");
+  HB_REQUIRE(E <= 65535, "hb_sgp_bwd: too many experts");
+  if (E * M == 0) return 0;
+  T* c = ws;
+  T* ellpart = ws + E * n;
+  T* mmws = ellpart + E * M * d;
+  const long mmws_elems = 8 * E * M * M;
+  if (n > 0) {
+    hipLaunchKernelGGL(sgp_prep_kernel<T>, dim3(hb_stream_grid(E * n, 256)), dim3(256), 0, stream, eps, v, fbar, c, E, n,
+                       P, mode);
+    HB_LAUNCH_CHECK();
+    SgpBwdArgs<T> a;
+    a.W = W; a.u = u; a.A = A; a.fbar = fbar; a.c = c; a.Kbar = Kbar;
+    a.n = n; a.M = M; a.P = P;
+    const int nRB = hb_cdiv(M, SGP_BM);
+    dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
+    hipLaunchKernelGGL(sgp_kbar_kernel<T>, grid, dim3(256), 0, stream, a);
+    HB_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(sgp_rowgrad_kernel<T>, dim3((unsigned)M, (unsigned)E), dim3(256), 0, stream, x, sx, z, ell, dl,
+                     Kbar, A, fbar, zbar, ellpart, ubar, n, M, d, P);
+  HB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sgp_ell_finish_kernel<T>, dim3((unsigned)dl, (unsigned)E), dim3(256), 0, stream, ellpart, M, d, dl,
+                     ellbar);
+  HB_LAUNCH_CHECK();
+  if (xbar && n > 0) {
+    hipLaunchKernelGGL(sgp_xbar_kernel<T>, dim3(hb_cdiv(n, 256), (unsigned)E), dim3(256), 0, stream, x, sx, z, ell, dl,
+                       Kbar, xbar, n, M, d);
+    HB_LAUNCH_CHECK();
+  }
+  // Lbar = -tril(Kbar A^T): contraction over the data axis, split-K, lower tiles only
+  if (n > 0) {
+    int rc = sgp_matmul(Kbar, A, Lbar, E, M, M, n, n, n, M, M * n, M * n, M * M, 0, 1, -1.0, HB_MM_LOWER_OUT, mmws,
+                        mmws_elems, (void*)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sgp_tril_kernel<T>, dim3(hb_stream_grid(E * M * M, 256)), dim3(256), 0, stream, Lbar, E, M);
+    HB_LAUNCH_CHECK();
+  } else {
+    HB_HIP(hipMemsetAsync(Lbar, 0, sizeof(T) * E * M * M, stream));
+  }
+  return 0;
+}
+
+extern "C" int hb_sgp_bwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell, long dl,
+                              const float* W, const float* u, const float* eps, const float* A, const float* v,
+                              const float* fbar, float* Kbar, float* Lbar, float* ubar, float* zbar, float* ellbar,
+                              float* xbar, long E, long n, long M, long d, long P, float* ws, void* stream) {
+  return sgp_bwd<float>(kind, mode, x, sx, z, ell, dl, W, u, eps, A, v, fbar, Kbar, Lbar, ubar, zbar, ellbar, xbar, E,
+                        n, M, d, P, ws, (hipStream_t)stream);
+}
+extern "C" int hb_sgp_bwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
+                              long dl, const double* W, const double* u, const double* eps, const double* A,
+                              const double* v, const double* fbar, double* Kbar, double* Lbar, double* ubar,
+                              double* zbar, double* ellbar, double* xbar, long E, long n, long M, long d, long P,
+                              double* ws, void* stream) {
+  return sgp_bwd<double>(kind, mode, x, sx, z, ell, dl, W, u, eps, A, v, fbar, Kbar, Lbar, ubar, zbar, ellbar, xbar, E,
+                         n, M, d, P, ws, (hipStream_t)stream);
+}

@@ -1,0 +1,299 @@
+// K1/K2: reparameterised Gaussian sampler fused with the Monte-Carlo KL term.
+//
+// Reference: Henbun/variationals.py:131-153 (_sample), :178-186 (logdet),
+// :225-230 (Normal._KL = -0.5*sum(logdet + u^2 - x^2)).  One pass over
+// mu, s(S), u: HBM-bound; algorithmic bytes = 3*n*B (diag: read mu,s; write x;
+// u in registers when drawn in-kernel) or (size^2+3*size)*B (full rank).
+#include "common.cuh"
+#include "rng_pairs.cuh"
+#include "../../include/henbun_hip.h"
+
+#define HB_KL_MAX_PARTIALS 2048
+
+// ---------------------------------------------------------------------------
+// diagonal
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) diag_fwd_kernel(const T* __restrict__ mu, const T* __restrict__ s,
+                                                       const T* __restrict__ u_in, uint64_t* rng, long rng_lanes,
+                                                       T* __restrict__ u_out, T* __restrict__ x,
+                                                       T* __restrict__ partial, long n) {
+  __shared__ T smem[16];
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nthreads = rng ? rng_lanes : (long)gridDim.x * blockDim.x;
+  const long npairs = (n + 1) / 2;
+  T acc = T(0);
+  const bool active = t < nthreads && t < npairs;
+  HbRng g;
+  if (rng && active) g = rng_load(rng, rng_lanes, t);
+  if (active) {
+    for (long p = t; p < npairs; p += nthreads) {
+      const long i0 = 2 * p, i1 = 2 * p + 1;
+      T u0, u1 = T(0);
+      if (rng) {
+        double z0, z1;
+        g.normal2(z0, z1);
+        u0 = (T)z0;
+        u1 = (T)z1;
+      } else {
+        u0 = u_in[i0];
+        if (i1 < n) u1 = u_in[i1];
+      }
+      {
+        const T sv = s[i0];
+        const T xv = mu[i0] + hb_exp(sv) * u0;
+        x[i0] = xv;
+        if (u_out) u_out[i0] = u0;
+        acc += T(2) * sv + u0 * u0 - xv * xv;
+      }
+      if (i1 < n) {
+        const T sv = s[i1];
+        const T xv = mu[i1] + hb_exp(sv) * u1;
+        x[i1] = xv;
+        if (u_out) u_out[i1] = u1;
+        acc += T(2) * sv + u1 * u1 - xv * xv;
+      }
+    }
+  }
+  if (rng && active) rng_store(rng, rng_lanes, t, g);
+  acc = block_sum(acc, smem);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) kl_finish_kernel(const T* __restrict__ partial, int np, T* __restrict__ kl) {
+  __shared__ T smem[16];
+  T acc = T(0);
+  for (int i = threadIdx.x; i < np; i += blockDim.x) acc += partial[i];
+  acc = block_sum(acc, smem);
+  if (threadIdx.x == 0) kl[0] = T(-0.5) * acc;
+}
+
+template <typename T>
+static int diag_fwd(const T* mu, const T* s, const T* u_in, uint64_t* rng, long rng_lanes, T* u_out, T* x, T* kl,
+                    long n, T* ws, hipStream_t stream) {
+  HB_REQUIRE(n >= 0, "hb_diag_sample_kl_fwd: n < 0");
+  HB_REQUIRE(mu && s && x && kl && ws, "hb_diag_sample_kl_fwd: NULL pointer");
+  HB_REQUIRE(u_in || (rng && rng_lanes > 0), "hb_diag_sample_kl_fwd: neither u_in nor rng given");
+  if (u_in) rng = nullptr;  // injected noise wins
+  int grid;
+  if (rng) {
+    grid = hb_cdiv(rng_lanes, 256);
+    HB_REQUIRE(grid <= HB_KL_MAX_PARTIALS, "hb_diag_sample_kl_fwd: rng_lanes too large");
+  } else {
+    grid = hb_stream_grid((n + 1) / 2, 256);
+  }
+  hipLaunchKernelGGL(diag_fwd_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, s, u_in, rng, rng_lanes, u_out, x, ws,
+                     n);
+  HB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kl_finish_kernel<T>, dim3(1), dim3(256), 0, stream, ws, grid, kl);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hb_diag_sample_kl_fwd_f32(const float* mu, const float* s, const float* u_in, uint64_t* rng,
+                                         long rng_lanes, float* u_out, float* x, float* kl, long n, float* ws,
+                                         void* stream) {
+  return diag_fwd<float>(mu, s, u_in, rng, rng_lanes, u_out, x, kl, n, ws, (hipStream_t)stream);
+}
+extern "C" int hb_diag_sample_kl_fwd_f64(const double* mu, const double* s, const double* u_in, uint64_t* rng,
+                                         long rng_lanes, double* u_out, double* x, double* kl, long n, double* ws,
+                                         void* stream) {
+  return diag_fwd<double>(mu, s, u_in, rng, rng_lanes, u_out, x, kl, n, ws, (hipStream_t)stream);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) diag_bwd_kernel(const T* __restrict__ s, const T* __restrict__ u,
+                                                       const T* __restrict__ x, const T* __restrict__ xbar,
+                                                       const T* __restrict__ klbar, T* __restrict__ mubar,
+                                                       T* __restrict__ sbar, long n) {
+  const T kb = klbar ? klbar[0] : T(0);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const T mb = (xbar ? xbar[i] : T(0)) + kb * x[i];
+    mubar[i] = mb;
+    sbar[i] = mb * hb_exp(s[i]) * u[i] - kb;
+  }
+}
+
+template <typename T>
+static int diag_bwd(const T* s, const T* u, const T* x, const T* xbar, const T* klbar, T* mubar, T* sbar, long n,
+                    hipStream_t stream) {
+  HB_REQUIRE(n >= 0, "hb_diag_sample_kl_bwd: n < 0");
+  HB_REQUIRE(s && u && x && mubar && sbar, "hb_diag_sample_kl_bwd: NULL pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(diag_bwd_kernel<T>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, s, u, x, xbar, klbar,
+                     mubar, sbar, n);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_diag_sample_kl_bwd_f32(const float* s, const float* u, const float* x, const float* xbar,
+                                         const float* klbar, float* mubar, float* sbar, long n, void* stream) {
+  return diag_bwd<float>(s, u, x, xbar, klbar, mubar, sbar, n, (hipStream_t)stream);
+}
+extern "C" int hb_diag_sample_kl_bwd_f64(const double* s, const double* u, const double* x, const double* xbar,
+                                         const double* klbar, double* mubar, double* sbar, long n, void* stream) {
+  return diag_bwd<double>(s, u, x, xbar, klbar, mubar, sbar, n, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// full rank: x_r = mu_r + tril(S_r) u_r
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) rng_fill_kernel(uint64_t* state, long nlanes, T* out, long n) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long npairs = (n + 1) / 2;
+  if (t >= nlanes || t >= npairs) return;
+  HbRng g = rng_load(state, nlanes, t);
+  for (long p = t; p < npairs; p += nlanes) {
+    double z0, z1;
+    g.normal2(z0, z1);
+    out[2 * p] = (T)z0;
+    if (2 * p + 1 < n) out[2 * p + 1] = (T)z1;
+  }
+  rng_store(state, nlanes, t, g);
+}
+
+// one wave per output (r,k): coalesced dot over j <= k.  Used for size > 64.
+template <typename T>
+__global__ void __launch_bounds__(256) fullrank_fwd_wave_kernel(const T* __restrict__ mu, const T* __restrict__ S,
+                                                                const T* __restrict__ u, T* __restrict__ x,
+                                                                T* __restrict__ partial, long rows, long size) {
+  __shared__ T smem[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long nout = rows * size;
+  const long wstride = (long)gridDim.x * 4;
+  T acc = T(0);
+  for (long o = (long)blockIdx.x * 4 + w; o < nout; o += wstride) {
+    const long r = o / size, k = o - r * size;
+    const T* Srow = S + (r * size + k) * size;
+    const T* ur = u + r * size;
+    T dot = T(0);
+    for (long j = lane; j <= k; j += 64) dot += Srow[j] * ur[j];
+    dot = wave_sum(dot);
+    if (lane == 0) {
+      const T xv = mu[o] + dot;
+      x[o] = xv;
+      const T skk = Srow[k], uk = ur[k];
+      acc += hb_log(skk * skk) + uk * uk - xv * xv;
+    }
+  }
+  acc = block_sum(acc, smem);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// one thread per output: for small blocks (local variationals, size <= 64)
+template <typename T>
+__global__ void __launch_bounds__(256) fullrank_fwd_thread_kernel(const T* __restrict__ mu, const T* __restrict__ S,
+                                                                  const T* __restrict__ u, T* __restrict__ x,
+                                                                  T* __restrict__ partial, long rows, long size) {
+  __shared__ T smem[16];
+  const long nout = rows * size;
+  const long stride = (long)gridDim.x * blockDim.x;
+  T acc = T(0);
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < nout; o += stride) {
+    const long r = o / size, k = o - r * size;
+    const T* Srow = S + (r * size + k) * size;
+    const T* ur = u + r * size;
+    T dot = T(0);
+    for (long j = 0; j <= k; ++j) dot += Srow[j] * ur[j];
+    const T xv = mu[o] + dot;
+    x[o] = xv;
+    const T skk = Srow[k], uk = ur[k];
+    acc += hb_log(skk * skk) + uk * uk - xv * xv;
+  }
+  acc = block_sum(acc, smem);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+template <typename T>
+static int fullrank_fwd(const T* mu, const T* S, const T* u_in, uint64_t* rng, long rng_lanes, T* u_out, T* x, T* kl,
+                        long rows, long size, T* ws, hipStream_t stream) {
+  HB_REQUIRE(rows >= 0 && size >= 0, "hb_fullrank_sample_kl_fwd: negative extent");
+  HB_REQUIRE(mu && S && x && kl && ws, "hb_fullrank_sample_kl_fwd: NULL pointer");
+  HB_REQUIRE(u_in || (rng && rng_lanes > 0 && u_out), "hb_fullrank_sample_kl_fwd: need u_in, or rng and u_out");
+  const long n = rows * size;
+  const T* u = u_in;
+  if (!u_in) {
+    if (n > 0) {
+      hipLaunchKernelGGL(rng_fill_kernel<T>, dim3(hb_cdiv(rng_lanes, 256)), dim3(256), 0, stream, rng, rng_lanes,
+                         u_out, n);
+      HB_LAUNCH_CHECK();
+    }
+    u = u_out;
+  } else if (u_out && u_out != u_in && n > 0) {
+    HB_HIP(hipMemcpyAsync(u_out, u_in, sizeof(T) * n, hipMemcpyDeviceToDevice, stream));
+  }
+  int grid;
+  if (size > 64) {
+    grid = (int)((n + 3) / 4);
+    if (grid > HB_KL_MAX_PARTIALS) grid = HB_KL_MAX_PARTIALS;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(fullrank_fwd_wave_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, S, u, x, ws, rows, size);
+  } else {
+    grid = hb_stream_grid(n, 256);
+    hipLaunchKernelGGL(fullrank_fwd_thread_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, S, u, x, ws, rows, size);
+  }
+  HB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kl_finish_kernel<T>, dim3(1), dim3(256), 0, stream, ws, grid, kl);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hb_fullrank_sample_kl_fwd_f32(const float* mu, const float* S, const float* u_in, uint64_t* rng,
+                                             long rng_lanes, float* u_out, float* x, float* kl, long rows, long size,
+                                             float* ws, void* stream) {
+  return fullrank_fwd<float>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, ws, (hipStream_t)stream);
+}
+extern "C" int hb_fullrank_sample_kl_fwd_f64(const double* mu, const double* S, const double* u_in, uint64_t* rng,
+                                             long rng_lanes, double* u_out, double* x, double* kl, long rows,
+                                             long size, double* ws, void* stream) {
+  return fullrank_fwd<double>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, ws, (hipStream_t)stream);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) fullrank_bwd_kernel(const T* __restrict__ S, const T* __restrict__ u,
+                                                           const T* __restrict__ x, const T* __restrict__ xbar,
+                                                           const T* __restrict__ klbar, T* __restrict__ mubar,
+                                                           T* __restrict__ Sbar, long rows, long size) {
+  const T kb = klbar ? klbar[0] : T(0);
+  const long total = rows * size * size;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long rk = t / size;         // r*size + k
+    const long j = t - rk * size;
+    const long r = rk / size, k = rk - r * size;
+    const T mb = (xbar ? xbar[rk] : T(0)) + kb * x[rk];
+    if (j == 0) mubar[rk] = mb;
+    T g = T(0);
+    if (j < k) {
+      g = mb * u[r * size + j];
+    } else if (j == k) {
+      g = mb * u[rk] - kb / S[t];
+    }
+    Sbar[t] = g;
+  }
+}
+
+template <typename T>
+static int fullrank_bwd(const T* S, const T* u, const T* x, const T* xbar, const T* klbar, T* mubar, T* Sbar,
+                        long rows, long size, hipStream_t stream) {
+  HB_REQUIRE(rows >= 0 && size >= 0, "hb_fullrank_sample_kl_bwd: negative extent");
+  HB_REQUIRE(S && u && x && mubar && Sbar, "hb_fullrank_sample_kl_bwd: NULL pointer");
+  const long total = rows * size * size;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(fullrank_bwd_kernel<T>, dim3(hb_stream_grid(total, 256)), dim3(256), 0, stream, S, u, x, xbar,
+                     klbar, mubar, Sbar, rows, size);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_fullrank_sample_kl_bwd_f32(const float* S, const float* u, const float* x, const float* xbar,
+                                             const float* klbar, float* mubar, float* Sbar, long rows, long size,
+                                             void* stream) {
+  return fullrank_bwd<float>(S, u, x, xbar, klbar, mubar, Sbar, rows, size, (hipStream_t)stream);
+}
+extern "C" int hb_fullrank_sample_kl_bwd_f64(const double* S, const double* u, const double* x, const double* xbar,
+                                             const double* klbar, double* mubar, double* Sbar, long rows, long size,
+                                             void* stream) {
+  return fullrank_bwd<double>(S, u, x, xbar, klbar, mubar, Sbar, rows, size, (hipStream_t)stream);
+}

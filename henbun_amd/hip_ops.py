@@ -1,0 +1,463 @@
+"""Device-buffer level wrappers over the C ABI (include/henbun_hip.h).
+
+PyTorch is used here ONLY as plumbing: `torch.empty(device='cuda')` for device
+memory, `tensor.data_ptr()` for the raw pointer and the current stream handle.
+No torch op computes anything on this path -- every function below is one (or
+a fixed few) launches of hand-written HIP kernels through ctypes.  If the
+backend library is missing, `_lib.lib()` raises; there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_double, c_long, c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# ---- enums mirrored from include/henbun_hip.h -------------------------------
+EW = dict(
+    NEG=1, EXP=2, LOG=3, SQRT=4, SQUARE=5, ABS=6, SIGN=7, SIGMOID=8, RELU=9, SOFTPLUS=10, TANH=11,
+    RECIP=12, RSQRT=13, STEP=14, AFFINE=15, CLIP=16, CLIPMASK=17, LGAMMA=18, POWC=19, LOG1P=20,
+    COPY=21, DIGAMMA=22,
+    ADD=32, SUB=33, MUL=34, DIV=35, MAX=36, MIN=37, POW=38, GT=39, GE=40, LT=41, LE=42, EQ=43,
+    SIGMOID_GRAD=44, TANH_GRAD=45, RELU_GRAD=46, SOFTPLUS_GRAD=47, CLIP_GRAD=48,
+    WHERE=64, FMA=65, GAUSS_LOGPDF=66,
+    GAUSS_LOGPDF_GRAD=80,
+)
+RED_SUM, RED_MAX = 0, 1
+KERN_RBF, KERN_CSYM_RBF = 0, 1
+MM_LOWER_OUT = 1
+ACT = dict(none=0, sigmoid=1, relu=2, tanh=3)
+SGP_NEGLECTED, SGP_DIAGONAL = 0, 1
+MATUTIL_BAND, MATUTIL_ADD_EYE, MATUTIL_PHI, MATUTIL_SYM = 0, 1, 2, 3
+
+WS_ELEMS = 1 << 16  # generic scratch (elements) for reductions / KL partials
+
+
+def _suf(t: torch.Tensor) -> str:
+    if t.dtype == torch.float32:
+        return "_f32"
+    if t.dtype == torch.float64:
+        return "_f64"
+    raise TypeError("henbun_amd kernels compute in float32 or float64, got %s" % t.dtype)
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def _chk(t: torch.Tensor, name="tensor"):
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU" % name)
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _larr(vals):
+    return (c_long * len(vals))(*[int(v) for v in vals])
+
+
+_ws_cache = {}
+
+
+def workspace(dtype, device, elems=WS_ELEMS) -> torch.Tensor:
+    key = (dtype, str(device), torch.cuda.current_stream().cuda_stream)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() < elems:
+        w = torch.empty(max(elems, WS_ELEMS), dtype=dtype, device=device)
+        _ws_cache[key] = w
+    return w
+
+
+def _bcast_strides(shape, out_shape):
+    """element strides of a contiguous tensor of `shape` viewed as `out_shape` (0 on broadcast dims)."""
+    nd = len(out_shape)
+    shape = (1,) * (nd - len(shape)) + tuple(shape)
+    strides, acc = [0] * nd, 1
+    for d in range(nd - 1, -1, -1):
+        if shape[d] == 1 and out_shape[d] != 1:
+            strides[d] = 0
+        elif shape[d] == out_shape[d]:
+            strides[d] = acc if shape[d] != 1 else 0
+        else:
+            raise ValueError("shape %s does not broadcast to %s" % (shape, out_shape))
+        acc *= shape[d]
+    return strides
+
+
+def ewise(op, inputs, nout=1, params=None, out=None):
+    """n-ary broadcasting elementwise op (hb_ewise_*).  Returns a tensor or a tuple."""
+    opc = EW[op] if isinstance(op, str) else int(op)
+    inputs = [_chk(t, "input") for t in inputs]
+    out_shape = tuple(torch.broadcast_shapes(*[tuple(t.shape) for t in inputs]))
+    if len(out_shape) > 6:
+        raise ValueError("elementwise ops support at most 6 dims")
+    nin = len(inputs)
+    nd = len(out_shape)
+    strides = []
+    for t in inputs:
+        strides += _bcast_strides(tuple(t.shape), out_shape)
+    if out is None:
+        outs = [torch.empty(out_shape, dtype=inputs[0].dtype, device=inputs[0].device) for _ in range(nout)]
+    else:
+        outs = list(out) if isinstance(out, (list, tuple)) else [out]
+        for o in outs:
+            assert tuple(o.shape) == out_shape and o.is_contiguous()
+    in_arr = (c_void_p * nin)(*[t.data_ptr() for t in inputs])
+    out_arr = (c_void_p * nout)(*[o.data_ptr() for o in outs])
+    pr = (c_double * 4)(*(list(params or []) + [0.0] * 4)[:4])
+    _lib.lib().call("hb_ewise" + _suf(inputs[0]), opc, nin, in_arr, _larr(strides) if strides else _larr([0]),
+                    nout, out_arr, nd, _larr(out_shape) if nd else _larr([1]), pr, stream())
+    return outs[0] if nout == 1 else tuple(outs)
+
+
+def reduce_mid(x, K1, R, K2, op=RED_SUM, out=None):
+    """out[K1,K2] = reduce_R x[K1,R,K2] (x contiguous, any shape with K1*R*K2 elements)."""
+    _chk(x)
+    assert x.numel() == K1 * R * K2
+    if out is None:
+        out = torch.empty(K1 * K2, dtype=x.dtype, device=x.device)
+    ws = workspace(x.dtype, x.device)
+    _lib.lib().call("hb_reduce" + _suf(x), op, _p(x), _p(out), K1, R, K2, _p(ws), ws.numel(), stream())
+    return out
+
+
+def copy_nd(src, src_strides, dst, dst_strides, shape, src_off=0, dst_off=0):
+    """strided element copy; strides/offsets in elements over the flat buffers."""
+    es = src.element_size()
+    sp = c_void_p(src.data_ptr() + src_off * es)
+    dp = c_void_p(dst.data_ptr() + dst_off * es)
+    nd = len(shape)
+    _lib.lib().call("hb_copy_nd" + _suf(src), sp, _larr(src_strides) if nd else _larr([0]), dp,
+                    _larr(dst_strides) if nd else _larr([0]), nd, _larr(shape) if nd else _larr([1]), stream())
+    return dst
+
+
+def fill(t, value):
+    _lib.lib().call("hb_fill" + _suf(t), _p(t), t.numel(), float(value), stream())
+    return t
+
+
+def gather_rows(src, idx, perm=None, out=None, err=None):
+    """out[i,:] = src[perm[idx[i]],:]  (K0)."""
+    _chk(src)
+    nsrc = src.shape[0]
+    row = src.numel() // max(nsrc, 1)
+    n = idx.numel()
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    assert idx.dtype == torch.int64 and (perm is None or perm.dtype == torch.int64)
+    _lib.lib().call("hb_gather_rows" + _suf(src), _p(src), nsrc, row, _p(idx), _p(perm), n, _p(out), _p(err), stream())
+    return out
+
+
+def matutil(x, mode, lower=-1, upper=-1, alpha=0.0, out=None):
+    _chk(x)
+    R, C = x.shape[-2], x.shape[-1]
+    B = x.numel() // max(R * C, 1)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.lib().call("hb_matutil" + _suf(x), _p(x), _p(out), B, R, C, mode, lower, upper, float(alpha), stream())
+    return out
+
+
+# ---- RNG --------------------------------------------------------------------
+class Rng:
+    """xoroshiro128+ per-lane state on the device (hb_rng_*)."""
+
+    def __init__(self, seed, stream_id=0, nlanes=16384, device="cuda"):
+        self.nlanes = int(nlanes)
+        self.state = torch.empty(2 * self.nlanes, dtype=torch.int64, device=device)
+        self.seed, self.stream_id = int(seed), int(stream_id)
+        self.reseed(seed, stream_id)
+
+    def reseed(self, seed, stream_id=0):
+        _lib.lib().call("hb_rng_init", _p(self.state), self.nlanes, int(seed) & (2**64 - 1),
+                        int(stream_id) & (2**64 - 1), stream())
+
+    def normal(self, shape, dtype=torch.float32, out=None):
+        if out is None:
+            out = torch.empty(shape, dtype=dtype, device=self.state.device)
+        _lib.lib().call("hb_rng_normal" + _suf(out), _p(self.state), self.nlanes, _p(out), out.numel(), stream())
+        return out
+
+    def randint(self, n, lo, hi, out=None):
+        if out is None:
+            out = torch.empty(n, dtype=torch.int64, device=self.state.device)
+        _lib.lib().call("hb_rng_randint", _p(self.state), self.nlanes, _p(out), out.numel(), int(lo), int(hi), stream())
+        return out
+
+
+def _rng_args(rng):
+    if rng is None:
+        return None, 0
+    return _p(rng.state), rng.nlanes
+
+
+# ---- K1/K2 variational sampler + MC-KL --------------------------------------
+def diag_sample_kl_fwd(mu, s, u_in=None, rng=None, out=None):
+    """x = mu + exp(s)*u ; kl = -0.5*sum(2s + u^2 - x^2).  Returns (x, kl[1], u)."""
+    _chk(mu), _chk(s)
+    n = mu.numel()
+    if out is None:
+        x, kl, u = torch.empty_like(mu), torch.empty(1, dtype=mu.dtype, device=mu.device), torch.empty_like(mu)
+    else:
+        x, kl, u = out
+    ws = workspace(mu.dtype, mu.device)
+    rp, rl = _rng_args(rng)
+    _lib.lib().call("hb_diag_sample_kl_fwd" + _suf(mu), _p(mu), _p(s), _p(u_in), rp, rl, _p(u), _p(x), _p(kl), n,
+                    _p(ws), stream())
+    return x, kl, u
+
+
+def diag_sample_kl_bwd(s, u, x, xbar, klbar, out=None):
+    if out is None:
+        mubar, sbar = torch.empty_like(s), torch.empty_like(s)
+    else:
+        mubar, sbar = out
+    _lib.lib().call("hb_diag_sample_kl_bwd" + _suf(s), _p(s), _p(u), _p(x), _p(xbar), _p(klbar), _p(mubar), _p(sbar),
+                    s.numel(), stream())
+    return mubar, sbar
+
+
+def fullrank_sample_kl_fwd(mu, S, u_in=None, rng=None, out=None):
+    """x_r = mu_r + tril(S_r) u_r over rows; S [..., size, size]."""
+    _chk(mu), _chk(S)
+    size = mu.shape[-1]
+    rows = mu.numel() // max(size, 1)
+    if out is None:
+        x, kl, u = torch.empty_like(mu), torch.empty(1, dtype=mu.dtype, device=mu.device), torch.empty_like(mu)
+    else:
+        x, kl, u = out
+    ws = workspace(mu.dtype, mu.device)
+    rp, rl = _rng_args(rng)
+    _lib.lib().call("hb_fullrank_sample_kl_fwd" + _suf(mu), _p(mu), _p(S), _p(u_in), rp, rl, _p(u), _p(x), _p(kl),
+                    rows, size, _p(ws), stream())
+    return x, kl, u
+
+
+def fullrank_sample_kl_bwd(S, u, x, xbar, klbar, out=None):
+    size = u.shape[-1]
+    rows = u.numel() // max(size, 1)
+    if out is None:
+        mubar, Sbar = torch.empty_like(u), torch.empty_like(S)
+    else:
+        mubar, Sbar = out
+    _lib.lib().call("hb_fullrank_sample_kl_bwd" + _suf(S), _p(S), _p(u), _p(x), _p(xbar), _p(klbar), _p(mubar),
+                    _p(Sbar), rows, size, stream())
+    return mubar, Sbar
+
+
+# ---- K3 Gram ------------------------------------------------------------------
+def _batch_view(X, nd_tail=2):
+    """(B, stride) of a [..., n, d] tensor flattened over leading dims."""
+    n, d = X.shape[-2], X.shape[-1]
+    B = X.numel() // max(n * d, 1)
+    return B, n, d
+
+
+def gram_fwd(X, X2, ell, kind=KERN_RBF, out=None):
+    """K[b,i,j] = k(X[b,i], X2[b,j]); X, X2: [n,d] or [B,n,d] (a 2-D operand is shared over B)."""
+    _chk(X), _chk(X2), _chk(ell)
+    BX, n, d = _batch_view(X)
+    BX2, n2, d2 = _batch_view(X2)
+    assert d == d2
+    B = max(BX, BX2)
+    assert BX in (1, B) and BX2 in (1, B)
+    sX = n * d if (BX == B and B > 1) else 0
+    sX2 = n2 * d if (BX2 == B and B > 1) else 0
+    batched = X.dim() > 2 or X2.dim() > 2
+    lead = tuple(X.shape[:-2]) if X.dim() >= X2.dim() else tuple(X2.shape[:-2])
+    if out is None:
+        out = torch.empty((lead if batched else ()) + (n, n2), dtype=X.dtype, device=X.device)
+    _lib.lib().call("hb_gram_fwd" + _suf(X), kind, _p(X), sX, _p(X2), sX2, _p(ell), ell.numel(), _p(out), B, n, n2, d,
+                    stream())
+    return out
+
+
+def gram_bwd(X, X2, ell, Kbar, kind=KERN_RBF, need=(True, True, True)):
+    """VJP of gram_fwd: returns (Xbar, X2bar, ellbar) (None where not needed).
+    Operands shared over the batch get their gradient summed over it."""
+    _chk(X), _chk(X2), _chk(ell), _chk(Kbar)
+    BX, n, d = _batch_view(X)
+    BX2, n2, _ = _batch_view(X2)
+    B = max(BX, BX2)
+    sX = n * d if (BX == B and B > 1) else 0
+    sX2 = n2 * d if (BX2 == B and B > 1) else 0
+    dev, dt = X.device, X.dtype
+    Xbar = torch.empty((B, n, d), dtype=dt, device=dev) if need[0] else None
+    X2bar = torch.empty((B, n2, d), dtype=dt, device=dev) if need[1] else None
+    ellbar = torch.empty(ell.numel(), dtype=dt, device=dev) if need[2] else None
+    ws = workspace(dt, dev, max(B * n * d, 1))
+    _lib.lib().call("hb_gram_bwd" + _suf(X), kind, _p(X), sX, _p(X2), sX2, _p(ell), ell.numel(), _p(Kbar), _p(Xbar),
+                    _p(X2bar), _p(ellbar), B, n, n2, d, _p(ws), stream())
+    if Xbar is not None:
+        Xbar = reduce_mid(Xbar, 1, B, n * d).reshape(X.shape) if (BX == 1 and B > 1) else Xbar.reshape(X.shape)
+    if X2bar is not None:
+        X2bar = reduce_mid(X2bar, 1, B, n2 * d).reshape(X2.shape) if (BX2 == 1 and B > 1) else X2bar.reshape(X2.shape)
+    if ellbar is not None:
+        ellbar = ellbar.reshape(ell.shape)
+    return Xbar, X2bar, ellbar
+
+
+# ---- dense linear algebra ------------------------------------------------------
+def matmul(A, B, transA=False, transB=False, alpha=1.0, bias=None, act="none", lower_out=False, out=None,
+           beta=0.0):
+    """C = act(alpha*op(A)@op(B) + bias) (+ beta*C).  A:[...,m,k], B:[...,k,n]; a 2-D operand broadcasts
+    over the other's leading (batch) dims.  bias: [n] or [batch..., n]/[batch...,1,n]."""
+    _chk(A), _chk(B)
+    am, ak = (A.shape[-1], A.shape[-2]) if transA else (A.shape[-2], A.shape[-1])
+    bk, bn = (B.shape[-1], B.shape[-2]) if transB else (B.shape[-2], B.shape[-1])
+    if ak != bk:
+        raise ValueError("matmul inner dims differ: %s vs %s" % (tuple(A.shape), tuple(B.shape)))
+    la, lb = tuple(A.shape[:-2]), tuple(B.shape[:-2])
+    ba, bb = int(np.prod(la)) if la else 1, int(np.prod(lb)) if lb else 1
+    if ba != bb and ba != 1 and bb != 1:
+        raise ValueError("matmul batch dims must match or be absent: %s vs %s" % (la, lb))
+    batch = max(ba, bb)
+    lead = la if ba >= bb else lb
+    sA = A.shape[-2] * A.shape[-1] if (ba == batch and batch > 1) else 0
+    sB = B.shape[-2] * B.shape[-1] if (bb == batch and batch > 1) else 0
+    if out is None:
+        out = torch.empty(lead + (am, bn), dtype=A.dtype, device=A.device)
+    sBias = 0
+    if bias is not None:
+        _chk(bias)
+        if bias.numel() == bn:
+            sBias = 0
+        elif bias.numel() == batch * bn:
+            sBias = bn
+        else:
+            raise ValueError("bias shape %s does not match [%d] or [%d,%d]" % (tuple(bias.shape), bn, batch, bn))
+    ws = workspace(A.dtype, A.device, 1 << 22)
+    _lib.lib().call("hb_matmul" + _suf(A), _p(A), _p(B), _p(out), batch, am, bn, ak, A.shape[-1], B.shape[-1], bn,
+                    sA, sB, am * bn, int(transA), int(transB), float(alpha), float(beta), _p(bias), sBias, ACT[act],
+                    MM_LOWER_OUT if lower_out else 0, _p(ws), ws.numel(), stream())
+    return out
+
+
+def cholesky(A, out=None, info=None):
+    """L = chol(A) (lower), batched over leading dims.  Returns (L, info[B] int32 device tensor)."""
+    _chk(A)
+    M = A.shape[-1]
+    assert A.shape[-2] == M
+    B = A.numel() // max(M * M, 1)
+    if out is None:
+        out = torch.empty_like(A)
+    if info is None:
+        info = torch.empty(max(B, 1), dtype=torch.int32, device=A.device)
+    _lib.lib().call("hb_cholesky" + _suf(A), _p(A), _p(out), B, M, _p(info), stream())
+    return out, info
+
+
+def trinv(L, out=None):
+    """W = L^{-1} for lower-triangular L, batched."""
+    _chk(L)
+    M = L.shape[-1]
+    B = L.numel() // max(M * M, 1)
+    if out is None:
+        out = torch.empty_like(L)
+    ws = workspace(L.dtype, L.device, max(B * M * M, 1))
+    _lib.lib().call("hb_trinv" + _suf(L), _p(L), _p(out), B, M, _p(ws), stream())
+    return out
+
+
+# ---- K5/K6 fused sparse GP -----------------------------------------------------
+def _sgp_dims(x, z, u):
+    E = z.shape[0] if z.dim() == 3 else 1
+    M, d = z.shape[-2], z.shape[-1]
+    n = x.shape[-2]
+    P = u.shape[-2]
+    sx = n * d if (x.dim() == 3 and x.shape[0] == E and E > 1) else 0
+    return E, n, M, d, P, sx
+
+
+def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None):
+    """Returns (f[E?,P,n], A[E?,M,n], v[E?,n], eps[E?,n])."""
+    for t in (x, z, ell, W, u):
+        _chk(t)
+    E, n, M, d, P, sx = _sgp_dims(x, z, u)
+    lead = (E,) if z.dim() == 3 else ()
+    dev, dt = x.device, x.dtype
+    if out is None:
+        f = torch.empty(lead + (P, n), dtype=dt, device=dev)
+        A = torch.empty(lead + (M, n), dtype=dt, device=dev)
+        v = torch.empty(lead + (n,), dtype=dt, device=dev)
+        eps = torch.empty(lead + (n,), dtype=dt, device=dev)
+    else:
+        f, A, v, eps = out
+    dl = ell.numel() // E
+    rp, rl = _rng_args(rng)
+    _lib.lib().call("hb_sgp_fwd" + _suf(x), KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(u), _p(eps_in),
+                    rp, rl, _p(eps), _p(A), _p(f), _p(v), E, n, M, d, P, None, stream())
+    return f, A, v, eps
+
+
+def sgp_bwd(x, z, ell, W, u, eps, A, v, fbar, mode=SGP_DIAGONAL, need_xbar=False, out=None):
+    """Returns (Lbar, ubar, zbar, ellbar, xbar|None)."""
+    E, n, M, d, P, sx = _sgp_dims(x, z, u)
+    dev, dt = x.device, x.dtype
+    dl = ell.numel() // E
+    if out is None:
+        Kbar = torch.empty_like(A)
+        Lbar = torch.empty_like(W)
+        ubar = torch.empty_like(u)
+        zbar = torch.empty_like(z)
+        ellbar = torch.empty_like(ell)
+        xbar = torch.empty((E, n, d), dtype=dt, device=dev) if need_xbar else None
+    else:
+        Kbar, Lbar, ubar, zbar, ellbar, xbar = out
+    wse = _lib.lib().raw("hb_sgp_ws_elems")(E, n, M, d, P)
+    ws = workspace(dt, dev, wse)
+    _lib.lib().call("hb_sgp_bwd" + _suf(x), KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(u), _p(eps),
+                    _p(A), _p(v), _p(fbar), _p(Kbar), _p(Lbar), _p(ubar), _p(zbar), _p(ellbar), _p(xbar), E, n, M, d,
+                    P, _p(ws), stream())
+    return Lbar, ubar, zbar, ellbar, xbar
+
+
+# ---- K9 Adam ---------------------------------------------------------------------
+def adam_step(theta, g, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0):
+    """In-place TF-1 Adam on flat buffers; `t` is a 1-element int64 device tensor."""
+    assert t.dtype == torch.int64
+    _lib.lib().call("hb_adam_step" + _suf(theta), _p(theta), _p(g), _p(m), _p(v), theta.numel(), float(lr), float(b1),
+                    float(b2), float(eps), float(gscale), _p(t), stream())
+
+
+# ---- hipGraph capture ---------------------------------------------------------------
+class CapturedGraph:
+    """A replayable hipGraph of whatever was launched between begin() and end()."""
+
+    def __init__(self):
+        self._exec = c_void_p(None)
+
+    def begin(self):
+        _lib.lib().call("hb_graph_begin_capture", stream())
+
+    def end(self):
+        _lib.lib().call("hb_graph_end_capture", stream(), ctypes.byref(self._exec))
+
+    def launch(self):
+        _lib.lib().call("hb_graph_launch", self._exec, stream())
+
+    def __del__(self):
+        try:
+            if self._exec:
+                _lib.lib().raw("hb_graph_destroy")(self._exec)
+        except Exception:
+            pass
+
+
+def device_info():
+    buf = ctypes.create_string_buffer(256)
+    cus = ctypes.c_int(0)
+    _lib.lib().call("hb_device_info", buf, 256, ctypes.byref(cus))
+    return buf.value.decode(), cus.value

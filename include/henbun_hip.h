@@ -1,0 +1,267 @@
+/*
+ * henbun_hip.h -- C ABI of libhenbun_hip.so, the MI355X (gfx950) numeric
+ * backend of henbun_amd.
+ *
+ * What this replaces.  The reference (fujii-team/Henbun) has NO native
+ * boundary of its own: every numeric op on the ELBO path is a TensorFlow 1.x
+ * graph node reached through `session.run` (reference Henbun/model.py:81,96,
+ * 225-227,250,265) and the thin shim module Henbun/tf_wraps.py:26-48.  The
+ * only native-op precedent is the disabled `tf.load_op_library('tfops/
+ * matpackops.so')` hook (Henbun/tf_wraps.py:50-71).  This header is the
+ * boundary the north star asks for in its place: a flat `extern "C"` surface,
+ * plain device pointers and sizes, loaded from Python with ctypes
+ * (henbun_amd/_lib.py).  Each entry cites the reference call site(s) whose TF
+ * op(s) it stands in for.
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer unless marked (host);
+ *     the library allocates nothing persistent; scratch comes in through
+ *     `ws`/`ws_elems` (elements of the op's dtype);
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous
+ *     on it and never synchronises;
+ *   - return 0 = ok, <0 = bad argument (message in hb_last_error_string()),
+ *     >0 = hipError_t from the runtime;
+ *   - numerical failure (non-positive-definite Cholesky) is reported through
+ *     a device-side `int* info` (LAPACK convention: k+1 = leading minor k+1
+ *     is not positive definite), since calls are asynchronous;
+ *   - `_f32` / `_f64` suffix = arithmetic type; layouts are row-major,
+ *     contiguous unless strides are given; extents are `long` (int64).
+ *   - samplers accept injected noise (`u_in`, nullable) and export the noise
+ *     they used (`u_out`), so parity tests never depend on the RNG stream.
+ */
+#ifndef HENBUN_HIP_H
+#define HENBUN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HB_ABI_VERSION 1
+
+/* ---- runtime ----------------------------------------------------------- */
+int hb_version(void);
+const char* hb_last_error_string(void);
+/* device name / arch of the current device into (host) buf; returns 0 or hipError */
+int hb_device_info(char* buf, int buflen, int* cu_count);
+
+/* hipGraph capture of a launch sequence (replaces the per-op dispatch of
+ * session.run, reference model.py:265-266).  exec is a (host) handle. */
+int hb_graph_begin_capture(void* stream);
+int hb_graph_end_capture(void* stream, void** exec_out);
+int hb_graph_launch(void* exec, void* stream);
+int hb_graph_destroy(void* exec);
+
+/* ---- generic tensor plumbing (tf elementwise ops, reduce_sum, transpose,
+ *      slice, tile; reference call sites listed in SURVEY.md 2.2) ---------- */
+enum {
+  /* unary */
+  HB_EW_NEG = 1, HB_EW_EXP, HB_EW_LOG, HB_EW_SQRT, HB_EW_SQUARE, HB_EW_ABS, HB_EW_SIGN,
+  HB_EW_SIGMOID, HB_EW_RELU, HB_EW_SOFTPLUS, HB_EW_TANH, HB_EW_RECIP, HB_EW_RSQRT,
+  HB_EW_STEP, HB_EW_AFFINE /* p0*x+p1 */, HB_EW_CLIP /* [p0,p1] */, HB_EW_CLIPMASK,
+  HB_EW_LGAMMA, HB_EW_POWC /* x^p0 */, HB_EW_LOG1P, HB_EW_COPY, HB_EW_DIGAMMA,
+  /* binary */
+  HB_EW_ADD = 32, HB_EW_SUB, HB_EW_MUL, HB_EW_DIV, HB_EW_MAX, HB_EW_MIN, HB_EW_POW,
+  HB_EW_GT, HB_EW_GE, HB_EW_LT, HB_EW_LE, HB_EW_EQ,
+  HB_EW_SIGMOID_GRAD /* (y,g) */, HB_EW_TANH_GRAD /* (y,g) */, HB_EW_RELU_GRAD /* (x,g) */,
+  HB_EW_SOFTPLUS_GRAD /* (x,g) */, HB_EW_CLIP_GRAD /* (x,g) p0,p1 */,
+  /* ternary */
+  HB_EW_WHERE = 64 /* (c,a,b) */, HB_EW_FMA /* a*b+c */,
+  HB_EW_GAUSS_LOGPDF /* (x,mu,var): reference densities.py:25-27 */,
+  /* 4 in, 3 out */
+  HB_EW_GAUSS_LOGPDF_GRAD = 80 /* (x,mu,var,g) -> (gx,gmu,gvar) */
+};
+
+/* out[k][i] = op(in[0][bcast(i)], ...); every output is contiguous with the
+ * broadcast `shape[ndim]`; `istrides` is [nin][ndim] in elements (0 = broadcast).
+ * in/out/istrides/shape/params are (host) arrays; params has 4 doubles or NULL. */
+int hb_ewise_f32(int op, int nin, const void* const* in, const long* istrides, int nout,
+                 void* const* out, int ndim, const long* shape, const double* params, void* stream);
+int hb_ewise_f64(int op, int nin, const void* const* in, const long* istrides, int nout,
+                 void* const* out, int ndim, const long* shape, const double* params, void* stream);
+
+enum { HB_RED_SUM = 0, HB_RED_MAX = 1 };
+/* out[K1,K2] = reduce over R of contiguous in[K1,R,K2]  (tf.reduce_sum / reduce_max) */
+int hb_reduce_f32(int op, const float* in, float* out, long K1, long R, long K2, float* ws,
+                  long ws_elems, void* stream);
+int hb_reduce_f64(int op, const double* in, double* out, long K1, long R, long K2, double* ws,
+                  long ws_elems, void* stream);
+
+/* strided n-d copy, strides in elements (tf.transpose / slice / tile / concat) */
+int hb_copy_nd_f32(const float* in, const long* istr, float* out, const long* ostr, int ndim,
+                   const long* shape, void* stream);
+int hb_copy_nd_f64(const double* in, const long* istr, double* out, const long* ostr, int ndim,
+                   const long* shape, void* stream);
+
+int hb_fill_f32(float* out, long n, double v, void* stream);
+int hb_fill_f64(double* out, long n, double v, void* stream);
+
+/* K0: dst[i,:] = src[perm[idx[i]],:]  (perm nullable).  Device-resident form
+ * of MinibatchData.get_feed_dict's `self.data[minibatch_index]`, reference
+ * param.py:733-739, with Indexer's train/test permutation (model.py:147-153)
+ * applied on device.  *err is set to 1 on an out-of-range index. */
+int hb_gather_rows_f32(const float* src, long nsrc, long row, const long* idx, const long* perm,
+                       long n, float* dst, int* err, void* stream);
+int hb_gather_rows_f64(const double* src, long nsrc, long row, const long* idx, const long* perm,
+                       long n, double* dst, int* err, void* stream);
+
+/* batched [B,R,C] matrix utilities.  mode 0 = tf.matrix_band_part(lower,upper)
+ * (reference variationals.py:145); 1 = + alpha*I (kernels.py:100 jitter);
+ * 2 = Phi (lower triangle, halved diagonal) of the Cholesky gradient;
+ * 3 = 0.5*(A + A^T). */
+int hb_matutil_f32(const float* in, float* out, long B, long R, long C, int mode, long lower,
+                   long upper, double alpha, void* stream);
+int hb_matutil_f64(const double* in, double* out, long B, long R, long C, int mode, long lower,
+                   long upper, double alpha, void* stream);
+
+/* ---- RNG: xoroshiro128+ per lane (replaces tf.random_normal, reference
+ *      variationals.py:107,127; gp/gp.py:132,138,142; and np.random.randint
+ *      of model.py:147-153) ------------------------------------------------ */
+/* state = 2*nlanes uint64 (s0[nlanes] then s1[nlanes]); seeded by splitmix64
+ * from (seed, stream_id, lane). */
+int hb_rng_init(uint64_t* state, long nlanes, uint64_t seed, uint64_t stream_id, void* stream);
+int hb_rng_normal_f32(uint64_t* state, long nlanes, float* out, long n, void* stream);
+int hb_rng_normal_f64(uint64_t* state, long nlanes, double* out, long n, void* stream);
+/* uniform integers in [lo, hi), with replacement */
+int hb_rng_randint(uint64_t* state, long nlanes, long* out, long n, long lo, long hi, void* stream);
+
+/* ---- K1/K2: reparameterised Gaussian sampler fused with the Monte-Carlo KL
+ *      (reference variationals.py:131-153 _sample, :178-186 logdet,
+ *      :225-230 Normal._KL) ------------------------------------------------ */
+/* diagonal q: x = mu + exp(s)*u ; kl = -0.5*sum(2 s + u^2 - x^2) over all n
+ * elements.  u_in nullable (then drawn from rng, which must be non-null);
+ * u_out, x: [n]; kl: 1 element; ws >= 2048 elements. */
+int hb_diag_sample_kl_fwd_f32(const float* mu, const float* s, const float* u_in, uint64_t* rng,
+                              long rng_lanes, float* u_out, float* x, float* kl, long n, float* ws,
+                              void* stream);
+int hb_diag_sample_kl_fwd_f64(const double* mu, const double* s, const double* u_in, uint64_t* rng,
+                              long rng_lanes, double* u_out, double* x, double* kl, long n,
+                              double* ws, void* stream);
+/* VJP.  xbar nullable (= 0); klbar = d loss / d kl, one device scalar
+ * (nullable = 0).  mubar = xbar + klbar*x ; sbar = mubar*exp(s)*u - klbar. */
+int hb_diag_sample_kl_bwd_f32(const float* s, const float* u, const float* x, const float* xbar,
+                              const float* klbar, float* mubar, float* sbar, long n, void* stream);
+int hb_diag_sample_kl_bwd_f64(const double* s, const double* u, const double* x, const double* xbar,
+                              const double* klbar, double* mubar, double* sbar, long n,
+                              void* stream);
+/* full-rank q over `rows` independent blocks: x_r = mu_r + tril(S_r) u_r ;
+ * kl = -0.5*sum(log S_kk^2 + u^2 - x^2).  S: [rows,size,size] (upper part
+ * ignored), mu/u/x: [rows,size]. */
+int hb_fullrank_sample_kl_fwd_f32(const float* mu, const float* S, const float* u_in, uint64_t* rng,
+                                  long rng_lanes, float* u_out, float* x, float* kl, long rows,
+                                  long size, float* ws, void* stream);
+int hb_fullrank_sample_kl_fwd_f64(const double* mu, const double* S, const double* u_in,
+                                  uint64_t* rng, long rng_lanes, double* u_out, double* x,
+                                  double* kl, long rows, long size, double* ws, void* stream);
+/* mubar = xbar + klbar*x ; Sbar = tril(mubar u^T) - klbar*diag(1/S_kk) ; strictly upper = 0 */
+int hb_fullrank_sample_kl_bwd_f32(const float* S, const float* u, const float* x, const float* xbar,
+                                  const float* klbar, float* mubar, float* Sbar, long rows,
+                                  long size, void* stream);
+int hb_fullrank_sample_kl_bwd_f64(const double* S, const double* u, const double* x,
+                                  const double* xbar, const double* klbar, double* mubar,
+                                  double* Sbar, long rows, long size, void* stream);
+
+/* ---- K3: stationary Gram matrices (reference gp/kernels.py:54-84
+ *      square_dist, :110-111 UnitRBF.K, :122-131 UnitCsymRBF) -------------- */
+enum { HB_KERN_RBF = 0, HB_KERN_CSYM_RBF = 1 };
+/* K[b,i,j] = k(X[b,i,:], X2[b,j,:]); sX/sX2 = batch strides in elements (0 =
+ * shared); ell has dl = 1 (scalar) or d entries (ARD), post-transform. */
+int hb_gram_fwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
+                    long dl, float* K, long B, long n, long n2, long d, void* stream);
+int hb_gram_fwd_f64(int kind, const double* X, long sX, const double* X2, long sX2,
+                    const double* ell, long dl, double* K, long B, long n, long n2, long d,
+                    void* stream);
+/* VJP: Xbar[B,n,d], X2bar[B,n2,d] (either nullable), ellbar[dl] (nullable).
+ * ws >= B*n*dl elements when ellbar != NULL. */
+int hb_gram_bwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
+                    long dl, const float* Kbar, float* Xbar, float* X2bar, float* ellbar, long B,
+                    long n, long n2, long d, float* ws, void* stream);
+int hb_gram_bwd_f64(int kind, const double* X, long sX, const double* X2, long sX2,
+                    const double* ell, long dl, const double* Kbar, double* Xbar, double* X2bar,
+                    double* ellbar, long B, long n, long n2, long d, double* ws, void* stream);
+
+/* ---- dense linear algebra on MFMA (f32: v_mfma_f32_32x32x2_f32, f64:
+ *      v_mfma_f64_16x16x4_f64) --------------------------------------------- */
+enum { HB_MM_LOWER_OUT = 1 /* only tiles touching the lower triangle of C are computed */ };
+enum { HB_ACT_NONE = 0, HB_ACT_SIGMOID = 1, HB_ACT_RELU = 2, HB_ACT_TANH = 3 };
+/* C[b] = act(alpha * op(A[b]) op(B[b]) + bias[b]) + beta * C[b], op = transpose if trans?.
+ * A is M x K (after op), B is K x N, C is M x N; ld* = row strides, s* = batch
+ * strides (0 = broadcast), bias nullable = per-column [N] (sBias batch stride).
+ * Replaces tf.matmul (reference gp/gp.py:50,122,125,171; nn.py:32) and, with
+ * bias/act, the fused MatBias layer clip(x@w+b) + activation (nn.py:31-32,79-84).
+ * ws: split-K scratch (nullable -> no split). */
+int hb_matmul_f32(const float* A, const float* B, float* C, long batch, long M, long N, long K,
+                  long lda, long ldb, long ldc, long sA, long sB, long sC, int transA, int transB,
+                  double alpha, double beta, const float* bias, long sBias, int act, int flags,
+                  float* ws, long ws_elems, void* stream);
+int hb_matmul_f64(const double* A, const double* B, double* C, long batch, long M, long N, long K,
+                  long lda, long ldb, long ldc, long sA, long sB, long sC, int transA, int transB,
+                  double alpha, double beta, const double* bias, long sBias, int act, int flags,
+                  double* ws, long ws_elems, void* stream);
+
+/* K4: L = chol(A), lower, batched [B,M,M]; the strict upper triangle of L is
+ * zeroed; info[B] (device) receives 0 or k+1.  Replaces tf.cholesky
+ * (reference gp/kernels.py:101; gp/gp.py:135).  A and L may alias. */
+int hb_cholesky_f32(const float* A, float* L, long B, long M, int* info, void* stream);
+int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void* stream);
+/* W = L^{-1} (lower triangular inverse), batched.  Used in place of
+ * tf.matrix_triangular_solve(Lm, .) (reference gp/gp.py:162,169): the
+ * reference's own batched branch forms the explicit inverse the same way.
+ * ws >= B*M*M elements (nullable when M <= 32); W must not alias L. */
+int hb_trinv_f32(const float* L, float* W, long B, long M, float* ws, void* stream);
+int hb_trinv_f64(const double* L, double* W, long B, long M, double* ws, void* stream);
+
+/* ---- K5/K6: fused sparse-GP conditional (reference gp/gp.py:99-143 samples,
+ *      :146-162 _effective_LT, :177-189 _additional_cov 'diagonal') -------- */
+enum { HB_SGP_NEGLECTED = 0, HB_SGP_DIAGONAL = 1 };
+/* Per expert e < E (all arrays carry a leading E; x may be shared: sx = 0):
+ *   Kmn = k(z, x)            [M,n]   (never written to memory)
+ *   A   = W Kmn              [M,n]   W = chol(Kmm + jitter I)^{-1}
+ *   mean= u A                [P,n]
+ *   v   = kdiag(x) - sum_m A^2        [n]
+ *   f   = mean + sqrt(|v|) * eps      (DIAGONAL; eps [n] shared by the P rows,
+ *                                      reference gp/gp.py:131-132)  or mean (NEGLECTED)
+ * eps_in nullable -> drawn from rng; eps_out [E,n] receives the noise used.
+ * ws >= hb_sgp_ws_elems(...) elements. */
+long hb_sgp_ws_elems(long E, long n, long M, long d, long P);
+int hb_sgp_fwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell,
+                   long dl, const float* W, const float* u, const float* eps_in, uint64_t* rng,
+                   long rng_lanes, float* eps_out, float* A, float* f, float* v, long E, long n,
+                   long M, long d, long P, float* ws, void* stream);
+int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
+                   long dl, const double* W, const double* u, const double* eps_in, uint64_t* rng,
+                   long rng_lanes, double* eps_out, double* A, double* f, double* v, long E, long n,
+                   long M, long d, long P, double* ws, void* stream);
+/* VJP given fbar [E,P,n]:
+ *   Abar = u^T fbar + A diag(c),  c = -eps sign(v)/sqrt|v| * sum_p fbar_p
+ *   Kbar = W^T Abar            [E,M,n]  (scratch output, kept for Lbar)
+ *   Lbar = -tril(Kbar A^T)     [E,M,M]
+ *   ubar = fbar A^T            [E,P,M]
+ *   zbar, ellbar (and xbar, nullable) through Kmn = k(z,x). */
+int hb_sgp_bwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell,
+                   long dl, const float* W, const float* u, const float* eps, const float* A,
+                   const float* v, const float* fbar, float* Kbar, float* Lbar, float* ubar,
+                   float* zbar, float* ellbar, float* xbar, long E, long n, long M, long d, long P,
+                   float* ws, void* stream);
+int hb_sgp_bwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
+                   long dl, const double* W, const double* u, const double* eps, const double* A,
+                   const double* v, const double* fbar, double* Kbar, double* Lbar, double* ubar,
+                   double* zbar, double* ellbar, double* xbar, long E, long n, long M, long d,
+                   long P, double* ws, void* stream);
+
+/* ---- K9: flat-buffer Adam, TensorFlow-1 formula (reference model.py:206,220
+ *      tf.train.AdamOptimizer via optimizer.minimize) --------
+ *   t <- t+1 ; lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+ *   m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; theta <- theta - lr_t m/(sqrt(v)+eps)
+ * g is read as gscale*g (gscale = 1/world_size for data-parallel means).
+ * t is a device-side step counter (one int64), incremented by the call. */
+int hb_adam_step_f32(float* theta, const float* g, float* m, float* v, long n, double lr, double b1,
+                     double b2, double eps, double gscale, long* t, void* stream);
+int hb_adam_step_f64(double* theta, const double* g, double* m, double* v, long n, double lr,
+                     double b1, double b2, double eps, double gscale, long* t, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HENBUN_HIP_H */

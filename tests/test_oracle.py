@@ -1,0 +1,241 @@
+"""Pin the CPU oracle to the reference's own known-answer formulas.
+
+Each test names the reference test whose inline numpy oracle produced the
+golden numbers (tests/golden/make_golden.py re-derives them with the same
+seeds); tolerances are at least as tight as the reference's own.
+"""
+import numpy as np
+import torch
+
+import henbun_oracle as O
+
+T = O.T
+
+
+def close(a, b, atol=1e-10, rtol=1e-10):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return np.allclose(a, b, atol=atol, rtol=rtol)
+
+
+def test_kernels_K_and_Kdiag(golden):
+    # reference testing/test_kernels.py:90-182 (atol 1e-4 there)
+    g = golden
+    l1, l2 = T(g["k_l1"]), T(g["k_l2"])
+    X, X2, Xb, X2b = T(g["k_X"]), T(g["k_X2"]), T(g["k_Xb"]), T(g["k_X2b"])
+    assert close(O.rbf_K(X, None, l1), g["k_rbf1_XX"])
+    assert close(O.rbf_K(X, None, l2), g["k_rbf2_XX"])
+    assert close(O.csym_rbf_K(X, None, l1), g["k_csym_XX"])
+    assert close(O.rbf_K(X, X2, l1), g["k_rbf1_XX2"])
+    assert close(O.rbf_K(X, X2, l2), g["k_rbf2_XX2"])
+    assert close(O.csym_rbf_K(X, X2, l1), g["k_csym_XX2"])
+    assert close(O.rbf_K(Xb, None, l1), g["k_rbf1_b"])
+    assert close(O.rbf_K(Xb, None, l2), g["k_rbf2_b"])
+    assert close(O.csym_rbf_K(Xb, None, l1), g["k_csym_b"])
+    assert close(O.rbf_K(Xb, X2b, l1), g["k_rbf1_b2"])
+    assert close(O.rbf_K(Xb, X2b, l2), g["k_rbf2_b2"])
+    assert close(O.csym_rbf_K(Xb, X2b, l1), g["k_csym_b2"])
+    assert close(O.rbf_Kdiag(X), np.ones(5))
+    assert close(O.csym_rbf_Kdiag(X, l1), g["k_csym_diag"])
+    assert close(O.csym_rbf_Kdiag(Xb, l1), g["k_csym_diag_b"])
+    # batch == non-batch (test_kernels.py:110-125)
+    assert close(O.rbf_K(X[None], None, l2)[0], g["k_rbf2_XX"])
+
+
+def test_kernel_cholesky_reconstructs(golden):
+    # reference testing/test_kernels.py:184-226: L L^T ~ K (+ jitter)
+    g = golden
+    X, l2 = T(g["k_X"]), T(g["k_l2"])
+    L = O.kern_cholesky(X, l2, 1e-5)
+    assert close(L @ L.T, g["k_rbf2_XX"] + 1e-5 * np.eye(5), atol=1e-12)
+    Lb = O.kern_cholesky(T(g["k_Xb"]), l2, 1e-5)
+    assert close(Lb @ Lb.transpose(-1, -2), g["k_rbf2_b"] + 1e-5 * np.eye(5), atol=1e-12)
+    assert np.allclose(np.triu(L.numpy(), 1), 0)
+
+
+def test_variational_logdet_sample_kl(golden):
+    # reference testing/test_variationals.py:69-122
+    g = golden
+    mu, iid = T(g["v_mu"]), T(g["v_iid"])
+    sf, sd = T(g["v_sq_full"]), T(g["v_sq_diag"])
+    assert close(O.logdet(sf, "fullrank"), g["v_logdet_full"])
+    assert close(O.logdet(sd, "diagonal"), g["v_logdet_diag"])
+    assert close(O.sample_fullrank(mu, sf, iid), g["v_post_full"])
+    assert close(O.sample_diag(mu, sd, iid), g["v_post_diag"])
+    assert np.isclose(O.gaussian_kl_analytic(g["v_mu"], g["v_sq_full"], "fullrank"), g["v_kl_full"])
+    assert np.isclose(O.gaussian_kl_analytic(g["v_mu"], g["v_sq_diag"], "diagonal"), g["v_kl_diag"])
+    # MC-KL mean over draws approaches the analytic value (reference: 100 draws, rtol 0.1)
+    rng = np.random.RandomState(1)
+    for shape, sq, ana in (("fullrank", sf, g["v_kl_full"]), ("diagonal", sd, g["v_kl_diag"])):
+        acc = 0.0
+        for _ in range(400):
+            u = T(rng.randn(3, 10))
+            x = O.sample_fullrank(mu, sq, u) if shape == "fullrank" else O.sample_diag(mu, sq, u)
+            acc += O.kl_normal(sq, u, x, shape).item()
+        assert np.isclose(acc / 400, ana, rtol=0.1)
+    # Normal._KL equals the generic KL with prior=Normal, transform=Identity (variationals.py:198-230)
+    u = T(rng.randn(3, 10))
+    x = O.sample_diag(mu, sd, u)
+    assert np.isclose(O.kl_normal(sd, u, x, "diagonal").item(),
+                      O.kl_generic(sd, u, x, "diagonal", prior_logp=O.prior_normal_logp).item())
+
+
+def test_feed_split_order():
+    # reference param.py:516-537 / testing/test_variationals.py:205-222: q_mu first, then q_sqrt
+    x = T(np.arange(2 * 5 * 6).reshape(2, 5, 6))
+    a, b = O.feed_split(x, [2, 4])
+    assert a.shape == (2, 5, 2) and b.shape == (2, 5, 4)
+    assert close(a, x.numpy()[..., :2]) and close(b, x.numpy()[..., 2:])
+
+
+def test_sparse_gp_fixture(golden):
+    # reference testing/test_gp.py:68-91 (atol 5e-3) and :115-131 (atol 1e-4)
+    g = golden
+    z, ell, x = T(g["g_z"]), T(g["g_ell"]), T(g["g_x"])
+    LT = O.sparse_effective_LT(z, z, ell, 1e-5)
+    assert close(LT, g["g_cholT"], atol=5e-3)
+    LnT = O.sparse_effective_LT(x, z, ell, 1e-5)
+    # the fixture is ill-conditioned (cond(Kzz) ~ 1e9): LAPACK solve vs triangular solve agree to ~1e-6
+    assert close(LnT, g["g_LnT"], atol=1e-5)
+    cf = O.sparse_additional_cov(x, LnT, ell, "fullrank")
+    cd = O.sparse_additional_cov(x, LnT, ell, "diagonal")
+    assert close(torch.diagonal(cf), cd.numpy(), atol=1e-10)
+    assert close(cd, g["g_cov_diag"], atol=1e-4)
+    # batched branch (explicit inverse + tile) equals the 2-D branch
+    xb = x[None].expand(3, -1, -1)
+    LnTb = O.sparse_effective_LT(xb, z, ell, 1e-5)
+    assert close(LnTb[1], LnT.numpy(), atol=1e-6)
+    # shapes for all three residual modes (test_gp.py:133-176)
+    u = T(np.random.RandomState(0).randn(20, 30))
+    for mode, eps in (("neglected", None), ("diagonal", T(np.ones(20))), ("fullrank", T(np.ones((20, 20))))):
+        assert tuple(O.sparse_samples(x, u, z, ell, 1e-5, mode, eps).shape) == (20, 20)
+
+
+def test_densities(golden):
+    # reference testing/test_densities.py:11-75 (atol 1e-5)
+    g = golden
+    lp0 = O.gaussian(T(g["d_a"]), T(0.0), T(2.0))
+    lp1 = O.student_t(T(g["d_b"]), T(0.0), T(2.0), 3.0)
+    assert close(lp0, g["d_logp0"]) and close(lp1, g["d_logp1"])
+    assert close(O.bimixture(T(g["d_frac"]), lp0, lp1), g["d_mix"])
+    assert close(O.student_t(T(g["s_x"]), T(g["s_mu"]), T(g["s_scale"]), 3.0), g["s_logp_nu3"])
+    assert close(O.student_t(T(g["s_x"]), T(g["s_mu"]), T(g["s_scale"]), T(g["s_nu"])), g["s_logp_nuT"])
+
+
+def test_mvn_matches_scipy():
+    from scipy.stats import multivariate_normal as mvn
+
+    rng = np.random.RandomState(0)
+    A = rng.randn(4, 4)
+    S = A @ A.T + 4 * np.eye(4)
+    L = np.linalg.cholesky(S)
+    x, mu = rng.randn(4), rng.randn(4)
+    assert np.isclose(O.multivariate_normal(T(x), T(mu), T(L)).item(), mvn(mu, S).logpdf(x))
+
+
+def test_log_sum_exp_and_transforms(golden):
+    # reference testing/test_tf_wraps.py:45-59 ; test_transforms.py:39-53
+    g = golden
+    assert close(O.log_sum_exp(T(g["lse_in"]), 1), g["lse_axis1"])
+    assert close(O.log_sum_exp(T(g["lse_in"]), 2), g["lse_axis2"])
+    y = O.log1pe_forward(T(g["t_x"]))
+    assert close(y, g["t_log1pe"])
+    assert np.allclose(O.log1pe_backward_np(y.numpy()), g["t_x"], atol=1e-8)
+    assert close(O.clip(T([-60.0, 3.0, 70.0]), True), [-50.0, 3.0, 50.0])
+    assert close(O.clip(T([-60.0, 3.0, 70.0]), False), [-60.0, 3.0, 70.0])
+
+
+def test_neural_net(golden):
+    # reference testing/test_nn.py:11-29 (layered weights, sigmoid between, none after last)
+    g = golden
+    y = O.neural_net(T(g["n_x"]), [T(g["n_w1"]), T(g["n_w2"])], [T(g["n_b1"]), T(g["n_b2"])])
+    assert close(y, g["n_y"])
+
+
+def test_adam_tf_converges():
+    # reference testing/test_model.py:16-29: maximise -sum(p^2), lr 0.01, 1500 its -> 0 (atol 1e-4)
+    rng = np.random.RandomState(0)
+    p = T(np.clip(rng.randn(2, 3), -2, 2))
+    opt = O.AdamTF([p], lr=0.01)
+    for _ in range(1500):
+        opt.step([2.0 * p])  # grad of -objective = +2p
+    assert np.allclose(p.numpy(), 0.0, atol=1e-4)
+
+
+def test_adam_tf_first_step_formula():
+    p = T([1.0, -2.0])
+    opt = O.AdamTF([p], lr=1e-3)
+    opt.step([T([0.5, -4.0])])
+    # t=1: m=(1-b1)g, v=(1-b2)g^2, lr_t=lr*sqrt(1-b2)/(1-b1)
+    g = np.array([0.5, -4.0])
+    lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    exp = np.array([1.0, -2.0]) - lr_t * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-8)
+    assert np.allclose(p.numpy(), exp, rtol=1e-12)
+
+
+def test_indexer_semantics():
+    # reference model.py:126-153 / testing/test_model.py:116-135
+    idx = O.Indexer(100, np.random.RandomState(0))
+    assert idx.test_size == 10 and idx.train_size == 90
+    tr = idx.train_index(1000)
+    te = idx.test_index(20)
+    assert te.shape == (20,)
+    assert set(tr).isdisjoint(set(te))
+    assert len(set(tr)) < 1000  # with replacement
+
+
+def _svgp_params(rng, M=12, d=1, q_shape="diagonal"):
+    p = {
+        "z": T(np.linspace(0, 6, M)[:, None] + 0.01 * rng.randn(M, d)),
+        "ell_raw": T(O.log1pe_backward_np(np.ones(1) * 0.9)),
+        "q_mu": T(0.3 * rng.randn(1, M)),
+        "k_var_raw": T(O.log1pe_backward_np(np.ones(1) * 1.3)),
+        "var_raw": T(O.log1pe_backward_np(np.ones(1) * 0.4)),
+    }
+    if q_shape == "diagonal":
+        p["q_sqrt"] = T(-0.5 + 0.1 * rng.randn(M))
+    else:
+        p["q_sqrt"] = T(0.3 * np.eye(M) + 0.05 * rng.randn(M, M))
+    return p
+
+
+def test_svgp_elbo_autograd_matches_finite_differences():
+    # gradient values are NOT pinned by the reference (its tests only assert a gradient exists,
+    # testing/test_gp.py:49-55); autograd and central differences must agree with each other.
+    rng = np.random.RandomState(0)
+    for q_shape in ("diagonal", "fullrank"):
+        p = _svgp_params(rng, q_shape=q_shape)
+        X = T(rng.uniform(0, 6, (40, 1)))
+        Y = T(np.sin(X.numpy()) + 0.3 * rng.randn(40, 1))
+        u = T(rng.randn(12))
+        eps = T(rng.randn(40))
+        fn = lambda q: O.svgp_elbo(q, X, Y, 1000.0, u, eps, jitter=1e-4, q_shape=q_shape)
+        val, gr = O.grads_of(fn, p)
+        assert np.isfinite(val.item())
+        for key in p:
+            flat = gr[key].reshape(-1)
+            for idx in (0, flat.numel() // 2, flat.numel() - 1):
+                fd = O.finite_difference(fn, p, key, idx, h=1e-6)
+                assert np.isclose(flat[idx].item(), fd, rtol=2e-5, atol=2e-5), (q_shape, key, idx)
+        if q_shape == "fullrank":
+            # strictly-upper entries of q_sqrt are masked: zero gradient (variationals.py:145)
+            assert np.allclose(np.triu(gr["q_sqrt"].numpy(), 1), 0.0)
+
+
+def test_amortised_elbo_autograd_matches_finite_differences():
+    rng = np.random.RandomState(0)
+    Din, H, L, n = 6, 5, 3, 16
+    p = {
+        "enc_w0": T(rng.randn(Din, H) / np.sqrt(Din)), "enc_b0": T(0.1 * rng.randn(1, H)),
+        "enc_w1": T(rng.randn(H, 2 * L) / np.sqrt(H)), "enc_b1": T(0.1 * rng.randn(1, 2 * L)),
+        "dec_w0": T(rng.randn(L, Din) / np.sqrt(L)), "dec_b0": T(0.1 * rng.randn(1, Din)),
+        "var_raw": T(O.log1pe_backward_np(np.ones(1) * 0.5)),
+    }
+    Y = T(rng.randn(n, Din))
+    u = T(rng.randn(n, L))
+    fn = lambda q: O.amortised_elbo(q, Y, u)
+    val, gr = O.grads_of(fn, p)
+    for key in p:
+        flat = gr[key].reshape(-1)
+        for idx in (0, flat.numel() - 1):
+            fd = O.finite_difference(fn, p, key, idx, h=1e-6)
+            assert np.isclose(flat[idx].item(), fd, rtol=2e-5, atol=2e-5), (key, idx)
