@@ -39,32 +39,37 @@ template <typename T, bool TA, bool TB>
 __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
   typedef TileGemm<T, 64, 64, 16, 2, 2> G;
   __shared__ T lds[G::LDS_ELEMS];
-  const int tiles_n = (int)((a.N + 63) / 64);
-  const long row0 = (long)(blockIdx.x / tiles_n) * 64;
-  const long col0 = (long)(blockIdx.x % tiles_n) * 64;
+  const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
+  const int lda = (int)a.lda, ldb = (int)a.ldb;
+  const int tiles_n = (N + 63) / 64;
+  const int row0 = (blockIdx.x / tiles_n) * 64;
+  const int col0 = (blockIdx.x % tiles_n) * 64;
   const long b = blockIdx.y;
   const int s = blockIdx.z;
   if ((a.flags & HB_MM_LOWER_OUT) && col0 > row0 + 63) return;
-  long kchunk = (a.K + a.S - 1) / a.S;
+  int kchunk = (K + a.S - 1) / a.S;
   kchunk = ((kchunk + G::BK - 1) / G::BK) * G::BK;
-  const long kbeg = s * kchunk;
-  long kend = kbeg + kchunk;
-  if (kend > a.K) kend = a.K;
+  const int kbeg = s * kchunk;
+  int kend = kbeg + kchunk;
+  if (kend > K) kend = K;
   const T* Ab = a.A + b * a.sA;
   const T* Bb = a.B + b * a.sB;
   G g;
   g.zero();
-  auto fa = [&](int m, long k) -> T {
-    const long r = row0 + m;
-    if (r >= a.M) return T(0);
-    return TA ? Ab[k * a.lda + r] : Ab[r * a.lda + k];
+  const int Mm1 = M - 1, Nm1 = N - 1;
+  auto la = [&](int m, int k) -> T {
+    const int r = row0 + m;
+    const int rr = r < M ? r : Mm1;
+    return TA ? Ab[k * lda + rr] : Ab[rr * lda + k];
   };
-  auto fb = [&](long k, int n) -> T {
-    const long c = col0 + n;
-    if (c >= a.N) return T(0);
-    return TB ? Bb[c * a.ldb + k] : Bb[k * a.ldb + c];
+  auto fa = [&](T raw, int m, int k) -> T { return row0 + m < M ? raw : T(0); };
+  auto lb = [&](int k, int n) -> T {
+    const int c = col0 + n;
+    const int cc = c < N ? c : Nm1;
+    return TB ? Bb[cc * ldb + k] : Bb[k * ldb + cc];
   };
-  g.template run<!TA, TB>(kbeg, kend, fa, fb, lds, lds + G::BK * G::LDA);
+  auto fb = [&](T raw, int k, int n) -> T { return col0 + n < N ? raw : T(0); };
+  g.template run<!TA, TB>(kbeg, kend, la, fa, lb, fb, lds);
   if (a.S > 1) {
     T* wsb = a.ws + ((long)s * a.batch + b) * a.M * a.N;
     g.for_each([&](int row, int col, T v) {
@@ -114,6 +119,8 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   HB_REQUIRE(A && B && C, "hb_matmul: NULL pointer");
   HB_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "hb_matmul: leading dimension too small");
   HB_REQUIRE(batch <= 65535, "hb_matmul: batch too large");
+  HB_REQUIRE((transA ? K : M) * lda < 2147483647L && (transB ? N : K) * ldb < 2147483647L,
+             "hb_matmul: operand too large for 32-bit indexing");
   HB_REQUIRE(act >= HB_ACT_NONE && act <= HB_ACT_TANH, "hb_matmul: unknown activation %d", act);
   if (batch * M * N == 0) return 0;
   MmArgs<T> a;
@@ -184,27 +191,41 @@ extern "C" int hb_matmul_f64(const double* A, const double* B, double* C, long b
 #define CH_NB 32
 #define CH_RB 96
 
+__device__ __forceinline__ float bcast_lane(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  const long long r = ((long long)hi << 32) | (unsigned int)lo;
+  return __builtin_bit_cast(double, r);
+}
+
+// Factor a 32x32 SPD block held one ROW per lane (a[j] = row `lane&31`, column
+// j; lanes 32..63 mirror 0..31).  Right-looking, fully unrolled: column k is
+// scaled in place, then every later column j gets a[j] -= l_rk * l_jk with
+// l_jk broadcast from lane j by v_readlane (no LDS, no barriers).  Returns
+// k+1 of the first non-positive pivot (0 = ok).  Upper-triangle entries end
+// up holding garbage and must be ignored by the caller.
 template <typename T>
-__device__ __forceinline__ void potrf32_wave(volatile T (*Cs)[CH_NB + 1], int nb, int* info, long j0, bool report) {
-  const int lane = threadIdx.x & 63;
-  const int r = lane & 31, h = lane >> 5;
-  for (int k = 0; k < nb; ++k) {
-    const T p = Cs[k][k];
-    if (report && lane == 0 && !(p > T(0))) {
-      if (*info == 0) *info = (int)(j0 + k + 1);
-    }
-    const T lkk = hb_sqrt(p);
+__device__ __forceinline__ int potrf32_regs(T (&a)[CH_NB], int lane) {
+  const int r = lane & 31;
+  int fail = 0;
+#pragma unroll
+  for (int k = 0; k < CH_NB; ++k) {
+    const T d = bcast_lane(a[k], k);
+    if (fail == 0 && !(d > T(0))) fail = k + 1;
+    const T lkk = hb_sqrt(d);
     const T inv = T(1) / lkk;
-    __builtin_amdgcn_wave_barrier();
-    if (h == 0 && r > k && r < nb) Cs[r][k] = Cs[r][k] * inv;
-    if (lane == 0) Cs[k][k] = lkk;
-    __builtin_amdgcn_wave_barrier();
-    if (r > k && r < nb) {
-      const T lrk = Cs[r][k];
-      for (int j = k + 1 + h; j <= r; j += 2) Cs[r][j] = Cs[r][j] - lrk * Cs[j][k];
+    a[k] = (r == k) ? lkk : a[k] * inv;
+#pragma unroll
+    for (int j = k + 1; j < CH_NB; ++j) {
+      const T ljk = bcast_lane(a[k], j);
+      a[j] -= a[k] * ljk;
     }
-    __builtin_amdgcn_wave_barrier();
   }
+  return fail;
 }
 
 template <typename T>
@@ -217,40 +238,57 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(const T* __restrict__ A
   Ain += b * M * M;
   L += b * M * M;
   info += b;
-  const int nb = (int)((M - j0) < CH_NB ? (M - j0) : CH_NB);
-  const long r0 = j0 + CH_NB + (long)blockIdx.x * CH_RB;
-  auto grow = [&](int m) -> long { return m < CH_NB ? j0 + m : r0 + (m - CH_NB); };
-  auto rvalid = [&](int m) -> bool { return m < CH_NB ? m < nb : (r0 + (m - CH_NB)) < M; };
+  const int Mi = (int)M, j0i = (int)j0;
+  const int nb = (Mi - j0i) < CH_NB ? (Mi - j0i) : CH_NB;
+  const int r0 = j0i + CH_NB + blockIdx.x * CH_RB;
+  auto rvalid = [&](int m) -> bool { return m < CH_NB ? m < nb : (r0 + (m - CH_NB)) < Mi; };
+  // global row of tile row m, clamped to a safe row when invalid
+  auto grow = [&](int m) -> int { return rvalid(m) ? (m < CH_NB ? j0i + m : r0 + (m - CH_NB)) : j0i; };
   G g;
   g.zero();
-  auto fa = [&](int m, long k) -> T { return rvalid(m) ? L[grow(m) * M + k] : T(0); };
-  auto fb = [&](long k, int n) -> T { return n < nb ? L[(j0 + n) * M + k] : T(0); };
-  g.template run<true, true>(0, j0, fa, fb, lds, lds + G::BK * G::LDA);
+  auto la = [&](int m, int k) -> T { return L[grow(m) * Mi + k]; };
+  auto fa = [&](T raw, int m, int k) -> T { return rvalid(m) ? raw : T(0); };
+  auto lb = [&](int k, int n) -> T { return L[(j0i + (n < nb ? n : nb - 1)) * Mi + k]; };
+  auto fb = [&](T raw, int k, int n) -> T { return n < nb ? raw : T(0); };
+  g.template run<true, true>(0, j0i, la, fa, lb, fb, lds);
   g.for_each([&](int row, int col, T v) {
-    T aval = T(0);
-    if (rvalid(row) && col < nb) aval = Ain[grow(row) * M + j0 + col];
-    Cs[row][col] = aval - v;
+    const bool ok = rvalid(row) && col < nb;
+    const T aval = Ain[(long)grow(row) * M + j0 + (col < nb ? col : nb - 1)];
+    T c = ok ? aval - v : T(0);
+    if (row < CH_NB && row >= nb && col == row) c = T(1);  // identity padding of a ragged last panel
+    Cs[row][col] = c;
   });
   __syncthreads();
-  if (threadIdx.x < 64) potrf32_wave<T>((volatile T(*)[CH_NB + 1])Cs, nb, info, j0, blockIdx.x == 0);
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    T a[CH_NB];
+#pragma unroll
+    for (int j = 0; j < CH_NB; ++j) a[j] = Cs[lane & 31][j];
+    const int fail = potrf32_regs<T>(a, lane);
+    if (lane < CH_NB) {
+#pragma unroll
+      for (int j = 0; j < CH_NB; ++j) Cs[lane][j] = a[j];
+    }
+    if (blockIdx.x == 0 && lane == 0 && fail != 0 && fail <= nb) {
+      if (*info == 0) *info = (int)(j0 + fail);
+    }
+  }
   __syncthreads();
   // panel rows: x L_jj^T = c, forward substitution along the row
   if (threadIdx.x < CH_RB) {
     const int m = CH_NB + threadIdx.x;
-    const long r = r0 + threadIdx.x;
+    const long r = (long)r0 + threadIdx.x;
     if (r < M) {
       T xr[CH_NB];
 #pragma unroll
       for (int c = 0; c < CH_NB; ++c) xr[c] = Cs[m][c];
 #pragma unroll
       for (int c = 0; c < CH_NB; ++c) {
-        if (c < nb) {
-          T sacc = xr[c];
+        T sacc = xr[c];
 #pragma unroll
-          for (int k = 0; k < c; ++k) sacc -= xr[k] * Cs[c][k];
-          xr[c] = sacc / Cs[c][c];
-          L[r * M + j0 + c] = xr[c];
-        }
+        for (int k = 0; k < c; ++k) sacc -= xr[k] * Cs[c][k];
+        xr[c] = sacc / Cs[c][c];
+        if (c < nb) L[r * M + j0 + c] = xr[c];
       }
     }
   }
@@ -273,6 +311,7 @@ static int cholesky_launch(const T* A, T* L, long B, long M, int* info, hipStrea
   HB_REQUIRE(B >= 0 && M >= 0, "hb_cholesky: negative extent");
   HB_REQUIRE(A && L && info, "hb_cholesky: NULL pointer");
   HB_REQUIRE(B <= 65535, "hb_cholesky: batch too large");
+  HB_REQUIRE(M * M < 2147483647L, "hb_cholesky: matrix too large for 32-bit indexing");
   if (B == 0) return 0;
   HB_HIP(hipMemsetAsync(info, 0, sizeof(int) * B, stream));
   for (long j0 = 0; j0 < M; j0 += CH_NB) {
@@ -331,48 +370,59 @@ __global__ void __launch_bounds__(64) trinv_diag_kernel(const T* __restrict__ L,
 // phase 1: W [r0+i, c0+j] = -sum_k W[r0+i, r0+k] Tm[r0+k, c0+j]    (k <= i: W22 lower)
 template <typename T, int PHASE>
 __global__ void __launch_bounds__(256) trinv_level_kernel(const T* __restrict__ L, T* __restrict__ W,
-                                                          T* __restrict__ Tm, long M, long s) {
+                                                          T* __restrict__ Tm, long Ml, long sl) {
   typedef TileGemm<T, 64, 64, 16, 2, 2> G;
   __shared__ T lds[G::LDS_ELEMS];
   const long b = blockIdx.z;
-  L += b * M * M;
-  W += b * M * M;
-  Tm += b * M * M;
-  const long pair = blockIdx.y;
-  const long c0 = 2 * pair * s, r0 = c0 + s;
-  const int tps = (int)((s + 63) / 64);  // tiles per side
-  const long ti = (long)(blockIdx.x / tps) * 64, tj = (long)(blockIdx.x % tps) * 64;
+  L += b * Ml * Ml;
+  W += b * Ml * Ml;
+  Tm += b * Ml * Ml;
+  const int M = (int)Ml, s = (int)sl;
+  const int pair = blockIdx.y;
+  const int c0 = 2 * pair * s, r0 = c0 + s;
+  const int tps = (s + 63) / 64;  // tiles per side
+  const int ti = (blockIdx.x / tps) * 64, tj = (blockIdx.x % tps) * 64;
   if (r0 + ti >= M) return;  // tile entirely below the matrix
   G g;
   g.zero();
   if (PHASE == 0) {
-    auto fa = [&](int m, long k) -> T {
-      const long r = r0 + ti + m, c = c0 + k;
-      return (ti + m < s && r < M) ? L[r * M + c] : T(0);
+    auto la = [&](int m, int k) -> T {
+      const int r = r0 + ti + m, c = c0 + k;
+      return L[(r < M ? r : M - 1) * M + c];
     };
-    auto fb = [&](long k, int n) -> T {
-      const long j = tj + n;
-      return (j < s && k >= j) ? W[(c0 + k) * M + c0 + j] : T(0);
+    auto fa = [&](T raw, int m, int k) -> T { return ((ti + m < s) & (r0 + ti + m < M)) ? raw : T(0); };
+    auto lb = [&](int k, int n) -> T {
+      const int cj = c0 + tj + n;
+      return W[(c0 + k) * M + (cj < M ? cj : M - 1)];
     };
-    g.template run<true, false>(tj, s, fa, fb, lds, lds + G::BK * G::LDA);
+    auto fb = [&](T raw, int k, int n) -> T {
+      const int j = tj + n;
+      return ((j < s) & (k >= j)) ? raw : T(0);
+    };
+    g.template run<true, false>(tj, s, la, fa, lb, fb, lds);
     g.for_each([&](int row, int col, T v) {
-      const long i = ti + row, j = tj + col;
+      const int i = ti + row, j = tj + col;
       if (i < s && j < s && r0 + i < M) Tm[(r0 + i) * M + c0 + j] = v;
     });
   } else {
-    long kend = ti + 64;
+    int kend = ti + 64;
     if (kend > s) kend = s;
-    auto fa = [&](int m, long k) -> T {
-      const long i = ti + m;
-      return (i < s && k <= i && r0 + i < M) ? W[(r0 + i) * M + r0 + k] : T(0);
+    auto la = [&](int m, int k) -> T {
+      const int ri = r0 + ti + m, rk = r0 + k;
+      return W[(ri < M ? ri : M - 1) * M + (rk < M ? rk : M - 1)];
     };
-    auto fb = [&](long k, int n) -> T {
-      const long j = tj + n;
-      return (j < s && r0 + k < M) ? Tm[(r0 + k) * M + c0 + j] : T(0);
+    auto fa = [&](T raw, int m, int k) -> T {
+      const int i = ti + m;
+      return ((i < s) & (k <= i) & (r0 + i < M)) ? raw : T(0);
     };
-    g.template run<true, false>(0, kend, fa, fb, lds, lds + G::BK * G::LDA);
+    auto lb = [&](int k, int n) -> T {
+      const int rk = r0 + k, cj = c0 + tj + n;
+      return Tm[(rk < M ? rk : M - 1) * M + (cj < M ? cj : M - 1)];
+    };
+    auto fb = [&](T raw, int k, int n) -> T { return ((tj + n < s) & (r0 + k < M)) ? raw : T(0); };
+    g.template run<true, false>(0, kend, la, fa, lb, fb, lds);
     g.for_each([&](int row, int col, T v) {
-      const long i = ti + row, j = tj + col;
+      const int i = ti + row, j = tj + col;
       if (i < s && j < s && r0 + i < M) W[(r0 + i) * M + c0 + j] = -v;
     });
   }
@@ -384,6 +434,7 @@ static int trinv_launch(const T* L, T* W, long B, long M, T* ws, hipStream_t str
   HB_REQUIRE(L && W, "hb_trinv: NULL pointer");
   HB_REQUIRE(L != W, "hb_trinv: in-place not supported");
   HB_REQUIRE(B <= 65535, "hb_trinv: batch too large");
+  HB_REQUIRE(M * M < 2147483647L, "hb_trinv: matrix too large for 32-bit indexing");
   if (B * M == 0) return 0;
   HB_REQUIRE(M <= CH_NB || ws, "hb_trinv: workspace of B*M*M elements required");
   HB_HIP(hipMemsetAsync(W, 0, sizeof(T) * B * M * M, stream));

@@ -46,76 +46,86 @@ struct SgpArgs {
   long n, M, d, P;
 };
 
-// RBF value between inducing point zk and data point (registers or memory)
-template <typename T>
-__device__ __forceinline__ T rbf_pair(const T* __restrict__ zk, const T* __restrict__ xj, const T* __restrict__ ell,
-                                      long dl, long d) {
-  T r2 = T(0);
-  for (long q = 0; q < d; ++q) {
-    const T t = (zk[q] - xj[q]) / ell[dl == 1 ? 0 : q];
-    r2 += t * t;
-  }
-  return hb_exp(T(-0.5) * r2);
-}
-
 // ---------------------------------------------------------------------------
 // forward: A = W K(z,x)
+//
+// D = compile-time input dimension (1..SGP_DREG) with z/ell staged in LDS and
+// x/ell in registers: the B-operand loader is then branch-free LDS reads + one
+// v_exp per element.  D = 0 is the generic (any d, any M) fallback reading
+// global memory.
 // ---------------------------------------------------------------------------
-template <typename T>
+#define SGP_ZS_MAX 4096  // scaled inducing points kept in LDS (elements)
+
+template <typename T> __device__ __forceinline__ T hb_exp_fast(T x);
+template <> __device__ __forceinline__ float hb_exp_fast<float>(float x) { return __expf(x); }
+template <> __device__ __forceinline__ double hb_exp_fast<double>(double x) { return exp(x); }
+
+template <typename T, int D>
 __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
   typedef TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2> G;
-  __shared__ T lds[G::LDS_ELEMS];
+  __shared__ T lds[G::LDS_ELEMS + (D > 0 ? SGP_ZS_MAX : 1)];
+  T* zs = lds + G::LDS_ELEMS;
   const long e = blockIdx.z;
   const T* x = a.x + e * a.sx;
   const T* z = a.z + e * a.M * a.d;
   const T* ell = a.ell + e * a.dl;
   const T* W = a.W + e * a.M * a.M;
   T* A = a.A + e * a.M * a.n;
-  const long col0 = (long)blockIdx.x * SGP_BN;
-  const int nRB = (int)((a.M + SGP_BM - 1) / SGP_BM);
+  const int M = (int)a.M, n = (int)a.n, d = (int)a.d;
+  const int col0 = blockIdx.x * SGP_BN;
+  const int nRB = (M + SGP_BM - 1) / SGP_BM;
+  const int Mm1 = M - 1;
 
   // this thread's operand column is fixed across k-steps (256 % SGP_BN == 0)
-  const long jcol = col0 + (threadIdx.x % SGP_BN);
-  const bool jok = jcol < a.n;
-  const bool dreg = a.d <= SGP_DREG;
-  T xr[SGP_DREG], il[SGP_DREG];
+  const int jcol = col0 + (threadIdx.x % SGP_BN);
+  const bool jok = jcol < n;
+  const int jc = jok ? jcol : n - 1;
+  T xs[D > 0 ? D : 1];
+  if (D > 0) {
 #pragma unroll
-  for (int q = 0; q < SGP_DREG; ++q) {
-    xr[q] = (dreg && jok && q < a.d) ? x[jcol * a.d + q] : T(0);
-    il[q] = (dreg && q < a.d) ? T(1) / ell[a.dl == 1 ? 0 : q] : T(0);
+    for (int q = 0; q < D; ++q) xs[q] = x[jc * D + q] / ell[a.dl == 1 ? 0 : q];
+    for (int t = threadIdx.x; t < M * D; t += blockDim.x) zs[t] = z[t] / ell[a.dl == 1 ? 0 : (t % D)];
+    __syncthreads();
   }
 
   for (int half = 0; half < 2; ++half) {
     const int rb = half == 0 ? (int)blockIdx.y : nRB - 1 - (int)blockIdx.y;
     if (half == 1 && rb <= (int)blockIdx.y) break;  // odd count: middle block handled once
-    const long row0 = (long)rb * SGP_BM;
-    long kend = row0 + SGP_BM;
-    if (kend > a.M) kend = a.M;
+    const int row0 = rb * SGP_BM;
+    int kend = row0 + SGP_BM;
+    if (kend > M) kend = M;
     G g;
     g.zero();
-    auto fa = [&](int m, long k) -> T {
-      const long r = row0 + m;
-      return (r < a.M && k <= r) ? W[r * a.M + k] : T(0);
+    auto la = [&](int m, int k) -> T {
+      const int r = row0 + m;
+      return W[(r < M ? r : Mm1) * M + k];
     };
-    auto fb = [&](long k, int nn) -> T {
-      if (!jok) return T(0);
-      if (dreg) {
-        T r2 = T(0);
+    auto fa = [&](T raw, int m, int k) -> T {
+      const int r = row0 + m;
+      return ((r < M) & (k <= r)) ? raw : T(0);
+    };
+    auto lb = [&](int k, int nn) -> T { return T(0); };
+    auto fb = [&](T raw, int k, int nn) -> T {
+      T r2 = T(0);
+      if (D > 0) {
 #pragma unroll
-        for (int q = 0; q < SGP_DREG; ++q) {
-          if (q < a.d) {
-            const T t = (z[k * a.d + q] - xr[q]) * il[q];
-            r2 += t * t;
-          }
+        for (int q = 0; q < D; ++q) {
+          const T t = zs[k * D + q] - xs[q];
+          r2 += t * t;
         }
-        return hb_exp(T(-0.5) * r2);
+      } else {
+        for (int q = 0; q < d; ++q) {
+          const T t = (z[k * d + q] - x[jc * d + q]) / ell[a.dl == 1 ? 0 : q];
+          r2 += t * t;
+        }
       }
-      return rbf_pair<T>(z + k * a.d, x + jcol * a.d, ell, a.dl, a.d);
+      const T val = hb_exp_fast<T>(T(-0.5) * r2);
+      return jok ? val : T(0);
     };
-    g.template run<true, false>(0, kend, fa, fb, lds, lds + G::BK * G::LDA);
+    g.template run<true, false>(0, kend, la, fa, lb, fb, lds);
     g.for_each([&](int row, int col, T v) {
-      const long r = row0 + row, c = col0 + col;
-      if (r < a.M && c < a.n) A[r * a.n + c] = v;
+      const int r = row0 + row, c = col0 + col;
+      if (r < M && c < n) A[(long)r * n + c] = v;
     });
   }
 }
@@ -203,6 +213,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   HB_REQUIRE(dl == 1 || dl == d, "hb_sgp_fwd: lengthscales must have 1 or d entries");
   HB_REQUIRE(x && z && ell && W && u && A && f && v, "hb_sgp_fwd: NULL pointer");
   HB_REQUIRE(E <= 65535, "hb_sgp_fwd: too many experts");
+  HB_REQUIRE(M * n < 2147483647L && M * M < 2147483647L && n * d < 2147483647L, "hb_sgp_fwd: matrix too large for 32-bit indexing");
   if (E * n == 0) return 0;
   const T* eps = eps_in;
   if (mode == HB_SGP_DIAGONAL) {
@@ -222,7 +233,17 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.n = n; a.M = M; a.d = d; a.P = P;
     const int nRB = hb_cdiv(M, SGP_BM);
     dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
-    hipLaunchKernelGGL(sgp_A_kernel<T>, grid, dim3(256), 0, stream, a);
+    const bool fast = d <= SGP_DREG && M * d <= SGP_ZS_MAX;
+    if (fast && d == 1)
+      hipLaunchKernelGGL((sgp_A_kernel<T, 1>), grid, dim3(256), 0, stream, a);
+    else if (fast && d == 2)
+      hipLaunchKernelGGL((sgp_A_kernel<T, 2>), grid, dim3(256), 0, stream, a);
+    else if (fast && d == 3)
+      hipLaunchKernelGGL((sgp_A_kernel<T, 3>), grid, dim3(256), 0, stream, a);
+    else if (fast && d == 4)
+      hipLaunchKernelGGL((sgp_A_kernel<T, 4>), grid, dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL((sgp_A_kernel<T, 0>), grid, dim3(256), 0, stream, a);
     HB_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(sgp_finish_kernel<T>, dim3(hb_cdiv(n, 32), (unsigned)E), dim3(256), 0, stream, A, u, eps, f, v, n,
@@ -280,6 +301,11 @@ struct SgpBwdArgs {
   long n, M, P;
 };
 
+template <typename T>
+struct SgpRawB {
+  T a, u;
+};
+
 // Kbar = W^T Abar,  Abar_kj = sum_p u_pk fbar_pj + A_kj c_j  (built in the loader)
 template <typename T>
 __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
@@ -292,38 +318,50 @@ __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
   const T* fbar = a.fbar + e * a.P * a.n;
   const T* c = a.c + e * a.n;
   T* Kbar = a.Kbar + e * a.M * a.n;
-  const long col0 = (long)blockIdx.x * SGP_BN;
-  const int nRB = (int)((a.M + SGP_BM - 1) / SGP_BM);
-  const long jcol = col0 + (threadIdx.x % SGP_BN);
-  const bool jok = jcol < a.n;
-  const T cj = jok ? c[jcol] : T(0);
+  const int M = (int)a.M, n = (int)a.n;
+  const int col0 = blockIdx.x * SGP_BN;
+  const int nRB = (M + SGP_BM - 1) / SGP_BM;
+  const int jcol = col0 + (threadIdx.x % SGP_BN);
+  const bool jok = jcol < n;
+  const int jc = jok ? jcol : n - 1;
+  const int Mm1 = M - 1;
+  const T cj = c[jc];
   const bool preg = a.P == 1;
-  const T fb0 = (preg && jok) ? fbar[jcol] : T(0);
+  const T fb0 = a.P > 0 ? fbar[jc] : T(0);
 
   for (int half = 0; half < 2; ++half) {
     const int rb = half == 0 ? (int)blockIdx.y : nRB - 1 - (int)blockIdx.y;
     if (half == 1 && rb <= (int)blockIdx.y) break;
-    const long row0 = (long)rb * SGP_BM;
+    const int row0 = rb * SGP_BM;
     G g;
     g.zero();
-    auto fa = [&](int m, long k) -> T {
-      const long r = row0 + m;
-      return (r < a.M && k >= r) ? W[k * a.M + r] : T(0);
+    auto la = [&](int m, int k) -> T {
+      const int r = row0 + m;
+      return W[k * M + (r < M ? r : Mm1)];
     };
-    auto fb = [&](long k, int nn) -> T {
-      if (!jok) return T(0);
-      T val = A[k * a.n + jcol] * cj;
+    auto fa = [&](T raw, int m, int k) -> T {
+      const int r = row0 + m;
+      return ((r < M) & (k >= r)) ? raw : T(0);
+    };
+    auto lb = [&](int k, int nn) -> SgpRawB<T> {
+      SgpRawB<T> r;
+      r.a = A[k * n + jc];
+      r.u = u[k];
+      return r;
+    };
+    auto fb = [&](SgpRawB<T> raw, int k, int nn) -> T {
+      T val = raw.a * cj;
       if (preg) {
-        val += u[k] * fb0;
+        val += raw.u * fb0;
       } else {
-        for (long p = 0; p < a.P; ++p) val += u[p * a.M + k] * fbar[p * a.n + jcol];
+        for (long p = 0; p < a.P; ++p) val += u[p * M + k] * fbar[p * n + jc];
       }
-      return val;
+      return jok ? val : T(0);
     };
-    g.template run<false, false>(row0, a.M, fa, fb, lds, lds + G::BK * G::LDA);
+    g.template run<false, false>(row0, M, la, fa, lb, fb, lds);
     g.for_each([&](int row, int col, T v) {
-      const long r = row0 + row, cc = col0 + col;
-      if (r < a.M && cc < a.n) Kbar[r * a.n + cc] = v;
+      const int r = row0 + row, cc = col0 + col;
+      if (r < M && cc < n) Kbar[(long)r * n + cc] = v;
     });
   }
 }
@@ -484,6 +522,7 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
              "hb_sgp_bwd: NULL pointer");
   HB_REQUIRE(mode == HB_SGP_NEGLECTED || eps, "hb_sgp_bwd: eps required for the diagonal mode");
   HB_REQUIRE(E <= 65535, "hb_sgp_bwd: too many experts");
+  HB_REQUIRE(M * n < 2147483647L && M * M < 2147483647L && n * d < 2147483647L, "hb_sgp_bwd: matrix too large for 32-bit indexing");
   if (E * M == 0) return 0;
   T* c = ws;
   T* ellpart = ws + E * n;
