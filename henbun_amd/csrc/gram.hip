@@ -19,6 +19,7 @@ __device__ __forceinline__ T gram_value(int kind, const T* __restrict__ xi, cons
     r2 += (a - b) * (a - b);
     r2m += (a + b) * (a + b);
   }
+  if (kind == HB_KERN_SQDIST) return r2;
   T v = hb_exp(T(-0.5) * r2);
   if (kind == HB_KERN_CSYM_RBF) v += hb_exp(T(-0.5) * r2m);
   return v;
@@ -41,7 +42,7 @@ __global__ void __launch_bounds__(256) gram_fwd_kernel(int kind, const T* __rest
 template <typename T>
 static int gram_fwd(int kind, const T* X, long sX, const T* X2, long sX2, const T* ell, long dl, T* K, long B, long n,
                     long n2, long d, hipStream_t stream) {
-  HB_REQUIRE(kind == HB_KERN_RBF || kind == HB_KERN_CSYM_RBF, "hb_gram_fwd: unknown kernel kind %d", kind);
+  HB_REQUIRE(kind >= HB_KERN_RBF && kind <= HB_KERN_SQDIST, "hb_gram_fwd: unknown kernel kind %d", kind);
   HB_REQUIRE(B >= 0 && n >= 0 && n2 >= 0 && d >= 1, "hb_gram_fwd: bad extents");
   HB_REQUIRE(dl == 1 || dl == d, "hb_gram_fwd: lengthscales must have 1 or d=%ld entries, got %ld", d, dl);
   HB_REQUIRE(X && X2 && ell && K, "hb_gram_fwd: NULL pointer");
@@ -100,7 +101,8 @@ gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const
         r2m += (a + bb) * (a + bb);
       }
       const T kb = Kbar[(b * n + i) * n2 + j];
-      const T em = kb * hb_exp(T(-0.5) * r2);
+      // squared distance: d r2 = 2 (a-b) d(a-b), i.e. the RBF formulas with E- := -2
+      const T em = kind == HB_KERN_SQDIST ? T(-2) * kb : kb * hb_exp(T(-0.5) * r2);
       const T ep = kind == HB_KERN_CSYM_RBF ? kb * hb_exp(T(-0.5) * r2m) : T(0);
 #pragma unroll
       for (int k = 0; k < HB_GRAM_MAXD; ++k) {
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(256) gram_ell_finish_kernel(const T* __restric
 template <typename T>
 static int gram_bwd(int kind, const T* X, long sX, const T* X2, long sX2, const T* ell, long dl, const T* Kbar,
                     T* Xbar, T* X2bar, T* ellbar, long B, long n, long n2, long d, T* ws, hipStream_t stream) {
-  HB_REQUIRE(kind == HB_KERN_RBF || kind == HB_KERN_CSYM_RBF, "hb_gram_bwd: unknown kernel kind %d", kind);
+  HB_REQUIRE(kind >= HB_KERN_RBF && kind <= HB_KERN_SQDIST, "hb_gram_bwd: unknown kernel kind %d", kind);
   HB_REQUIRE(B >= 0 && n >= 0 && n2 >= 0 && d >= 1, "hb_gram_bwd: bad extents");
   HB_REQUIRE(dl == 1 || dl == d, "hb_gram_bwd: lengthscales must have 1 or d entries");
   HB_REQUIRE(X && X2 && ell && Kbar, "hb_gram_bwd: NULL pointer");

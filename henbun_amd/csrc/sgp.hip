@@ -283,8 +283,12 @@ __global__ void __launch_bounds__(256) sgp_prep_kernel(const T* __restrict__ eps
       const long e = t / n, j = t - e * n;
       T cs = T(0);
       for (long p = 0; p < P; ++p) cs += fbar[(e * P + p) * n + j];
+      // d sqrt|v| / dv = sign(v) / (2 sqrt|v|) is 0/0 at v == 0 (reachable in fp32 when
+      // x sits on an inducing point); the reference has no guard there (gp/gp.py:131) and
+      // would propagate NaN -- take the sub-gradient 0 instead.
       const T vv = v[t];
-      out = -eps[t] * hb_sign(vv) / hb_sqrt(hb_abs(vv)) * cs;
+      const T av = hb_abs(vv);
+      out = av > T(0) ? -eps[t] * hb_sign(vv) / hb_sqrt(av) * cs : T(0);
     }
     c[t] = out;
   }

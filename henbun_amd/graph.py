@@ -1,0 +1,1387 @@
+"""Lazy tensor graph, graph-level reverse-mode autodiff and the HIP executor.
+
+This module stands where the reference leans on TensorFlow's graph + autodiff
++ session (reference Henbun/model.py:206-230 `Optimizer.compile`:
+`likelihood_method(model)` traced in tf_mode, `optimizer.minimize(-objective)`;
+model.py:265-266 `session.run`).  User code written against `henbun_amd.tf`
+builds `Tensor` nodes; `gradients()` extends the graph with the backward pass
+(every VJP is expressed with the same primitive ops, fused HIP kernels included);
+`Plan` lowers the graph to a fixed list of C-ABI kernel launches on
+preallocated device buffers, which `Plan.capture()` turns into one hipGraph.
+
+Nothing here computes on the host: evaluation happens only through
+`henbun_amd.hip_ops` (ctypes -> libhenbun_hip.so).
+"""
+from __future__ import annotations
+
+import itertools
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_uid = itertools.count()
+
+# ------------------------------------------------------------------------------
+# graph objects
+# ------------------------------------------------------------------------------
+
+
+class Node:
+    __slots__ = ("op", "inputs", "attrs", "outputs", "id")
+
+    def __init__(self, op, inputs, attrs, out_shapes):
+        self.op = op
+        self.inputs = tuple(inputs)
+        self.attrs = attrs
+        self.id = next(_uid)
+        self.outputs = [Tensor(self, i, tuple(int(d) for d in s)) for i, s in enumerate(out_shapes)]
+
+
+class Tensor:
+    """A symbolic value: output `index` of `node`, static `shape`."""
+
+    __slots__ = ("node", "index", "shape")
+    __array_priority__ = 1000  # numpy defers to our reflected operators
+
+    def __init__(self, node, index, shape):
+        self.node, self.index, self.shape = node, index, shape
+
+    # -- tf.Tensor look-alikes
+    def get_shape(self):
+        return _Shape(self.shape)
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    def __repr__(self):
+        return "<hb.Tensor %s#%d:%d shape=%s>" % (self.node.op, self.node.id, self.index, self.shape)
+
+    def __hash__(self):
+        return id(self)
+
+    def __eq__(self, other):
+        return self is other
+
+    # -- operators
+    def __add__(self, o):
+        return add(self, o)
+
+    def __radd__(self, o):
+        return add(o, self)
+
+    def __sub__(self, o):
+        return sub(self, o)
+
+    def __rsub__(self, o):
+        return sub(o, self)
+
+    def __mul__(self, o):
+        return mul(self, o)
+
+    def __rmul__(self, o):
+        return mul(o, self)
+
+    def __truediv__(self, o):
+        return div(self, o)
+
+    def __rtruediv__(self, o):
+        return div(o, self)
+
+    def __neg__(self):
+        return unary("NEG", self)
+
+    def __pow__(self, p):
+        if isinstance(p, (int, float)):
+            return square(self) if p == 2 else unary("POWC", self, (float(p),))
+        return binary("POW", self, p)
+
+    def __getitem__(self, key):
+        return getitem(self, key)
+
+
+class _Shape(tuple):
+    """tuple with the tf.TensorShape bits user code touches (`.ndims`, `.as_list()`)."""
+
+    @property
+    def ndims(self):
+        return len(self)
+
+    def as_list(self):
+        return list(self)
+
+
+_intern: Dict[tuple, Node] = {}
+
+
+def _freeze(v):
+    if isinstance(v, dict):
+        return tuple(sorted((k, _freeze(x)) for k, x in v.items()))
+    if isinstance(v, (list, tuple)):
+        return tuple(_freeze(x) for x in v)
+    if isinstance(v, np.ndarray):
+        return ("nd", v.shape, v.tobytes())
+    return v
+
+
+def make(op, inputs, attrs, out_shapes, unique=False) -> Node:
+    """Create (or reuse: structural hash-consing) a node.  The reference builds
+    e.g. kern.Cholesky(z) twice per sample (gp/gp.py:116,159); interning makes
+    the duplicate free."""
+    attrs = dict(attrs or {})
+    if unique:
+        return Node(op, inputs, attrs, out_shapes)
+    key = (op, tuple(id(t) for t in inputs), _freeze(attrs))
+    n = _intern.get(key)
+    if n is None:
+        n = Node(op, inputs, attrs, out_shapes)
+        _intern[key] = n
+    return n
+
+
+def reset_interning():
+    _intern.clear()
+
+
+# ------------------------------------------------------------------------------
+# op registry
+# ------------------------------------------------------------------------------
+class OpDef:
+    def __init__(self, emit=None, vjp=None):
+        self.emit = emit  # (plan, node) -> None (appends launch closures to plan.steps)
+        self.vjp = vjp    # (node, out_grads[list[Tensor|None]]) -> list[Tensor|None] per input
+
+
+OPS: Dict[str, OpDef] = {}
+
+
+def defop(name, emit=None, vjp=None):
+    OPS[name] = OpDef(emit, vjp)
+
+
+# ------------------------------------------------------------------------------
+# leaves
+# ------------------------------------------------------------------------------
+def leaf(kind, shape, **attrs) -> Tensor:
+    """kind in {'param','data','minibatch','const','noise'}; always unique."""
+    return Node("leaf:" + kind, (), attrs, [shape]).outputs[0]
+
+
+def constant(value) -> Tensor:
+    arr = np.asarray(value, dtype=np.float64)
+    return make("leaf:const", (), {"value": arr}, [arr.shape]).outputs[0]
+
+
+def as_tensor(x) -> Tensor:
+    if isinstance(x, Tensor):
+        return x
+    if hasattr(x, "tensor") and callable(x.tensor):  # Variable / Variational used outside tf_mode
+        return x.tensor()
+    return constant(x)
+
+
+def is_scalar_const(x):
+    return isinstance(x, (int, float, np.floating, np.integer)) or (
+        isinstance(x, np.ndarray) and x.ndim == 0
+    )
+
+
+# ------------------------------------------------------------------------------
+# elementwise
+# ------------------------------------------------------------------------------
+def bshape(*shapes):
+    return tuple(np.broadcast_shapes(*shapes))
+
+
+def unary(opname, x, params=()) -> Tensor:
+    x = as_tensor(x)
+    return make("ew", (x,), {"f": opname, "p": tuple(float(p) for p in params)}, [x.shape]).outputs[0]
+
+
+def binary(opname, a, b, params=()) -> Tensor:
+    a, b = as_tensor(a), as_tensor(b)
+    return make("ew", (a, b), {"f": opname, "p": tuple(float(p) for p in params)}, [bshape(a.shape, b.shape)]).outputs[0]
+
+
+def affine(x, scale=1.0, shift=0.0) -> Tensor:
+    if scale == 1.0 and shift == 0.0:
+        return as_tensor(x)
+    return unary("AFFINE", x, (scale, shift))
+
+
+def add(a, b):
+    if is_scalar_const(b):
+        return affine(a, 1.0, float(b))
+    if is_scalar_const(a):
+        return affine(b, 1.0, float(a))
+    return binary("ADD", a, b)
+
+
+def sub(a, b):
+    if is_scalar_const(b):
+        return affine(a, 1.0, -float(b))
+    if is_scalar_const(a):
+        return affine(b, -1.0, float(a))
+    return binary("SUB", a, b)
+
+
+def mul(a, b):
+    if is_scalar_const(b):
+        return affine(a, float(b), 0.0)
+    if is_scalar_const(a):
+        return affine(b, float(a), 0.0)
+    return binary("MUL", a, b)
+
+
+def div(a, b):
+    if is_scalar_const(b):
+        return affine(a, 1.0 / float(b), 0.0)
+    if is_scalar_const(a):
+        return affine(unary("RECIP", b), float(a), 0.0)
+    return binary("DIV", a, b)
+
+
+def square(x):
+    return unary("SQUARE", x)
+
+
+def gauss_logpdf(x, mu, var) -> Tensor:
+    """Fused densities.gaussian (reference densities.py:25-27)."""
+    x, mu, var = as_tensor(x), as_tensor(mu), as_tensor(var)
+    return make("ew", (x, mu, var), {"f": "GAUSS_LOGPDF", "p": ()}, [bshape(x.shape, mu.shape, var.shape)]).outputs[0]
+
+
+def where(c, a, b) -> Tensor:
+    c, a, b = as_tensor(c), as_tensor(a), as_tensor(b)
+    return make("ew", (c, a, b), {"f": "WHERE", "p": ()}, [bshape(c.shape, a.shape, b.shape)]).outputs[0]
+
+
+def stop_gradient(x) -> Tensor:
+    x = as_tensor(x)
+    return make("stop_gradient", (x,), {}, [x.shape]).outputs[0]
+
+
+def sum_to_shape(g: Tensor, shape) -> Tensor:
+    """Reduce a broadcast gradient back to `shape`."""
+    shape = tuple(shape)
+    if g.shape == shape:
+        return g
+    nd = len(g.shape)
+    lead = nd - len(shape)
+    axes = list(range(lead))
+    for i, s in enumerate(shape):
+        if s == 1 and g.shape[lead + i] != 1:
+            axes.append(lead + i)
+    r = reduce_sum(g, axes, keepdims=True) if axes else g
+    return reshape(r, shape)
+
+
+def _ew_vjp(node, gs):
+    g = gs[0]
+    if g is None:
+        return [None] * len(node.inputs)
+    f, p = node.attrs["f"], node.attrs["p"]
+    ins = node.inputs
+    y = node.outputs[0]
+    x = ins[0]
+    one = lambda t, s: sum_to_shape(t, s.shape)
+    if f == "NEG":
+        return [unary("NEG", g)]
+    if f == "EXP":
+        return [mul(g, y)]
+    if f == "LOG":
+        return [div(g, x)]
+    if f == "SQRT":
+        return [div(affine(g, 0.5), y)]
+    if f == "SQUARE":
+        return [mul(affine(g, 2.0), x)]
+    if f == "ABS":
+        return [mul(g, unary("SIGN", x))]
+    if f in ("SIGN", "STEP", "CLIPMASK", "GT", "GE", "LT", "LE", "EQ"):
+        return [None] * len(ins)
+    if f == "SIGMOID":
+        return [binary("SIGMOID_GRAD", y, g)]
+    if f == "TANH":
+        return [binary("TANH_GRAD", y, g)]
+    if f == "RELU":
+        return [binary("RELU_GRAD", x, g)]
+    if f == "SOFTPLUS":
+        return [binary("SOFTPLUS_GRAD", x, g)]
+    if f == "RECIP":
+        return [unary("NEG", mul(g, square(y)))]
+    if f == "RSQRT":
+        return [affine(mul(g, mul(y, square(y))), -0.5)]
+    if f == "AFFINE":
+        return [affine(g, p[0])]
+    if f == "CLIP":
+        return [binary("CLIP_GRAD", x, g, p)]
+    if f == "LGAMMA":
+        return [mul(g, unary("DIGAMMA", x))]
+    if f == "POWC":
+        return [mul(affine(g, p[0]), unary("POWC", x, (p[0] - 1.0,)))]
+    if f == "LOG1P":
+        return [div(g, affine(x, 1.0, 1.0))]
+    if f == "COPY":
+        return [g]
+    a, b = ins[0], ins[1] if len(ins) > 1 else None
+    if f == "ADD":
+        return [one(g, a), one(g, b)]
+    if f == "SUB":
+        return [one(g, a), one(unary("NEG", g), b)]
+    if f == "MUL":
+        return [one(mul(g, b), a), one(mul(g, a), b)]
+    if f == "DIV":
+        return [one(div(g, b), a), one(unary("NEG", div(mul(g, y), b)), b)]
+    if f == "MAX":
+        m = binary("GE", a, b)
+        return [one(mul(g, m), a), one(mul(g, affine(m, -1.0, 1.0)), b)]
+    if f == "MIN":
+        m = binary("LE", a, b)
+        return [one(mul(g, m), a), one(mul(g, affine(m, -1.0, 1.0)), b)]
+    if f == "POW":
+        ga = mul(g, mul(b, binary("POW", a, affine(b, 1.0, -1.0))))
+        gb = mul(g, mul(y, unary("LOG", a)))
+        return [one(ga, a), one(gb, b)]
+    if f == "WHERE":
+        c, aa, bb = ins
+        z = affine(g, 0.0)
+        return [None, one(where(c, g, z), aa), one(where(c, z, g), bb)]
+    if f == "GAUSS_LOGPDF":
+        xx, mu, var = ins
+        n = make("ew", (xx, mu, var, g), {"f": "GAUSS_LOGPDF_GRAD", "p": ()}, [y.shape] * 3)
+        return [one(n.outputs[0], xx), one(n.outputs[1], mu), one(n.outputs[2], var)]
+    if f in ("SIGMOID_GRAD", "TANH_GRAD", "RELU_GRAD", "SOFTPLUS_GRAD", "CLIP_GRAD", "GAUSS_LOGPDF_GRAD", "DIGAMMA"):
+        raise NotImplementedError("second-order gradients are not supported (%s)" % f)
+    raise NotImplementedError("no VJP for elementwise op " + f)
+
+
+def _ew_emit(plan, node):
+    H = plan.H
+    ins = [plan.buf(t) for t in node.inputs]
+    outs = [plan.out(t) for t in node.outputs]
+    f, p = node.attrs["f"], list(node.attrs["p"])
+    nout = len(outs)
+    plan.steps.append(lambda: H.ewise(f, ins, nout=nout, params=p, out=outs))
+
+
+defop("ew", _ew_emit, _ew_vjp)
+defop("stop_gradient", lambda plan, node: plan.alias(node.outputs[0], plan.buf(node.inputs[0])),
+      lambda node, gs: [None])
+
+
+# ------------------------------------------------------------------------------
+# reductions
+# ------------------------------------------------------------------------------
+def _norm_axes(axes, nd):
+    if axes is None:
+        return tuple(range(nd))
+    if isinstance(axes, (int, np.integer)):
+        axes = [axes]
+    return tuple(sorted(set(int(a) % nd if nd else 0 for a in axes)))
+
+
+def _reduce(kind, x, axes=None, keepdims=False) -> Tensor:
+    x = as_tensor(x)
+    nd = len(x.shape)
+    axes = _norm_axes(axes, nd)
+    if not axes:
+        return x
+    # chain contiguous runs of reduced axes (each run is one [K1,R,K2] launch)
+    runs, cur = [], [axes[0]]
+    for a in axes[1:]:
+        if a == cur[-1] + 1:
+            cur.append(a)
+        else:
+            runs.append(cur)
+            cur = [a]
+    runs.append(cur)
+    t = x
+    for run in reversed(runs):  # reduce trailing runs first so earlier axis numbers stay valid
+        shp = list(t.shape)
+        K1 = int(np.prod(shp[: run[0]])) if run[0] > 0 else 1
+        R = int(np.prod(shp[run[0] : run[-1] + 1]))
+        K2 = int(np.prod(shp[run[-1] + 1 :])) if run[-1] + 1 < len(shp) else 1
+        out_shape = shp[: run[0]] + [1] * len(run) + shp[run[-1] + 1 :]
+        t = make("reduce", (t,), {"kind": kind, "K1": K1, "R": R, "K2": K2}, [tuple(out_shape)]).outputs[0]
+    if not keepdims:
+        t = reshape(t, [s for i, s in enumerate(x.shape) if i not in axes])
+    return t
+
+
+def reduce_sum(x, axis=None, keepdims=False, keep_dims=None) -> Tensor:
+    if keep_dims is not None:
+        keepdims = keep_dims
+    return _reduce("sum", x, axis, keepdims)
+
+
+def reduce_max(x, axis=None, keepdims=False, keep_dims=None) -> Tensor:
+    if keep_dims is not None:
+        keepdims = keep_dims
+    return _reduce("max", x, axis, keepdims)
+
+
+def reduce_mean(x, axis=None, keepdims=False, keep_dims=None) -> Tensor:
+    x = as_tensor(x)
+    if keep_dims is not None:
+        keepdims = keep_dims
+    axes = _norm_axes(axis, len(x.shape))
+    cnt = int(np.prod([x.shape[a] for a in axes])) if axes else 1
+    return affine(_reduce("sum", x, axis, keepdims), 1.0 / max(cnt, 1))
+
+
+def _reduce_emit(plan, node):
+    H = plan.H
+    x, out = plan.buf(node.inputs[0]), plan.out(node.outputs[0])
+    a = node.attrs
+    op = H.RED_SUM if a["kind"] == "sum" else H.RED_MAX
+    plan.steps.append(lambda: H.reduce_mid(x, a["K1"], a["R"], a["K2"], op=op, out=out))
+
+
+def _reduce_vjp(node, gs):
+    g = gs[0]
+    if g is None:
+        return [None]
+    x = node.inputs[0]
+    if node.attrs["kind"] == "sum":
+        return [broadcast_to(g, x.shape)]
+    mask = binary("EQ", x, node.outputs[0])
+    return [mul(mask, g)]
+
+
+defop("reduce", _reduce_emit, _reduce_vjp)
+
+
+# ------------------------------------------------------------------------------
+# shape ops
+# ------------------------------------------------------------------------------
+def reshape(x, shape) -> Tensor:
+    x = as_tensor(x)
+    shape = [int(s) for s in shape]
+    if -1 in shape:
+        known = int(np.prod([s for s in shape if s != -1])) if len(shape) > 1 else 1
+        shape[shape.index(-1)] = x.size // max(known, 1)
+    shape = tuple(shape)
+    if int(np.prod(shape)) != x.size:
+        raise ValueError("cannot reshape %s to %s" % (x.shape, shape))
+    if shape == x.shape:
+        return x
+    return make("reshape", (x,), {"shape": shape}, [shape]).outputs[0]
+
+
+defop("reshape", lambda plan, node: plan.alias(node.outputs[0], plan.buf(node.inputs[0]).view(node.outputs[0].shape)),
+      lambda node, gs: [None if gs[0] is None else reshape(gs[0], node.inputs[0].shape)])
+
+
+def expand_dims(x, axis) -> Tensor:
+    x = as_tensor(x)
+    shp = list(x.shape)
+    axis = axis if axis >= 0 else axis + len(shp) + 1
+    shp.insert(axis, 1)
+    return reshape(x, shp)
+
+
+def squeeze(x, axis=None) -> Tensor:
+    x = as_tensor(x)
+    shp = list(x.shape)
+    if axis is None:
+        shp = [s for s in shp if s != 1]
+    else:
+        axs = _norm_axes(axis, len(shp))
+        shp = [s for i, s in enumerate(shp) if i not in axs]
+    return reshape(x, shp)
+
+
+def _contig_strides(shape):
+    st, acc = [0] * len(shape), 1
+    for d in range(len(shape) - 1, -1, -1):
+        st[d] = acc
+        acc *= shape[d]
+    return st
+
+
+def strided_view(x, out_shape, strides, offset=0) -> Tensor:
+    """out[idx] = x.flat[offset + sum idx*strides] (materialised copy; covers
+    transpose / slice / broadcast / tile).  Linear in x."""
+    x = as_tensor(x)
+    return make("strided", (x,), {"shape": tuple(out_shape), "strides": tuple(int(s) for s in strides),
+                                  "offset": int(offset)}, [tuple(out_shape)]).outputs[0]
+
+
+def _strided_emit(plan, node):
+    H = plan.H
+    x, out = plan.buf(node.inputs[0]), plan.out(node.outputs[0])
+    a = node.attrs
+    shp = list(a["shape"])
+    ostr = _contig_strides(shp)
+    plan.steps.append(lambda: H.copy_nd(x, list(a["strides"]), out, ostr, shp, src_off=a["offset"]))
+
+
+def _strided_vjp(node, gs):
+    g = gs[0]
+    if g is None:
+        return [None]
+    x = node.inputs[0]
+    a = node.attrs
+    if 0 in [s for s, d in zip(a["strides"], a["shape"]) if d > 1]:
+        # broadcast dims: sum them first, then scatter the rest
+        keep = [i for i, (s, d) in enumerate(zip(a["strides"], a["shape"])) if not (s == 0 and d > 1)]
+        red = [i for i in range(len(a["shape"])) if i not in keep]
+        g = reduce_sum(g, red, keepdims=False)
+        shape = [a["shape"][i] for i in keep]
+        strides = [a["strides"][i] for i in keep]
+    else:
+        shape, strides = list(a["shape"]), list(a["strides"])
+    return [make("scatter_strided", (g,), {"xshape": x.shape, "shape": tuple(shape), "strides": tuple(strides),
+                                          "offset": a["offset"]}, [x.shape]).outputs[0]]
+
+
+defop("strided", _strided_emit, _strided_vjp)
+
+
+def _scatter_emit(plan, node):
+    H = plan.H
+    g, out = plan.buf(node.inputs[0]), plan.out(node.outputs[0])
+    a = node.attrs
+    shp = list(a["shape"])
+    istr = _contig_strides(shp)
+    covers = int(np.prod(shp)) == int(np.prod(a["xshape"]))
+
+    def step():
+        if not covers:
+            H.fill(out, 0.0)
+        H.copy_nd(g, istr, out, list(a["strides"]), shp, dst_off=a["offset"])
+
+    plan.steps.append(step)
+
+
+defop("scatter_strided", _scatter_emit,
+      lambda node, gs: [None if gs[0] is None else strided_view(gs[0], node.attrs["shape"], node.attrs["strides"],
+                                                                 node.attrs["offset"])])
+
+
+def transpose(x, perm=None) -> Tensor:
+    x = as_tensor(x)
+    nd = len(x.shape)
+    perm = list(range(nd - 1, -1, -1)) if perm is None else [int(p) % nd for p in perm]
+    if perm == list(range(nd)):
+        return x
+    st = _contig_strides(x.shape)
+    return strided_view(x, [x.shape[p] for p in perm], [st[p] for p in perm])
+
+
+def matrix_transpose(x) -> Tensor:
+    nd = len(as_tensor(x).shape)
+    return transpose(x, list(range(nd - 2)) + [nd - 1, nd - 2])
+
+
+def broadcast_to(x, shape) -> Tensor:
+    x = as_tensor(x)
+    shape = tuple(int(s) for s in shape)
+    if x.shape == shape:
+        return x
+    nd = len(shape)
+    xs = (1,) * (nd - len(x.shape)) + tuple(x.shape)
+    st = _contig_strides(xs)
+    strides = [0 if (xs[i] == 1 and shape[i] != 1) else st[i] for i in range(nd)]
+    for i in range(nd):
+        if xs[i] != shape[i] and xs[i] != 1:
+            raise ValueError("cannot broadcast %s to %s" % (x.shape, shape))
+    return strided_view(x, shape, strides)
+
+
+def tile(x, multiples) -> Tensor:
+    x = as_tensor(x)
+    mult = [int(m) for m in multiples]
+    assert len(mult) == len(x.shape)
+    # view x as [1,s0,1,s1,...] broadcast to [m0,s0,m1,s1,...] then merge
+    st = _contig_strides(x.shape)
+    shape, strides = [], []
+    for m, s, t in zip(mult, x.shape, st):
+        shape += [m, s]
+        strides += [0, t]
+    v = strided_view(x, shape, strides)
+    return reshape(v, [m * s for m, s in zip(mult, x.shape)])
+
+
+def slice_(x, begin, size) -> Tensor:
+    x = as_tensor(x)
+    begin = [int(b) for b in begin]
+    size = [int(x.shape[i] - begin[i]) if int(s) == -1 else int(s) for i, s in enumerate(size)]
+    st = _contig_strides(x.shape)
+    for b, s, d in zip(begin, size, x.shape):
+        if b < 0 or b + s > d:
+            raise ValueError("slice out of range")
+    if list(size) == list(x.shape):
+        return x
+    return strided_view(x, size, st, offset=sum(b * t for b, t in zip(begin, st)))
+
+
+def getitem(x, key) -> Tensor:
+    x = as_tensor(x)
+    if not isinstance(key, tuple):
+        key = (key,)
+    if any(k is Ellipsis for k in key):
+        i = key.index(Ellipsis)
+        nfill = len(x.shape) - sum(1 for k in key if k is not None and k is not Ellipsis)
+        key = key[:i] + (slice(None),) * nfill + key[i + 1 :]
+    begin, size, final = [], [], []
+    dim = 0
+    for k in key:
+        if k is None:
+            final.append(1)
+            continue
+        d = x.shape[dim]
+        if isinstance(k, (int, np.integer)):
+            kk = int(k) % d
+            begin.append(kk)
+            size.append(1)
+        elif isinstance(k, slice):
+            s, e, stp = k.indices(d)
+            if stp != 1:
+                raise NotImplementedError("strided slicing")
+            begin.append(s)
+            size.append(max(e - s, 0))
+            final.append(max(e - s, 0))
+        else:
+            raise TypeError("unsupported index %r" % (k,))
+        dim += 1
+    while dim < len(x.shape):
+        begin.append(0)
+        size.append(x.shape[dim])
+        final.append(x.shape[dim])
+        dim += 1
+    return reshape(slice_(x, begin, size), final)
+
+
+def concat(values, axis) -> Tensor:
+    vals = [as_tensor(v) for v in values]
+    nd = len(vals[0].shape)
+    axis = axis % nd
+    oshape = list(vals[0].shape)
+    oshape[axis] = sum(v.shape[axis] for v in vals)
+    return make("concat", tuple(vals), {"axis": axis}, [tuple(oshape)]).outputs[0]
+
+
+def _concat_emit(plan, node):
+    H = plan.H
+    out = plan.out(node.outputs[0])
+    axis = node.attrs["axis"]
+    ostr = _contig_strides(node.outputs[0].shape)
+    off = 0
+    for t in node.inputs:
+        src = plan.buf(t)
+        shp = list(t.shape)
+        istr = _contig_strides(shp)
+        o = off * ostr[axis]
+        plan.steps.append(lambda src=src, istr=istr, shp=shp, o=o: H.copy_nd(src, istr, out, ostr, shp, dst_off=o))
+        off += t.shape[axis]
+
+
+def _concat_vjp(node, gs):
+    g = gs[0]
+    if g is None:
+        return [None] * len(node.inputs)
+    axis = node.attrs["axis"]
+    res, off = [], 0
+    for t in node.inputs:
+        begin = [0] * len(t.shape)
+        begin[axis] = off
+        res.append(slice_(g, begin, t.shape))
+        off += t.shape[axis]
+    return res
+
+
+defop("concat", _concat_emit, _concat_vjp)
+
+
+def stack(values, axis=0) -> Tensor:
+    vals = [as_tensor(v) for v in values]
+    nd = len(vals[0].shape) + 1
+    axis = axis % nd
+    return concat([expand_dims(v, axis) for v in vals], axis)
+
+
+# ------------------------------------------------------------------------------
+# linear algebra
+# ------------------------------------------------------------------------------
+def matmul(a, b, transpose_a=False, transpose_b=False, bias=None, act="none") -> Tensor:
+    """tf.matmul with batch dims (equal, or absent on one side); optional fused
+    bias (+activation) epilogue = the reference MatBias layer (nn.py:31-32)."""
+    a, b = as_tensor(a), as_tensor(b)
+    if len(a.shape) < 2 or len(b.shape) < 2:
+        raise ValueError("matmul needs rank >= 2 operands")
+    m, k = (a.shape[-1], a.shape[-2]) if transpose_a else (a.shape[-2], a.shape[-1])
+    k2, n = (b.shape[-1], b.shape[-2]) if transpose_b else (b.shape[-2], b.shape[-1])
+    if k != k2:
+        raise ValueError("matmul inner dimensions differ: %s x %s" % (a.shape, b.shape))
+    la, lb = a.shape[:-2], b.shape[:-2]
+    if la and lb and la != lb:
+        raise ValueError("matmul batch dimensions differ: %s vs %s" % (la, lb))
+    lead = la if la else lb
+    ins = (a, b) if bias is None else (a, b, as_tensor(bias))
+    return make("matmul", ins, {"ta": bool(transpose_a), "tb": bool(transpose_b), "act": act},
+                [tuple(lead) + (m, n)]).outputs[0]
+
+
+def _matmul_emit(plan, node):
+    H = plan.H
+    a, b = plan.buf(node.inputs[0]), plan.buf(node.inputs[1])
+    bias = plan.buf(node.inputs[2]) if len(node.inputs) > 2 else None
+    out = plan.out(node.outputs[0])
+    at = node.attrs
+    plan.steps.append(lambda: H.matmul(a, b, transA=at["ta"], transB=at["tb"], bias=bias, act=at["act"], out=out))
+
+
+def _sum_lead(g, t):
+    """sum a batched gradient over leading dims the operand `t` does not have."""
+    extra = len(g.shape) - len(t.shape)
+    return reduce_sum(g, list(range(extra))) if extra > 0 else g
+
+
+def _matmul_vjp(node, gs):
+    g = gs[0]
+    if g is None:
+        return [None] * len(node.inputs)
+    a, b = node.inputs[0], node.inputs[1]
+    ta, tb, act = node.attrs["ta"], node.attrs["tb"], node.attrs["act"]
+    y = node.outputs[0]
+    if act == "sigmoid":
+        g = binary("SIGMOID_GRAD", y, g)
+    elif act == "tanh":
+        g = binary("TANH_GRAD", y, g)
+    elif act == "relu":
+        g = binary("RELU_GRAD", y, g)  # y > 0  <=>  pre-activation > 0
+    if not ta:
+        ga = matmul(g, b, transpose_b=not tb)
+    else:
+        ga = matmul(b, g, transpose_a=tb, transpose_b=True)
+    if not tb:
+        gb = matmul(a, g, transpose_a=not ta)
+    else:
+        gb = matmul(g, a, transpose_a=True, transpose_b=ta)
+    res = [_sum_lead(ga, a), _sum_lead(gb, b)]
+    if len(node.inputs) > 2:
+        res.append(sum_to_shape(g, node.inputs[2].shape))
+    return res
+
+
+defop("matmul", _matmul_emit, _matmul_vjp)
+
+
+def matutil(x, mode, lower=-1, upper=-1, alpha=0.0) -> Tensor:
+    x = as_tensor(x)
+    return make("matutil", (x,), {"mode": mode, "lower": int(lower), "upper": int(upper), "alpha": float(alpha)},
+                [x.shape]).outputs[0]
+
+
+def band_part(x, num_lower, num_upper):
+    return matutil(x, 0, num_lower, num_upper)
+
+
+def add_eye(x, alpha):
+    return matutil(x, 1, alpha=alpha)
+
+
+def _matutil_emit(plan, node):
+    H = plan.H
+    x, out = plan.buf(node.inputs[0]), plan.out(node.outputs[0])
+    a = node.attrs
+    plan.steps.append(lambda: H.matutil(x, a["mode"], a["lower"], a["upper"], a["alpha"], out=out))
+
+
+def _matutil_vjp(node, gs):
+    g = gs[0]
+    if g is None:
+        return [None]
+    a = node.attrs
+    if a["mode"] == 0:
+        return [matutil(g, 0, a["lower"], a["upper"])]
+    if a["mode"] == 1:
+        return [g]
+    if a["mode"] == 2:
+        return [matutil(g, 2)]
+    return [matutil(g, 3)]
+
+
+defop("matutil", _matutil_emit, _matutil_vjp)
+
+
+def diag_part(x) -> Tensor:
+    x = as_tensor(x)
+    n = x.shape[-1]
+    st = _contig_strides(x.shape)
+    return strided_view(x, x.shape[:-2] + (n,), st[:-2] + [n + 1])
+
+
+def cholesky(a) -> Tensor:
+    """Lower Cholesky factor, batched (tf.cholesky; reference gp/kernels.py:101)."""
+    a = as_tensor(a)
+    if a.shape[-1] != a.shape[-2]:
+        raise ValueError("cholesky needs square matrices")
+    return make("cholesky", (a,), {}, [a.shape]).outputs[0]
+
+
+def _cholesky_emit(plan, node):
+    H = plan.H
+    a, out = plan.buf(node.inputs[0]), plan.out(node.outputs[0])
+    B = int(np.prod(node.outputs[0].shape[:-2])) if len(node.outputs[0].shape) > 2 else 1
+    info = plan.new_info(B, "cholesky#%d" % node.id)
+    plan.steps.append(lambda: H.cholesky(a, out=out, info=info))
+
+
+def _cholesky_vjp(node, gs):
+    """Murray (2016) / TF _CholeskyGrad:  P = Phi(L^T Lbar);  S = L^-T P L^-1;  Abar = (S+S^T)/2."""
+    g = gs[0]
+    if g is None:
+        return [None]
+    L = node.outputs[0]
+    W = trinv(L)
+    P = matutil(matmul(L, band_part(g, -1, 0), transpose_a=True), 2)
+    S = matmul(matmul(W, P, transpose_a=True), W)
+    return [matutil(S, 3)]
+
+
+defop("cholesky", _cholesky_emit, _cholesky_vjp)
+
+
+def trinv(L) -> Tensor:
+    """Inverse of a lower-triangular matrix (batched)."""
+    L = as_tensor(L)
+    return make("trinv", (L,), {}, [L.shape]).outputs[0]
+
+
+def _trinv_vjp(node, gs):
+    g = gs[0]
+    if g is None:
+        return [None]
+    W = node.outputs[0]
+    # d(L^-1) = -W dL W  ->  Lbar = -tril(W^T Wbar W^T)
+    t = matmul(matmul(W, band_part(g, -1, 0), transpose_a=True), W, transpose_b=True)
+    return [band_part(unary("NEG", t), -1, 0)]
+
+
+defop("trinv", lambda plan, node: plan.steps.append(
+    (lambda H, l, o: (lambda: H.trinv(l, out=o)))(plan.H, plan.buf(node.inputs[0]), plan.out(node.outputs[0]))),
+      _trinv_vjp)
+
+
+def triangular_solve(L, b, lower=True, adjoint=False) -> Tensor:
+    """tf.matrix_triangular_solve(L, b): formed as L^{-1} b with the explicit
+    triangular inverse (the reference's batched SparseGP branch does the same,
+    gp/gp.py:169-172)."""
+    if not lower:
+        raise NotImplementedError("upper-triangular solve")
+    return matmul(trinv(L), b, transpose_a=adjoint)
+
+
+# ------------------------------------------------------------------------------
+# fused probabilistic ops
+# ------------------------------------------------------------------------------
+def random_normal(shape, stream="local") -> Tensor:
+    """tf.random_normal: fresh N(0,1) draw per run.  stream 'global' draws are
+    identical on every data-parallel rank, 'local' ones are rank-distinct."""
+    return Node("leaf:noise", (), {"stream": stream}, [tuple(int(s) for s in shape)]).outputs[0]
+
+
+def diag_sample_kl(mu, s, u=None, stream="global") -> Tuple[Tensor, Tensor, Tensor]:
+    """(x, kl, u):  x = mu + exp(s) u ;  kl = -0.5 sum(2 s + u^2 - x^2)
+    (reference variationals.py:138-142, :225-230).  `u` = injected noise tensor
+    or None (drawn in-kernel)."""
+    mu, s = as_tensor(mu), as_tensor(s)
+    assert mu.shape == s.shape
+    ins = (mu, s) if u is None else (mu, s, as_tensor(u))
+    n = make("diag_sample_kl", ins, {"stream": stream}, [mu.shape, (1,), mu.shape], unique=u is None)
+    return n.outputs[0], n.outputs[1], n.outputs[2]
+
+
+def _diag_skl_emit(plan, node):
+    H = plan.H
+    mu, s = plan.buf(node.inputs[0]), plan.buf(node.inputs[1])
+    u_in = plan.buf(node.inputs[2]) if len(node.inputs) > 2 else None
+    outs = tuple(plan.out(t) for t in node.outputs)
+    x, kl, u = outs
+    rng = None if u_in is not None else plan.rng(node.attrs["stream"])
+    plan.steps.append(lambda: H.diag_sample_kl_fwd(mu, s, u_in=u_in, rng=rng, out=(x, kl, u)))
+
+
+def _diag_skl_vjp(node, gs):
+    gx, gkl = gs[0], gs[1]
+    if gx is None and gkl is None:
+        return [None] * len(node.inputs)
+    x, kl, u = node.outputs
+    s = node.inputs[1]
+    ins = [s, u, x]
+    flags = {"has_x": gx is not None, "has_kl": gkl is not None}
+    if gx is not None:
+        ins.append(gx)
+    if gkl is not None:
+        ins.append(gkl)
+    n = make("diag_sample_kl_grad", tuple(ins), flags, [s.shape, s.shape])
+    return [n.outputs[0], n.outputs[1]] + [None] * (len(node.inputs) - 2)
+
+
+def _diag_skl_grad_emit(plan, node):
+    H = plan.H
+    bufs = [plan.buf(t) for t in node.inputs]
+    s, u, x = bufs[:3]
+    k = 3
+    xbar = klbar = None
+    if node.attrs["has_x"]:
+        xbar = bufs[k]
+        k += 1
+    if node.attrs["has_kl"]:
+        klbar = bufs[k]
+    outs = tuple(plan.out(t) for t in node.outputs)
+    plan.steps.append(lambda: H.diag_sample_kl_bwd(s, u, x, xbar, klbar, out=outs))
+
+
+defop("diag_sample_kl", _diag_skl_emit, _diag_skl_vjp)
+defop("diag_sample_kl_grad", _diag_skl_grad_emit, None)
+
+
+def fullrank_sample_kl(mu, S, u=None, stream="global") -> Tuple[Tensor, Tensor, Tensor]:
+    """(x, kl, u):  x = mu + tril(S) u ; kl = -0.5 sum(log S_kk^2 + u^2 - x^2)
+    (reference variationals.py:144-146, :186, :225-230)."""
+    mu, S = as_tensor(mu), as_tensor(S)
+    assert S.shape == mu.shape + (mu.shape[-1],)
+    ins = (mu, S) if u is None else (mu, S, as_tensor(u))
+    n = make("fullrank_sample_kl", ins, {"stream": stream}, [mu.shape, (1,), mu.shape], unique=u is None)
+    return n.outputs[0], n.outputs[1], n.outputs[2]
+
+
+def _fr_skl_emit(plan, node):
+    H = plan.H
+    mu, S = plan.buf(node.inputs[0]), plan.buf(node.inputs[1])
+    u_in = plan.buf(node.inputs[2]) if len(node.inputs) > 2 else None
+    outs = tuple(plan.out(t) for t in node.outputs)
+    rng = None if u_in is not None else plan.rng(node.attrs["stream"])
+    plan.steps.append(lambda: H.fullrank_sample_kl_fwd(mu, S, u_in=u_in, rng=rng, out=outs))
+
+
+def _fr_skl_vjp(node, gs):
+    gx, gkl = gs[0], gs[1]
+    if gx is None and gkl is None:
+        return [None] * len(node.inputs)
+    x, kl, u = node.outputs
+    S = node.inputs[1]
+    ins = [S, u, x]
+    flags = {"has_x": gx is not None, "has_kl": gkl is not None}
+    if gx is not None:
+        ins.append(gx)
+    if gkl is not None:
+        ins.append(gkl)
+    n = make("fullrank_sample_kl_grad", tuple(ins), flags, [x.shape, S.shape])
+    return [n.outputs[0], n.outputs[1]] + [None] * (len(node.inputs) - 2)
+
+
+def _fr_skl_grad_emit(plan, node):
+    H = plan.H
+    bufs = [plan.buf(t) for t in node.inputs]
+    S, u, x = bufs[:3]
+    k = 3
+    xbar = klbar = None
+    if node.attrs["has_x"]:
+        xbar = bufs[k]
+        k += 1
+    if node.attrs["has_kl"]:
+        klbar = bufs[k]
+    outs = tuple(plan.out(t) for t in node.outputs)
+    plan.steps.append(lambda: H.fullrank_sample_kl_bwd(S, u, x, xbar, klbar, out=outs))
+
+
+defop("fullrank_sample_kl", _fr_skl_emit, _fr_skl_vjp)
+defop("fullrank_sample_kl_grad", _fr_skl_grad_emit, None)
+
+KERN_KINDS = {"rbf": 0, "csym_rbf": 1, "sqdist": 2}
+
+
+def gram(X, X2, ell, kind="rbf") -> Tensor:
+    """Stationary Gram matrix K(X, X2) (reference gp/kernels.py:54-131); X, X2
+    are [n,d] or [B,n,d] (a 2-D operand is shared by the batch)."""
+    X, X2, ell = as_tensor(X), as_tensor(X2), as_tensor(ell)
+    if X.shape[-1] != X2.shape[-1]:
+        raise ValueError("gram: input dimensions differ")
+    lead = X.shape[:-2] if len(X.shape) >= len(X2.shape) else X2.shape[:-2]
+    return make("gram", (X, X2, ell), {"kind": kind}, [tuple(lead) + (X.shape[-2], X2.shape[-2])]).outputs[0]
+
+
+def _gram_emit(plan, node):
+    H = plan.H
+    X, X2, ell = (plan.buf(t) for t in node.inputs)
+    out = plan.out(node.outputs[0])
+    k = KERN_KINDS[node.attrs["kind"]]
+    plan.steps.append(lambda: H.gram_fwd(X, X2, ell, kind=k, out=out))
+
+
+def _gram_vjp(node, gs):
+    g = gs[0]
+    if g is None:
+        return [None, None, None]
+    X, X2, ell = node.inputs
+    n = make("gram_grad", (X, X2, ell, g), {"kind": node.attrs["kind"]}, [X.shape, X2.shape, ell.shape])
+    return list(n.outputs)
+
+
+def _gram_grad_emit(plan, node):
+    H = plan.H
+    tX, tX2, tell, tg = node.inputs
+    X, X2, ell, g = (plan.buf(t) for t in node.inputs)
+    oX, oX2, oL = [plan.out(t) for t in node.outputs]
+    k = KERN_KINDS[node.attrs["kind"]]
+    n, d = tX.shape[-2], tX.shape[-1]
+    n2 = tX2.shape[-2]
+    BX = int(np.prod(tX.shape[:-2])) if len(tX.shape) > 2 else 1
+    BX2 = int(np.prod(tX2.shape[:-2])) if len(tX2.shape) > 2 else 1
+    B = max(BX, BX2)
+    sX = n * d if (BX == B and B > 1) else 0
+    sX2 = n2 * d if (BX2 == B and B > 1) else 0
+    # an operand shared by the batch gets its per-batch gradients summed
+    tmpX = plan.scratch((B, n, d)) if (BX == 1 and B > 1) else None
+    tmpX2 = plan.scratch((B, n2, d)) if (BX2 == 1 and B > 1) else None
+    ws = plan.scratch((max(B * n * d, 1),))
+
+    def step():
+        H.gram_bwd_raw(k, X, sX, X2, sX2, ell, g, tmpX if tmpX is not None else oX,
+                       tmpX2 if tmpX2 is not None else oX2, oL, B, n, n2, d, ws)
+        if tmpX is not None:
+            H.reduce_mid(tmpX, 1, B, n * d, out=oX)
+        if tmpX2 is not None:
+            H.reduce_mid(tmpX2, 1, B, n2 * d, out=oX2)
+
+    plan.steps.append(step)
+
+
+defop("gram", _gram_emit, _gram_vjp)
+defop("gram_grad", _gram_grad_emit, None)
+
+SGP_MODES = {"neglected": 0, "diagonal": 1}
+
+
+def sgp_samples(x, z, ell, L, u, mode="diagonal", eps=None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Fused SparseGP.samples (reference gp/gp.py:99-143) for the UnitRBF kernel
+    and a 2-D x:  A = L^-1 K(z,x); f = u A + sqrt|1 - colsum(A^2)| eps.
+    Returns (f [P,n], A [M,n], v [n], eps [n]).  L = chol(K(z,z)+jitter I)."""
+    x, z, ell, L, u = (as_tensor(t) for t in (x, z, ell, L, u))
+    W = stop_gradient(trinv(L))  # helper operand: the VJP differentiates through L directly
+    M, n, P = z.shape[-2], x.shape[-2], u.shape[-2]
+    lead = z.shape[:-2]
+    ins = [x, z, ell, L, W, u] + ([as_tensor(eps)] if eps is not None else [])
+    nd = make("sgp", tuple(ins), {"mode": mode}, [lead + (P, n), lead + (M, n), lead + (n,), lead + (n,)],
+              unique=(eps is None and mode == "diagonal"))
+    return tuple(nd.outputs)
+
+
+def _sgp_emit(plan, node):
+    H = plan.H
+    x, z, ell, L, W, u = (plan.buf(t) for t in node.inputs[:6])
+    eps_in = plan.buf(node.inputs[6]) if len(node.inputs) > 6 else None
+    outs = tuple(plan.out(t) for t in node.outputs)
+    mode = SGP_MODES[node.attrs["mode"]]
+    rng = plan.rng("local") if (eps_in is None and mode == 1) else None
+    plan.steps.append(lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs))
+
+
+def _sgp_vjp(node, gs):
+    gf = gs[0]
+    if gf is None:
+        return [None] * len(node.inputs)
+    if any(g is not None for g in gs[1:3]):
+        raise NotImplementedError("gradients through the A / v outputs of sgp_samples")
+    x, z, ell, L, W, u = node.inputs[:6]
+    f, A, v, eps = node.outputs
+    n = make("sgp_grad", (x, z, ell, W, u, eps, A, v, gf), {"mode": node.attrs["mode"]},
+             [L.shape, u.shape, z.shape, ell.shape, x.shape])
+    Lb, ub, zb, lb, xb = n.outputs
+    return [xb, zb, lb, Lb, None, ub] + [None] * (len(node.inputs) - 6)
+
+
+def _sgp_grad_emit(plan, node):
+    H = plan.H
+    x, z, ell, W, u, eps, A, v, gf = (plan.buf(t) for t in node.inputs)
+    Lb, ub, zb, lb, xb = (plan.out(t) for t in node.outputs)
+    Kbar = plan.scratch(A.shape)
+    mode = SGP_MODES[node.attrs["mode"]]
+    need_x = plan.needed(node.outputs[4])
+    if need_x and len(node.inputs[1].shape) > 2 and len(node.inputs[0].shape) == 2:
+        raise NotImplementedError("gradient w.r.t. an x shared by several experts")
+    xbuf = xb.reshape((-1,) + tuple(xb.shape[-2:])) if need_x else None
+    plan.steps.append(lambda: H.sgp_bwd(x, z, ell, W, u, eps, A, v, gf, mode=mode, need_xbar=need_x,
+                                        out=(Kbar, Lb, ub, zb, lb, xbuf)))
+
+
+defop("sgp", _sgp_emit, _sgp_vjp)
+defop("sgp_grad", _sgp_grad_emit, None)
+
+
+# ------------------------------------------------------------------------------
+# autodiff
+# ------------------------------------------------------------------------------
+def topo_order(outputs: Sequence[Tensor]) -> List[Node]:
+    seen, order = set(), []
+    stack = [(t.node, False) for t in outputs]
+    while stack:
+        n, done = stack.pop()
+        if done:
+            order.append(n)
+            continue
+        if n.id in seen:
+            continue
+        seen.add(n.id)
+        stack.append((n, True))
+        for t in n.inputs:
+            if t.node.id not in seen:
+                stack.append((t.node, False))
+    return order
+
+
+def add_n(ts: List[Tensor]) -> Tensor:
+    acc = ts[0]
+    for t in ts[1:]:
+        acc = binary("ADD", acc, t)
+    return acc
+
+
+def gradients(loss: Tensor, wrt: Sequence[Tensor]) -> List[Optional[Tensor]]:
+    """d loss / d wrt[i] as new graph tensors (None where independent).
+
+    Stands in for TF's autodiff inside optimizer.minimize (reference model.py:220)."""
+    if loss.size != 1:
+        raise ValueError("gradients() needs a scalar objective, got shape %s" % (loss.shape,))
+    order = topo_order([loss])
+    # nodes that depend on any wrt tensor
+    wrt_set = set(wrt)
+    dep = set()
+    for n in order:
+        if any(o in wrt_set for o in n.outputs) or any(t.node.id in dep for t in n.inputs):
+            dep.add(n.id)
+    grads: Dict[Tensor, List[Tensor]] = {loss: [unary("AFFINE", loss, (0.0, 1.0))]}  # ones_like(loss), on device
+    for n in reversed(order):
+        if n.id not in dep or n.op.startswith("leaf:"):
+            continue
+        outg = []
+        anyg = False
+        for o in n.outputs:
+            lst = grads.get(o)
+            if lst:
+                g = add_n(lst) if len(lst) > 1 else lst[0]
+                grads[o] = [g]
+                outg.append(g)
+                anyg = True
+            else:
+                outg.append(None)
+        if not anyg:
+            continue
+        d = OPS.get(n.op)
+        if d is None or d.vjp is None:
+            raise NotImplementedError("op %s has no gradient" % n.op)
+        ing = d.vjp(n, outg)
+        for t, g in zip(n.inputs, ing):
+            if g is None or t.node.id not in dep and t not in wrt_set:
+                continue
+            if g.shape != t.shape:
+                g = sum_to_shape(g, t.shape)
+            grads.setdefault(t, []).append(g)
+    res = []
+    for w in wrt:
+        lst = grads.get(w)
+        if not lst:
+            res.append(None)
+        else:
+            res.append(add_n(lst) if len(lst) > 1 else lst[0])
+    return res
+
+
+# ------------------------------------------------------------------------------
+# HIP executor
+# ------------------------------------------------------------------------------
+class CholeskyError(ArithmeticError):
+    """A Cholesky factorisation met a non-positive pivot (TensorFlow raises
+    InvalidArgumentError from tf.cholesky at the same point)."""
+
+
+class Plan:
+    """A compiled launch sequence for a set of output tensors.
+
+    `leaf_resolver(tensor) -> torch.Tensor` supplies device buffers for param /
+    data / minibatch leaves; `rngs` maps stream name -> hip_ops.Rng; `binds`
+    lets the caller alias chosen outputs (e.g. leaf gradients) onto its own
+    flat buffers so no copy is needed."""
+
+    def __init__(self, outputs, dtype, device, leaf_resolver, rngs, binds=None, prologue=None, stream=None):
+        from . import hip_ops
+
+        import torch
+
+        self.H = hip_ops
+        self.torch = torch
+        self.dtype, self.device = dtype, device
+        self.outputs = list(outputs)
+        self.steps: List = []
+        self._buf: Dict[Tensor, object] = {}
+        self._bind: Dict[Tensor, object] = {}
+        self._rngs = rngs
+        self._infos: List[Tuple[object, str]] = []
+        self._nocap: List[str] = []
+        self._graph = None
+        self.stream = stream          # torch.cuda.Stream the plan runs on (None = current)
+        self.side_effect_steps = set()  # steps skipped by the capture warm-up (e.g. the Adam update)
+        self.noise_inputs: Dict[Tensor, object] = {}
+        self._injected: Dict[Tensor, bool] = {}
+        self._leaf_resolver = leaf_resolver
+        order = topo_order(self.outputs)
+        self._needed = set()
+        for n in order:
+            for t in n.inputs:
+                self._needed.add(t)
+        for t in self.outputs:
+            self._needed.add(t)
+        self._extra_copies = []
+        for t, b in (binds or []):
+            self._prebind(t, b)
+        if prologue:
+            prologue(self)
+        for n in order:
+            self._emit(n)
+        # outputs that could not be bound in place: explicit copy
+        for t, b in list(self._bind.items()) + self._extra_copies:
+            got = self._buf.get(t)
+            if got is not None and got.data_ptr() != b.data_ptr():
+                src = got
+                self.steps.append(lambda src=src, b=b: hip_ops.ewise("COPY", [src.reshape(b.shape)], out=b))
+
+    # -- buffer management
+    def _prebind(self, t, b):
+        n = t.node
+        if n.op == "reshape":
+            self._prebind(n.inputs[0], b.view(n.inputs[0].shape))
+            return
+        b = b.view(t.shape) if tuple(b.shape) != t.shape else b
+        if t in self._bind:
+            self._extra_copies.append((t, b))  # same tensor feeds two destinations
+        else:
+            self._bind[t] = b
+
+    def needed(self, t):
+        return t in self._needed
+
+    def buf(self, t):
+        b = self._buf.get(t)
+        if b is None:
+            raise RuntimeError("buffer of %r requested before it was produced" % (t,))
+        return b
+
+    def out(self, t):
+        b = self._buf.get(t)
+        if b is None:
+            if t in self._bind and t.node.op not in ("reshape", "stop_gradient") and not t.node.op.startswith("leaf:"):
+                b = self._bind[t]
+            else:
+                b = self.torch.empty(t.shape, dtype=self.dtype, device=self.device)
+            self._buf[t] = b
+        return b
+
+    def alias(self, t, b):
+        self._buf[t] = b
+
+    def scratch(self, shape):
+        return self.torch.empty(tuple(shape), dtype=self.dtype, device=self.device)
+
+    def new_info(self, n, label):
+        info = self.torch.zeros(max(int(n), 1), dtype=self.torch.int32, device=self.device)
+        self._infos.append((info, label))
+        return info
+
+    def rng(self, stream):
+        return self._rngs[stream]
+
+    def not_capturable(self, why):
+        self._nocap.append(why)
+
+    # -- lowering
+    def _emit(self, n: Node):
+        if n.op.startswith("leaf:"):
+            t = n.outputs[0]
+            kind = n.op[5:]
+            if kind == "const":
+                arr = np.ascontiguousarray(n.attrs["value"])
+                self._buf[t] = self.torch.as_tensor(arr).to(dtype=self.dtype, device=self.device).reshape(t.shape)
+            elif kind == "noise":
+                b = self.torch.empty(t.shape, dtype=self.dtype, device=self.device)
+                self._buf[t] = b
+                self.noise_inputs[t] = b
+                rng = self._rngs[n.attrs["stream"]]
+                plan = self
+
+                def step(b=b, rng=rng, t=t):
+                    if t not in plan._injected:
+                        rng.normal(b.shape, out=b)
+
+                self.steps.append(step)
+            else:
+                self._buf[t] = self._leaf_resolver(t)
+            return
+        d = OPS.get(n.op)
+        if d is None or d.emit is None:
+            raise NotImplementedError("op %s cannot be lowered" % n.op)
+        d.emit(self, n)
+
+    def inject_noise(self, t: Tensor, value):
+        """Overwrite a random_normal leaf with a fixed draw (parity runs)."""
+        b = self.noise_inputs[t]
+        b.copy_(self.torch.as_tensor(np.asarray(value)).to(dtype=self.dtype, device=self.device).reshape(b.shape))
+        self._injected[t] = True
+        self._graph = None
+
+    # -- execution
+    def _on_stream(self):
+        import contextlib
+
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def run(self):
+        with self._on_stream():
+            if self._graph is not None:
+                self._graph.launch()
+            else:
+                for s in self.steps:
+                    s()
+
+    def capture(self):
+        """Record the launch sequence into one hipGraph (replayed by run()).  A
+        warm-up pass first lets lazily sized workspaces allocate outside the
+        capture; steps with side effects on the parameters are skipped in it."""
+        if self._nocap:
+            return False
+        self.torch.cuda.synchronize()
+        with self._on_stream():
+            for s in self.steps:
+                if s not in self.side_effect_steps:
+                    s()
+            self.torch.cuda.current_stream().synchronize()
+            g = self.H.CapturedGraph()
+            g.begin()
+            try:
+                for s in self.steps:
+                    s()
+            finally:
+                g.end()
+        self._graph = g
+        return True
+
+    def check(self):
+        """Synchronise and raise if any Cholesky in the plan failed."""
+        self.torch.cuda.synchronize()
+        for info, label in self._infos:
+            bad = info.nonzero()
+            if bad.numel():
+                k = int(info[bad[0, 0]].item())
+                raise CholeskyError("%s: leading minor %d is not positive definite (matrix %d)"
+                                    % (label, k, int(bad[0, 0].item())))
+
+    def value(self, t: Tensor):
+        return self.buf(t).detach().cpu().numpy()

@@ -27,7 +27,7 @@ EW = dict(
     GAUSS_LOGPDF_GRAD=80,
 )
 RED_SUM, RED_MAX = 0, 1
-KERN_RBF, KERN_CSYM_RBF = 0, 1
+KERN_RBF, KERN_CSYM_RBF, KERN_SQDIST = 0, 1, 2
 MM_LOWER_OUT = 1
 ACT = dict(none=0, sigmoid=1, relu=2, tanh=3)
 SGP_NEGLECTED, SGP_DIAGONAL = 0, 1
@@ -284,6 +284,12 @@ def gram_fwd(X, X2, ell, kind=KERN_RBF, out=None):
     return out
 
 
+def gram_bwd_raw(kind, X, sX, X2, sX2, ell, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws):
+    """hb_gram_bwd on caller-provided buffers (no allocation: graph-capturable)."""
+    _lib.lib().call("hb_gram_bwd" + _suf(X), kind, _p(X), sX, _p(X2), sX2, _p(ell), ell.numel(), _p(Kbar), _p(Xbar),
+                    _p(X2bar), _p(ellbar), B, n, n2, d, _p(ws), stream())
+
+
 def gram_bwd(X, X2, ell, Kbar, kind=KERN_RBF, need=(True, True, True)):
     """VJP of gram_fwd: returns (Xbar, X2bar, ellbar) (None where not needed).
     Operands shared over the batch get their gradient summed over it."""
@@ -298,8 +304,7 @@ def gram_bwd(X, X2, ell, Kbar, kind=KERN_RBF, need=(True, True, True)):
     X2bar = torch.empty((B, n2, d), dtype=dt, device=dev) if need[1] else None
     ellbar = torch.empty(ell.numel(), dtype=dt, device=dev) if need[2] else None
     ws = workspace(dt, dev, max(B * n * d, 1))
-    _lib.lib().call("hb_gram_bwd" + _suf(X), kind, _p(X), sX, _p(X2), sX2, _p(ell), ell.numel(), _p(Kbar), _p(Xbar),
-                    _p(X2bar), _p(ellbar), B, n, n2, d, _p(ws), stream())
+    gram_bwd_raw(kind, X, sX, X2, sX2, ell, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws)
     if Xbar is not None:
         Xbar = reduce_mid(Xbar, 1, B, n * d).reshape(X.shape) if (BX == 1 and B > 1) else Xbar.reshape(X.shape)
     if X2bar is not None:

@@ -1,0 +1,326 @@
+"""Model / AutoOptimize / Optimizer: the driver of the ELBO step.
+
+Same surface as reference Henbun/model.py:13-269:
+    class M(hb.model.Model):
+        def setUp(self): ...parameters...
+        @hb.model.AutoOptimize()
+        def ELBO(self): ...
+    m.ELBO().compile(optimizer=hb.tf.train.AdamOptimizer(1e-3))
+    m.ELBO().run(minibatch_size)       -> float
+    m.ELBO().optimize(maxiter, minibatch_size)
+
+`compile` traces the method in tf_mode into a henbun_amd graph, differentiates
+it (graph-level autodiff stands in for TF's), and lowers objective + gradients +
+the fused flat-buffer Adam update into one hipGraph per minibatch size;
+`optimize` replays it (one host call per step).  Under torch.distributed the
+flat gradient is all-reduced (RCCL) between backward and Adam.
+"""
+from __future__ import annotations
+
+from functools import wraps
+
+import numpy as np
+
+from . import graph as G
+from ._settings import settings
+from .param import Data, MinibatchData, Parameterized, Variable, graph_key
+from .session import Indexer, Session
+
+
+class AdamOptimizer:
+    """tf.train.AdamOptimizer hyper-parameters + slots (TF-1 update rule, see
+    include/henbun_hip.h hb_adam_step).  One instance may serve several compiled
+    objectives; its slots (m, v, step count) are kept per parameter layout."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-08, name="Adam"):
+        self.learning_rate, self.beta1, self.beta2, self.epsilon = learning_rate, beta1, beta2, epsilon
+        self._slots = {}
+
+    def slots(self, session):
+        key = (id(session), session.layout_version)
+        s = self._slots.get(key)
+        if s is None:
+            torch = session.torch
+            n = session.theta.numel()
+            s = {
+                "m": torch.zeros(n, dtype=session.torch_dtype, device=session.device),
+                "v": torch.zeros(n, dtype=session.torch_dtype, device=session.device),
+                "t": torch.zeros(1, dtype=torch.int64, device=session.device),
+            }
+            self._slots[key] = s
+        return s
+
+
+class Model(Parameterized):
+    """Root of a parameter tree; owns the device session (reference model.py:13-123)."""
+
+    def __init__(self, name="model", dtype=None, seed=None, **kw):
+        Parameterized.__init__(self)
+        self._name = name
+        self._session = Session(self, dtype=dtype, seed=seed)
+        self._index = Indexer()
+        self.setUp(**kw)
+
+    @property
+    def name(self):
+        return self._name
+
+    def setUp(self):
+        pass
+
+    def _begin_tf_mode(self):
+        self._session.trace_id += 1
+        Parameterized._begin_tf_mode(self)
+
+    def initialize(self):
+        """Make pending assignments effective on the device (reference model.py:76-82)."""
+        self._session.initialize()
+        self.finalize()
+
+    def run(self, tensor, feed_dict=None):
+        """Evaluate a graph tensor (built in tf_mode) with the current parameters
+        (reference model.py:84-96).  MinibatchData is fed whole."""
+        self.initialize()
+        plan = self._session.make_plan([G.as_tensor(tensor)])
+        plan.run()
+        plan.check()
+        return plan.value(plan.outputs[0])
+
+    def validate(self):
+        """reference model.py:98-117."""
+        for p in self.get_variables(graph_key.LOCAL):
+            if p._tensor is None:
+                raise ValueError("local variable " + p.long_name + " is not fed.")
+        self._setup_index()
+
+    def _setup_index(self):
+        mb = [d for d in self.get_variables(graph_key.DATA) if isinstance(d, MinibatchData)]
+        if len(mb) > 1:
+            for d in mb:
+                if d.data_size != mb[0].data_size:
+                    raise ValueError("Minibatch data" + d.long_name + " is not the same size.")
+        if len(mb) > 0:
+            data_size = mb[0].data_size
+            if self._index.data_size is None or self._index.data_size != data_size:
+                self._index.setUp(data_size)
+
+    def test_feed_dict(self, minibatch_size=None):
+        return self.get_feed_dict(self._index.test_index(minibatch_size))
+
+
+class AutoOptimize:
+    """Decorator: `m.method()` returns the cached Optimizer of that method
+    (reference model.py:155-188)."""
+
+    def __call__(self, method):
+        @wraps(method)
+        def runnable(instance):
+            name = "_" + method.__name__ + "_AF_optimizer"
+            d = object.__getattribute__(instance, "__dict__")
+            if name not in d:
+                object.__setattr__(instance, name, Optimizer(instance, method))
+            return d[name]
+
+        return runnable
+
+
+_DEFAULT_ADAM = AdamOptimizer()
+
+
+class Optimizer:
+    def __init__(self, model_instance, likelihood_method):
+        self.model = model_instance
+        self.likelihood_method = likelihood_method
+        self.method_op = None
+        self.optimize_op = None
+        self._optimizer = None
+        self._collection = graph_key.VARIABLES
+        self._plans = {}
+        self.dp_reduce = "mean"
+        self.last_plan = None
+
+    # ------------------------------------------------------------------ tracing
+    def _trace(self, minibatch):
+        sess = self.model._session
+        sess.trace_minibatch = minibatch
+        try:
+            with self.model.tf_mode():
+                obj = self.likelihood_method(self.model)
+        finally:
+            sess.trace_minibatch = None
+        if not isinstance(obj, G.Tensor):
+            obj = G.constant(np.asarray(obj, dtype=np.float64))
+        if obj.size != 1:
+            raise ValueError("the objective must be a scalar, got shape %s" % (obj.shape,))
+        return G.reshape(obj, [])
+
+    def compile(self, optimizer=_DEFAULT_ADAM, collection=graph_key.VARIABLES, global_step=None, dp_reduce="mean"):
+        """Trace + validate; device plans are built per minibatch size on first use
+        (reference model.py:206-230).  `dp_reduce`: how per-rank gradients combine
+        under data parallelism ('mean': each rank's objective already estimates the
+        full ELBO from its own minibatch; 'sum': the objective is a plain sum over rows)."""
+        print("compiling...")
+        self._optimizer = optimizer
+        self._collection = collection
+        self.dp_reduce = dp_reduce
+        self._plans = {}
+        self.model.initialize()
+        mbs = [d for d in self.model.get_variables(graph_key.DATA) if isinstance(d, MinibatchData)]
+        probe = None
+        if mbs:
+            self.model._setup_index()
+            probe = min(2, self.model._index.train_size)
+        self.model._session.probing = True
+        try:
+            self.method_op = self._trace(probe)
+        finally:
+            self.model._session.probing = False
+        self.model.validate()
+        self.optimize_op = True
+        print("finished.")
+
+    # ------------------------------------------------------------------ plans
+    def _settings_key(self):
+        n = settings.numerics
+        return (n.jitter_level, n.clip_by_value, n.clip_value_min, n.clip_value_max,
+                str(settings.runtime.index_source))
+
+    def _get_plan(self, kind, minibatch, training=True):
+        sess = self.model._session
+        self.model.initialize()
+        key = (kind, minibatch, training, sess.layout_version, self._settings_key())
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        if minibatch is not None:
+            self.model._setup_index()
+        obj = self._trace(minibatch)
+        if kind == "run":
+            plan = sess.make_plan([obj], minibatch=minibatch, training=training)
+            plan.objective = obj
+        else:
+            leaves = []
+            for t in self.model.get_tf_variables(self._collection):
+                if t is not None and t.node.op == "leaf:param" and t not in leaves:
+                    leaves.append(t)
+            loss = G.unary("NEG", obj)
+            grads = G.gradients(loss, leaves)
+            torch = sess.torch
+            gflat = torch.zeros(sess.theta.numel(), dtype=sess.torch_dtype, device=sess.device)
+            binds, segs = [], []
+            for t, g in zip(leaves, grads):
+                o, s = sess._offsets[id(t.node.attrs["var"])]
+                segs.append((o, s))
+                if g is not None:
+                    binds.append((g, gflat[o:o + s]))
+            outs = [obj] + [g for g in grads if g is not None]
+            plan = sess.make_plan(outs, binds=binds, minibatch=minibatch, training=True)
+            plan.objective = obj
+            plan.gflat = gflat
+            # merge optimised leaves into contiguous segments of the flat buffer
+            segs.sort()
+            merged = []
+            for o, s in segs:
+                if merged and merged[-1][0] + merged[-1][1] == o:
+                    merged[-1] = (merged[-1][0], merged[-1][1] + s)
+                else:
+                    merged.append((o, s))
+            plan.segments = merged
+            opt = self._optimizer
+            slots = opt.slots(sess)
+            H = sess.H
+            theta = sess.theta
+            gscale = 1.0 / sess.world_size if (sess.world_size > 1 and self.dp_reduce == "mean") else 1.0
+
+            def adam():
+                # one fused launch per contiguous segment; the shared step counter ticks once
+                t = slots["t"]
+                for i, (o, s) in enumerate(merged):
+                    last = i == len(merged) - 1
+                    tt = t if last else plan.t_scratch
+                    if not last:
+                        tt.copy_(t)
+                    H.adam_step(theta[o:o + s], gflat[o:o + s], slots["m"][o:o + s], slots["v"][o:o + s], tt,
+                                lr=opt.learning_rate, b1=opt.beta1, b2=opt.beta2, eps=opt.epsilon, gscale=gscale)
+
+            plan.t_scratch = torch.zeros(1, dtype=torch.int64, device=sess.device)
+            plan.adam = adam
+            if sess.world_size == 1:
+                plan.steps.append(adam)
+                plan.side_effect_steps.add(adam)
+        if settings.runtime.graph_capture:
+            plan.capture()
+        self._plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------ reference API
+    def feed_dict(self, minibatch_size=None, training=True):
+        """Host-side view of what a step would be fed (reference model.py:232-243)."""
+        if minibatch_size is None:
+            return self.model.get_feed_dict(None)
+        if training:
+            return self.model.get_feed_dict(self.model._index.train_index(minibatch_size))
+        return self.model.get_feed_dict(self.model._index.test_index(minibatch_size))
+
+    def _ensure_compiled(self):
+        if self._optimizer is None:
+            self.compile()
+
+    def run(self, minibatch_size=None, training=True, indices=None):
+        """Objective value at the current parameters (reference model.py:245-253).
+        `indices` optionally fixes the minibatch rows (indices into the data array)."""
+        self._ensure_compiled()
+        plan = self._get_plan("run", minibatch_size, training)
+        if indices is not None:
+            plan.set_indices(indices)
+        plan.run()
+        plan.check()
+        self.last_plan = plan
+        return float(plan.value(plan.objective))
+
+    def optimize(self, maxiter=1, minibatch_size=None, indices=None):
+        """`maxiter` Adam steps (reference model.py:255-269)."""
+        self._ensure_compiled()
+        plan = self._get_plan("opt", minibatch_size)
+        if indices is not None:
+            plan.set_indices(indices)
+        sess = self.model._session
+        if sess.world_size == 1:
+            for _ in range(int(maxiter)):
+                plan.run()
+        else:
+            import torch.distributed as dist
+
+            for _ in range(int(maxiter)):
+                plan.run()
+                with plan._on_stream():
+                    for o, s in plan.segments:
+                        dist.all_reduce(plan.gflat[o:o + s])
+                    plan.adam()
+        plan.check()
+        self.last_plan = plan
+
+    def gradients(self, minibatch_size=None, indices=None):
+        """{long_name: d objective / d raw parameter} at the current parameters
+        (not in the reference; used by the parity tests).  Runs forward+backward
+        without the Adam update."""
+        self._ensure_compiled()
+        sess = self.model._session
+        self.model.initialize()
+        obj = self._trace(minibatch_size)
+        leaves, names = [], []
+        for v in self.model.get_variables(self._collection):
+            if v.is_parameter and v._leaf not in leaves:
+                leaves.append(v._leaf)
+                names.append(v.long_name)
+        grads = G.gradients(obj, leaves)
+        outs = [obj] + [g for g in grads if g is not None]
+        plan = sess.make_plan(outs, minibatch=minibatch_size)
+        if indices is not None:
+            plan.set_indices(indices)
+        plan.run()
+        plan.check()
+        res = {}
+        for nme, t, g in zip(names, leaves, grads):
+            res[nme] = np.zeros(t.shape) if g is None else plan.value(g).astype(np.float64)
+        return float(plan.value(obj)), res

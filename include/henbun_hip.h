@@ -164,7 +164,7 @@ int hb_fullrank_sample_kl_bwd_f64(const double* S, const double* u, const double
 
 /* ---- K3: stationary Gram matrices (reference gp/kernels.py:54-84
  *      square_dist, :110-111 UnitRBF.K, :122-131 UnitCsymRBF) -------------- */
-enum { HB_KERN_RBF = 0, HB_KERN_CSYM_RBF = 1 };
+enum { HB_KERN_RBF = 0, HB_KERN_CSYM_RBF = 1, HB_KERN_SQDIST = 2 /* the scaled squared distance itself */ };
 /* K[b,i,j] = k(X[b,i,:], X2[b,j,:]); sX/sX2 = batch strides in elements (0 =
  * shared); ell has dl = 1 (scalar) or d entries (ARD), post-transform. */
 int hb_gram_fwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,

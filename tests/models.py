@@ -1,0 +1,78 @@
+"""Model definitions shared by the CPU and GPU test suites and by bench.py.
+
+Written the way a reference user would write them (SURVEY.md Appendix C;
+reference notebooks/GaussianProcess.ipynb:109-159), with `tf = hb.tf`.
+"""
+import numpy as np
+
+import henbun_amd as hb
+
+tf = hb.tf
+
+
+class SVGP(hb.model.Model):
+    """Sparse variational GP regression: cfg 1/2 (q_shape='diagonal') and cfg 3 ('fullrank')."""
+
+    def setUp(self, X, Y, Z, q_shape="diagonal", residual="diagonal", eps=None):
+        self.N = X.shape[0]
+        self.X = hb.param.MinibatchData(X)
+        self.Y = hb.param.MinibatchData(Y)
+        self.gp = hb.gp.SparseGP(kern=hb.gp.kernels.UnitRBF(np.ones(1)), z=Z)
+        self.u = hb.variationals.Normal(shape=[1, Z.shape[0]], q_shape=q_shape)
+        self.k_var = hb.param.Variable([1], transform=hb.transforms.positive)
+        self.var = hb.param.Variable([1], transform=hb.transforms.positive)
+        self.residual = residual
+        self.eps = None if eps is None else hb.param.MinibatchData(eps)  # injected residual noise (parity runs)
+
+    @hb.model.AutoOptimize()
+    def ELBO(self):
+        f = self.gp.samples(self.X, self.u, q_shape=self.residual, eps=self.eps) * tf.sqrt(self.k_var)
+        n = tf.shape(self.X)[0]
+        ll = tf.reduce_sum(hb.densities.gaussian(tf.transpose(self.Y), f, self.var))
+        return (self.N / n) * ll - self.KL()
+
+
+class Amortised(hb.model.Model):
+    """cfg 4: NeuralNet encoder -> LOCAL Normal -> linear Gaussian decoder."""
+
+    def setUp(self, Y, L=16, H=256, stddev=None):
+        Din = Y.shape[1]
+        self.Y = hb.param.MinibatchData(Y)
+        self.z = hb.variationals.Normal([L], collections=hb.param.graph_key.LOCAL)
+        self.enc = hb.nn.NeuralNet([Din, H, 2 * L], stddev=stddev or 1.0 / np.sqrt(Din))
+        self.dec = hb.nn.NeuralNet([L, Din], stddev=stddev or 1.0 / np.sqrt(L))
+        self.var = hb.param.Variable([1], transform=hb.transforms.positive)
+
+    @hb.model.AutoOptimize()
+    def ELBO(self):
+        self.z = self.enc(self.Y)
+        ll = tf.reduce_sum(hb.densities.gaussian(self.Y, self.dec(self.z), self.var))
+        return ll - self.KL()
+
+
+class DenseGPR(hb.model.Model):
+    """Dense variational GP regression, the form of notebooks/GaussianProcess.ipynb:109-148."""
+
+    def setUp(self, X, Y):
+        self.X = hb.param.Data(X)
+        self.Y = hb.param.Data(Y)
+        self.kern = hb.gp.kernels.UnitRBF(np.ones(1))
+        self.k_var = hb.param.Variable([1], transform=hb.transforms.positive)
+        self.var = hb.param.Variable([1], transform=hb.transforms.positive)
+        self.q = hb.variationals.Normal(shape=[X.shape[0], 1], q_shape="fullrank")
+
+    @hb.model.AutoOptimize()
+    def ELBO(self):
+        f = tf.matmul(self.kern.Cholesky(self.X), self.q) * tf.sqrt(self.k_var)
+        return tf.reduce_sum(hb.densities.gaussian(self.Y, f, self.var)) - self.KL()
+
+
+def svgp_data(N, M, seed=0, domain=None, dtype=np.float64):
+    """Synthetic regression set of the BASELINE configs: X ~ U(0, domain),
+    Y = sin X + 0.3 eps, Z = linspace(0, domain, M) (spacing 0.5 lengthscales)."""
+    rng = np.random.RandomState(seed)
+    domain = 0.5 * M if domain is None else domain
+    X = rng.uniform(0, domain, (N, 1))
+    Y = np.sin(X) + 0.3 * rng.randn(N, 1)
+    Z = np.linspace(0, domain, M)[:, None]
+    return X.astype(dtype), Y.astype(dtype), Z.astype(dtype)

@@ -1,0 +1,280 @@
+"""GPU end-to-end parity: the compiled ELBO path (trace -> autodiff -> HIP plan
+-> fused Adam) against the CPU oracle, through the reference-style model API.
+
+North-star bar: ELBO and gradients within 1e-5 relative on fp64 inputs at
+injected noise; tolerances are written at each assertion."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import henbun_amd as hb
+import henbun_oracle as O
+
+from models import SVGP, Amortised, DenseGPR, svgp_data
+
+pytestmark = pytest.mark.gpu
+tf = hb.tf
+
+
+def raw(v):
+    return O.T(v._host_raw) if v._host_raw is not None else None
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64).reshape(-1), np.asarray(b, dtype=np.float64).reshape(-1)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def make_svgp(N, M, n, q_shape, dtype, seed=0, residual="diagonal"):
+    np.random.seed(seed)
+    rng = np.random.RandomState(seed)
+    X, Y, Z = svgp_data(N, M, seed)
+    eps = rng.randn(N)
+    m = SVGP(X=X, Y=Y, Z=Z, q_shape=q_shape, residual=residual, eps=eps, dtype=dtype)
+    m.gp.kern.lengthscales = np.ones(1) * 0.9
+    m.k_var = np.ones(1) * 1.3
+    m.var = np.ones(1) * 0.4
+    if q_shape == "fullrank":
+        m.u.q_sqrt = 0.3 * np.eye(M) + 0.02 * rng.randn(M, M)
+    u = rng.randn(M)
+    m.u.inject_noise(u)
+    idx = rng.randint(0, N, n)
+    return m, (X, Y, Z, eps, u, idx)
+
+
+def oracle_svgp(m, data, jitter, q_shape, residual="diagonal"):
+    X, Y, Z, eps, u, idx = data
+    M = Z.shape[0]
+    sess = m._session
+    params = {
+        "z": O.T(sess.read_raw(m.gp.z)), "ell_raw": O.T(sess.read_raw(m.gp.kern.lengthscales)),
+        "q_mu": O.T(sess.read_raw(m.u.q_mu)).reshape(1, M), "q_sqrt": O.T(sess.read_raw(m.u.q_sqrt)),
+        "k_var_raw": O.T(sess.read_raw(m.k_var)), "var_raw": O.T(sess.read_raw(m.var)),
+    }
+    fn = lambda p: O.svgp_elbo(p, O.T(X[idx]), O.T(Y[idx]), float(X.shape[0]), O.T(u), O.T(eps[idx]), jitter=jitter,
+                               q_shape=q_shape, residual=residual)
+    return fn, params
+
+
+NAMES = [("model.gp.z", "z"), ("model.gp.kern.lengthscales", "ell_raw"), ("model.u.q_mu", "q_mu"),
+         ("model.u.q_sqrt", "q_sqrt"), ("model.k_var", "k_var_raw"), ("model.var", "var_raw")]
+
+
+@pytest.mark.parametrize("q_shape,N,M,n", [("diagonal", 1000, 64, 1000),    # BASELINE cfg 1 sizes
+                                           ("diagonal", 3000, 200, 700),
+                                           ("fullrank", 2000, 96, 512),
+                                           ("diagonal", 5000, 512, 2048)])   # cfg-2 inducing count
+def test_svgp_fp64_elbo_and_gradient_parity(q_shape, N, M, n):
+    cfg = hb.settings.get_settings()
+    cfg.numerics.jitter_level = 1e-5
+    with hb.settings.temp_settings(cfg):
+        m, data = make_svgp(N, M, n, q_shape, "float64")
+        opt = m.ELBO()
+        opt.compile()
+        val, grads = opt.gradients(minibatch_size=n, indices=data[5])
+        assert np.isclose(opt.run(minibatch_size=n, indices=data[5]), val, rtol=1e-12)
+        fn, params = oracle_svgp(m, data, 1e-5, q_shape)
+        ref_val, ref = O.grads_of(fn, params)
+    assert abs(val - ref_val.item()) <= 1e-5 * abs(ref_val.item()), (val, ref_val.item())
+    for mine, theirs in NAMES:
+        e = rel_err(grads[mine], ref[theirs].numpy())
+        assert e <= 1e-5, "%s: relative gradient error %.3e > 1e-5" % (mine, e)
+
+
+def test_svgp_fp32_tracks_fp64():
+    """fp32 (the benchmark dtype) against the fp64 oracle: reported, loosely bounded (cond(Kmm) ~ 1e5)."""
+    cfg = hb.settings.get_settings()
+    cfg.numerics.jitter_level = 1e-5
+    with hb.settings.temp_settings(cfg):
+        m, data = make_svgp(4000, 256, 1024, "diagonal", "float32")
+        opt = m.ELBO()
+        opt.compile()
+        val, grads = opt.gradients(minibatch_size=1024, indices=data[5])
+        fn, params = oracle_svgp(m, data, 1e-5, "diagonal")
+        ref_val, ref = O.grads_of(fn, params)
+    assert abs(val - ref_val.item()) <= 2e-3 * abs(ref_val.item())
+    for mine, theirs in NAMES:
+        assert rel_err(grads[mine], ref[theirs].numpy()) <= 5e-2, mine
+
+
+@pytest.mark.parametrize("capture", [True, False])
+def test_svgp_adam_trajectory_matches_oracle(capture):
+    """10 Adam steps at fixed noise/minibatch == the oracle's TF-formula Adam on autograd gradients."""
+    cfg = hb.settings.get_settings()
+    cfg.numerics.jitter_level = 1e-5
+    cfg.runtime.graph_capture = capture
+    with hb.settings.temp_settings(cfg):
+        m, data = make_svgp(1500, 48, 400, "diagonal", "float64", seed=3)
+        opt = m.ELBO()
+        opt.compile(optimizer=tf.train.AdamOptimizer(0.01))
+        fn, params = oracle_svgp(m, data, 1e-5, "diagonal")
+        names = list(params)
+        leaves = [params[k].clone() for k in names]
+        adam = O.AdamTF(leaves, lr=0.01)
+        for _ in range(10):
+            _, g = O.grads_of(fn, dict(zip(names, leaves)))
+            adam.step([-g[k] for k in names])  # minimise -ELBO
+        opt.optimize(maxiter=10, minibatch_size=400, indices=data[5])
+    sess = m._session
+    got = {"z": sess.read_raw(m.gp.z), "ell_raw": sess.read_raw(m.gp.kern.lengthscales),
+           "q_mu": sess.read_raw(m.u.q_mu), "q_sqrt": sess.read_raw(m.u.q_sqrt),
+           "k_var_raw": sess.read_raw(m.k_var), "var_raw": sess.read_raw(m.var)}
+    for k, ref in zip(names, leaves):
+        assert rel_err(got[k], ref.numpy()) <= 1e-6, k
+
+
+def test_amortised_fp64_parity_and_training():
+    np.random.seed(5)
+    rng = np.random.RandomState(0)
+    N, Din, H, L, n = 3000, 12, 32, 4, 512
+    Z0 = rng.randn(N, L)
+    Y = np.tanh(Z0 @ rng.randn(L, Din) / np.sqrt(L)) + 0.1 * rng.randn(N, Din)
+    m = Amortised(Y=Y, L=L, H=H, dtype="float64")
+    u = rng.randn(n, L)
+    m.z.inject_noise(u)
+    idx = rng.randint(0, N, n)
+    opt = m.ELBO()
+    opt.compile(dp_reduce="sum")
+    val, grads = opt.gradients(minibatch_size=n, indices=idx)
+    sess = m._session
+    params = {
+        "enc_w0": O.T(sess.read_raw(m.enc.matbias0.w)), "enc_b0": O.T(sess.read_raw(m.enc.matbias0.b)),
+        "enc_w1": O.T(sess.read_raw(m.enc.matbias1.w)), "enc_b1": O.T(sess.read_raw(m.enc.matbias1.b)),
+        "dec_w0": O.T(sess.read_raw(m.dec.matbias0.w)), "dec_b0": O.T(sess.read_raw(m.dec.matbias0.b)),
+        "var_raw": O.T(sess.read_raw(m.var)),
+    }
+    ref_val, ref = O.grads_of(lambda p: O.amortised_elbo(p, O.T(Y[idx]), O.T(u)), params)
+    assert abs(val - ref_val.item()) <= 1e-8 * abs(ref_val.item())
+    names = {"model.enc.matbias0.w": "enc_w0", "model.enc.matbias0.b": "enc_b0", "model.enc.matbias1.w": "enc_w1",
+             "model.enc.matbias1.b": "enc_b1", "model.dec.matbias0.w": "dec_w0", "model.dec.matbias0.b": "dec_b0",
+             "model.var": "var_raw"}
+    for k, r in names.items():
+        assert rel_err(grads[k], ref[r].numpy()) <= 1e-7, k
+    # training with in-kernel noise and device-drawn minibatches improves the held-out objective
+    m.z.inject_noise(None)
+    before = np.mean([m.ELBO().run(minibatch_size=256, training=False) for _ in range(5)])
+    opt2 = m.ELBO()
+    opt2.compile(optimizer=tf.train.AdamOptimizer(0.01), dp_reduce="sum")
+    opt2.optimize(maxiter=300, minibatch_size=256)
+    after = np.mean([m.ELBO().run(minibatch_size=256, training=False) for _ in range(5)])
+    assert after > before
+
+
+def test_dense_gpr_parity():
+    np.random.seed(2)
+    rng = np.random.RandomState(0)
+    n = 40  # notebooks/GaussianProcess.ipynb:75-76 size
+    X = np.sort(rng.uniform(0, 6, (n, 1)), axis=0)
+    Y = np.sin(X) + 0.3 * rng.randn(n, 1)
+    cfg = hb.settings.get_settings()
+    cfg.numerics.jitter_level = 1e-4
+    with hb.settings.temp_settings(cfg):
+        m = DenseGPR(X=X, Y=Y, dtype="float64")
+        m.q.q_sqrt = 0.5 * np.eye(n) + 0.02 * rng.randn(n, n)
+        u = rng.randn(n)
+        m.q.inject_noise(u)
+        opt = m.ELBO()
+        opt.compile()
+        val, grads = opt.gradients()
+    sess = m._session
+    ps = [v for v in m.get_variables() if v.is_parameter]
+    leaves = {v.long_name: O.T(sess.read_raw(v)).clone().requires_grad_(True) for v in ps}
+    ell = O.log1pe_forward(leaves["model.kern.lengthscales"])
+    L = O.kern_cholesky(O.T(X), ell, 1e-4)
+    S = leaves["model.q.q_sqrt"]
+    xs = O.sample_fullrank(leaves["model.q.q_mu"], S, O.T(u))
+    kl = O.kl_normal(S, O.T(u), xs, "fullrank")
+    f = (L @ xs.reshape(n, 1)) * torch.sqrt(O.log1pe_forward(leaves["model.k_var"]))
+    elbo = torch.sum(O.gaussian(O.T(Y), f, O.log1pe_forward(leaves["model.var"]))) - kl
+    ref = torch.autograd.grad(elbo, [leaves[v.long_name] for v in ps])
+    assert abs(val - elbo.item()) <= 1e-8 * abs(elbo.item())
+    for v, r in zip(ps, ref):
+        assert rel_err(grads[v.long_name], r.numpy()) <= 1e-5, v.long_name
+
+
+def test_square_model_converges_and_collections():
+    """reference testing/test_model.py:8-29,61-74: Adam drives -sum(p^2) to 0 (lr 0.01, 1500 its, atol 1e-4)."""
+
+    class SquareModel(hb.model.Model):
+        def setUp(self):
+            self.p = hb.param.Variable([2, 3])
+            self.q = hb.param.Variable([2, 3], collections=["other"])
+
+        @hb.model.AutoOptimize()
+        def likelihood(self):
+            return -tf.reduce_sum(tf.square(self.p)) - tf.reduce_sum(tf.square(self.q))
+
+    np.random.seed(0)
+    m = SquareModel()
+    q0 = None
+    m.likelihood().compile(optimizer=tf.train.AdamOptimizer(0.01))
+    m.initialize()
+    q0 = m.q.value.copy()
+    m.likelihood().optimize(maxiter=1500)
+    assert np.allclose(m.p.value, 0.0, atol=1e-4)
+    assert np.allclose(m.q.value, q0)  # other collection untouched
+    assert np.isclose(m.likelihood().run(), -np.sum(q0 ** 2), rtol=1e-4)
+    m.likelihood().compile(optimizer=tf.train.AdamOptimizer(0.01), collection="other")
+    m.likelihood().optimize(maxiter=1500)
+    assert np.allclose(m.q.value, 0.0, atol=1e-4)
+
+
+def test_assign_value_save_restore(tmp_path):
+    """reference testing/test_model.py:53-59,76-105."""
+
+    class M(hb.model.Model):
+        def setUp(self):
+            self.a = hb.param.Variable([3], transform=hb.transforms.positive)
+            self.sub = hb.nn.NeuralNet([2, 3, 1])
+
+    np.random.seed(0)
+    m = M()
+    m.a = np.array([0.5, 1.0, 2.0])
+    m.initialize()
+    assert np.allclose(m.a.value, [0.5, 1.0, 2.0], atol=1e-5)
+    w0 = m.sub.matbias0.w.value.copy()
+    path = str(tmp_path / "ckpt")
+    m.save(path)
+    sub_path = str(tmp_path / "sub")
+    m.sub.save(sub_path)
+    m.a = np.array([3.0, 3.0, 3.0])
+    m.sub.matbias0.w = np.zeros((2, 3))
+    m.initialize()
+    assert np.allclose(m.a.value, 3.0, atol=1e-5)
+    m.sub.restore(sub_path)
+    assert np.allclose(m.sub.matbias0.w.value, w0, atol=1e-6)
+    assert np.allclose(m.a.value, 3.0, atol=1e-5)  # sub-tree restore leaves the rest alone
+    m.a = np.array([9.0, 9.0, 9.0])  # pending assignment must not override the restore
+    m.restore(path)
+    m.initialize()
+    assert np.allclose(m.a.value, [0.5, 1.0, 2.0], atol=1e-5)
+
+
+def test_cholesky_failure_is_reported():
+    class Bad(hb.model.Model):
+        def setUp(self):
+            self.A = hb.param.Data(np.array([[1.0, 2.0], [2.0, 1.0]]))
+
+        @hb.model.AutoOptimize()
+        def obj(self):
+            return tf.reduce_sum(tf.cholesky(self.A))
+
+    with pytest.raises(hb.CholeskyError):
+        Bad().obj().run()
+
+
+def test_rng_noise_statistics_and_minibatch_indices():
+    np.random.seed(0)
+    X, Y, Z = svgp_data(2000, 32, 0)
+    m = SVGP(X=X, Y=Y, Z=Z, dtype="float64")
+    opt = m.ELBO()
+    opt.compile()
+    vals = [opt.run(minibatch_size=256) for _ in range(30)]
+    assert np.std(vals) > 0  # fresh noise + fresh minibatch every run
+    # the index plan honours the 10 % hold-out (reference model.py:132,140-149)
+    assert m._index.train_size == 1800 and m._index.test_size == 200
+    plan = opt.last_plan
+    idx = plan.index_buffer.cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < 1800
