@@ -252,6 +252,46 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   return 0;
 }
 
+// A = W K(z,x) alone (posterior-prediction callers need A without a draw; also
+// lets bench.py time the contraction kernel in isolation).
+template <typename T>
+static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, T* A, long E,
+                      long n, long M, long d, hipStream_t stream) {
+  HB_REQUIRE(kind == HB_KERN_RBF, "hb_sgp_A: only the UnitRBF kernel is fused (kind=%d)", kind);
+  HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1, "hb_sgp_A: bad extents");
+  HB_REQUIRE(dl == 1 || dl == d, "hb_sgp_A: lengthscales must have 1 or d entries");
+  HB_REQUIRE(x && z && ell && W && A, "hb_sgp_A: NULL pointer");
+  HB_REQUIRE(E <= 65535, "hb_sgp_A: too many experts");
+  HB_REQUIRE(M * n < 2147483647L && M * M < 2147483647L && n * d < 2147483647L, "hb_sgp_A: matrix too large");
+  if (E * n * M == 0) return 0;
+  SgpArgs<T> a;
+  a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = nullptr; a.A = A;
+  a.n = n; a.M = M; a.d = d; a.P = 0;
+  const int nRB = hb_cdiv(M, SGP_BM);
+  dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
+  const bool fast = d <= SGP_DREG && M * d <= SGP_ZS_MAX;
+  if (fast && d == 1)
+    hipLaunchKernelGGL((sgp_A_kernel<T, 1>), grid, dim3(256), 0, stream, a);
+  else if (fast && d == 2)
+    hipLaunchKernelGGL((sgp_A_kernel<T, 2>), grid, dim3(256), 0, stream, a);
+  else if (fast && d == 3)
+    hipLaunchKernelGGL((sgp_A_kernel<T, 3>), grid, dim3(256), 0, stream, a);
+  else if (fast && d == 4)
+    hipLaunchKernelGGL((sgp_A_kernel<T, 4>), grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((sgp_A_kernel<T, 0>), grid, dim3(256), 0, stream, a);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
+                            const float* W, float* A, long E, long n, long M, long d, void* stream) {
+  return sgp_A_only<float>(kind, x, sx, z, ell, dl, W, A, E, n, M, d, (hipStream_t)stream);
+}
+extern "C" int hb_sgp_A_f64(int kind, const double* x, long sx, const double* z, const double* ell, long dl,
+                            const double* W, double* A, long E, long n, long M, long d, void* stream) {
+  return sgp_A_only<double>(kind, x, sx, z, ell, dl, W, A, E, n, M, d, (hipStream_t)stream);
+}
+
 extern "C" int hb_sgp_fwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell, long dl,
                               const float* W, const float* u, const float* eps_in, uint64_t* rng, long rng_lanes,
                               float* eps_out, float* A, float* f, float* v, long E, long n, long M, long d, long P,

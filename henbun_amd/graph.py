@@ -1230,6 +1230,7 @@ class Plan:
         self._graph = None
         self.stream = stream          # torch.cuda.Stream the plan runs on (None = current)
         self.side_effect_steps = set()  # steps skipped by the capture warm-up (e.g. the Adam update)
+        self.step_labels = {}           # id(step closure) -> op label (profiling)
         self.noise_inputs: Dict[Tensor, object] = {}
         self._injected: Dict[Tensor, bool] = {}
         self._leaf_resolver = leaf_resolver
@@ -1328,7 +1329,11 @@ class Plan:
         d = OPS.get(n.op)
         if d is None or d.emit is None:
             raise NotImplementedError("op %s cannot be lowered" % n.op)
+        before = len(self.steps)
         d.emit(self, n)
+        label = n.op if n.op != "ew" else "ew:" + n.attrs["f"]
+        for s in self.steps[before:]:
+            self.step_labels[id(s)] = label
 
     def inject_noise(self, t: Tensor, value):
         """Overwrite a random_normal leaf with a fixed draw (parity runs)."""
@@ -1372,6 +1377,30 @@ class Plan:
                 g.end()
         self._graph = g
         return True
+
+    def profile(self, iters=20):
+        """Per-op device time (us) from an eager, event-bracketed replay of the
+        plan: {label: (avg_us_per_run, launches_per_run)}.  Diagnostic; the
+        captured graph is what run() replays."""
+        torch = self.torch
+        acc, cnt = {}, {}
+        with self._on_stream():
+            st = torch.cuda.current_stream()
+            for it in range(iters + 2):
+                evs = []
+                for s in self.steps:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    s()
+                    e1.record(st)
+                    evs.append((self.step_labels.get(id(s), "other"), e0, e1))
+                st.synchronize()
+                if it < 2:
+                    continue
+                for lab, e0, e1 in evs:
+                    acc[lab] = acc.get(lab, 0.0) + e0.elapsed_time(e1) * 1e3
+                    cnt[lab] = cnt.get(lab, 0) + 1
+        return {k: (acc[k] / iters, cnt[k] // iters) for k in acc}
 
     def check(self):
         """Synchronise and raise if any Cholesky in the plan failed."""

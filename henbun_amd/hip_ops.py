@@ -407,6 +407,19 @@ def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None)
     return f, A, v, eps
 
 
+def sgp_A(x, z, ell, W, out=None):
+    """A = W K(z,x): the M^2 n contraction alone (hb_sgp_A)."""
+    E = z.shape[0] if z.dim() == 3 else 1
+    M, d = z.shape[-2], z.shape[-1]
+    n = x.shape[-2]
+    sx = n * d if (x.dim() == 3 and x.shape[0] == E and E > 1) else 0
+    if out is None:
+        out = torch.empty(((E,) if z.dim() == 3 else ()) + (M, n), dtype=x.dtype, device=x.device)
+    _lib.lib().call("hb_sgp_A" + _suf(x), KERN_RBF, _p(x), sx, _p(z), _p(ell), ell.numel() // E, _p(W), _p(out), E, n,
+                    M, d, stream())
+    return out
+
+
 def sgp_bwd(x, z, ell, W, u, eps, A, v, fbar, mode=SGP_DIAGONAL, need_xbar=False, out=None):
     """Returns (Lbar, ubar, zbar, ellbar, xbar|None)."""
     E, n, M, d, P, sx = _sgp_dims(x, z, u)

@@ -24,6 +24,7 @@ import numpy as np
 from . import graph as G
 from ._settings import settings
 from .param import Data, MinibatchData, Parameterized, Variable, graph_key
+from . import parallel
 from .session import Indexer, Session
 
 
@@ -230,7 +231,7 @@ class Optimizer:
             slots = opt.slots(sess)
             H = sess.H
             theta = sess.theta
-            gscale = 1.0 / sess.world_size if (sess.world_size > 1 and self.dp_reduce == "mean") else 1.0
+            gscale = parallel.gradient_scale(sess.world_size, self.dp_reduce)
 
             def adam():
                 # one fused launch per contiguous segment; the shared step counter ticks once
@@ -289,13 +290,10 @@ class Optimizer:
             for _ in range(int(maxiter)):
                 plan.run()
         else:
-            import torch.distributed as dist
-
             for _ in range(int(maxiter)):
                 plan.run()
                 with plan._on_stream():
-                    for o, s in plan.segments:
-                        dist.all_reduce(plan.gflat[o:o + s])
+                    parallel.allreduce_gradient(plan.gflat, plan.segments)
                     plan.adam()
         plan.check()
         self.last_plan = plan

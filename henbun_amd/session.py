@@ -84,20 +84,20 @@ class Session:
             self.rank, self.world_size = torch.distributed.get_rank(), torch.distributed.get_world_size()
         # RNG streams: 'global' identical on every rank (global variational noise must agree),
         # 'local' / 'index' rank-distinct (per-datapoint noise, minibatch indices).
-        self.rngs = {
-            "global": hip_ops.Rng(self.seed, stream_id=0, device=self.device),
-            "local": hip_ops.Rng(self.seed, stream_id=1 + 2 * self.rank, device=self.device),
-            "index": hip_ops.Rng(self.seed, stream_id=2 + 2 * self.rank, device=self.device),
-        }
+        from . import parallel
+
+        ids = parallel.rng_stream_ids(self.rank)
+        self.rngs = {k: hip_ops.Rng(self.seed, stream_id=v, device=self.device) for k, v in ids.items()}
         self.stream = torch.cuda.Stream(device=self.device)
         self._ready = True
 
     def reseed(self, seed):
         self.seed = int(seed)
         if self._ready:
-            self.rngs["global"].reseed(self.seed, 0)
-            self.rngs["local"].reseed(self.seed, 1 + 2 * self.rank)
-            self.rngs["index"].reseed(self.seed, 2 + 2 * self.rank)
+            from . import parallel
+
+            for k, v in parallel.rng_stream_ids(self.rank).items():
+                self.rngs[k].reseed(self.seed, v)
 
     # ------------------------------------------------------------------ flat parameter store
     def invalidate(self):

@@ -233,6 +233,11 @@ int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, const double* z
                    long dl, const double* W, const double* u, const double* eps_in, uint64_t* rng,
                    long rng_lanes, double* eps_out, double* A, double* f, double* v, long E, long n,
                    long M, long d, long P, double* ws, void* stream);
+/* The contraction alone, A = W k(z,x) (posterior-prediction callers; isolated timing). */
+int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
+                 const float* W, float* A, long E, long n, long M, long d, void* stream);
+int hb_sgp_A_f64(int kind, const double* x, long sx, const double* z, const double* ell, long dl,
+                 const double* W, double* A, long E, long n, long M, long d, void* stream);
 /* VJP given fbar [E,P,n]:
  *   Abar = u^T fbar + A diag(c),  c = -eps sign(v)/sqrt|v| * sum_p fbar_p
  *   Kbar = W^T Abar            [E,M,n]  (scratch output, kept for Lbar)

@@ -1,0 +1,267 @@
+"""Host logic that needs no GPU: the C-ABI library loads and exports every
+declared symbol, the parameter tree / tf_mode / feed semantics mirror the
+reference, settings push/pop, Indexer, data-parallel helpers (gloo, 2 ranks)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import henbun_amd as hb
+from henbun_amd import graph as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tf = hb.tf
+
+
+# ---------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    from henbun_amd import _lib
+
+    lib = _lib.lib()  # loads without a GPU; raises if the .so is missing
+    assert lib.raw("hb_version")() == 1
+    header = open(os.path.join(ROOT, "include", "henbun_hip.h")).read()
+    declared = set(re.findall(r"\b(hb_[A-Za-z0-9_]+)\s*\(", header))
+    bound = set(_lib.declared_symbols())
+    assert declared == bound, (declared - bound, bound - declared)
+    import ctypes
+
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(dll, name), name
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    """Argument validation happens before any launch, so it is testable without a GPU."""
+    from henbun_amd import _lib
+
+    lib = _lib.lib()
+    rc = lib.raw("hb_reduce_f32")(0, None, None, -1, 1, 1, None, 0, None)
+    assert rc < 0 and "negative" in lib.last_error()
+    rc = lib.raw("hb_gram_fwd_f64")(7, None, 0, None, 0, None, 1, None, 1, 1, 1, 1, None)
+    assert rc < 0 and "kind" in lib.last_error()
+    with pytest.raises(_lib.HipBackendError):
+        lib.call("hb_rng_randint", None, 0, None, 1, 0, 0, None)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+
+    class M(hb.model.Model):
+        def setUp(self):
+            self.p = hb.param.Variable([2])
+
+        @hb.model.AutoOptimize()
+        def f(self):
+            return -tf.reduce_sum(tf.square(self.p))
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        M().f().run()
+
+
+# ---------------------------------------------------------------- parameter tree (reference testing/test_param.py)
+def test_naming_and_tree():
+    m = hb.model.Model()
+    m.p = hb.param.Variable([2, 3])
+    m.sub = hb.param.Parameterized()
+    m.sub.q = hb.param.Variable([1])
+    assert m.p.name == "p" and m.p.long_name == "model.p"
+    assert m.sub.q.long_name == "model.sub.q"
+    assert m.sub.q.highest_parent is m
+    assert [v.long_name for v in m.get_variables()] == ["model.p", "model.sub.q"]
+    orphan = hb.param.Variable([1])
+    assert orphan.name == "unnamed"
+    m.lst = hb.param.ParamList([hb.param.Variable([1]), hb.param.Variable([2])])
+    assert m.lst[1].name == "item1" and m.lst[1].long_name == "model.lst.item1"
+    with pytest.raises(TypeError):
+        m.lst[0] = "x"
+
+
+def test_truncated_normal_bounds_and_assign():
+    # reference testing/test_param.py:286-296: initial values within two standard deviations
+    np.random.seed(0)
+    v = hb.param.Variable([1000], mean=1.0, stddev=0.5)
+    assert np.all(np.abs(v._host_raw - 1.0) <= 1.0 + 1e-12)
+    m = hb.model.Model()
+    m.a = hb.param.Variable([3], transform=hb.transforms.positive)
+    m.a = np.array([0.5, 1.0, 2.0])
+    assert m.a._assigned
+    assert np.allclose(hb.transforms.positive.forward(m.a._host_raw), [0.5, 1.0, 2.0])
+    m.a = 3.0  # scalar assignment broadcasts (reference param.py:397-402)
+    assert np.allclose(hb.transforms.positive.forward(m.a._host_raw), 3.0)
+
+
+def test_tf_mode_returns_tensors_and_feed_order():
+    # reference testing/test_param.py:117-149, test_variationals.py:205-222
+    m = hb.model.Model()
+    m.v = hb.variationals.Normal([3], collections=hb.param.graph_key.LOCAL)
+    m.w = hb.variationals.Normal([2], q_shape="fullrank", n_layers=[4], collections=hb.param.graph_key.LOCAL)
+    m.g = hb.param.Variable([2])
+    assert m.v.feed_size == 6 and m.w.feed_size == 2 + 4
+    assert isinstance(m.g, hb.param.Variable)
+    x = G.leaf("data", (7, 6), var=None)
+    xw = G.leaf("data", (4, 7, 6), var=None)
+    with m.tf_mode():
+        assert isinstance(m.g, G.Tensor)
+        m.v = x
+        m.w = xw
+        tv, tw = m.v, m.w
+        assert isinstance(m.get_variables()[0], hb.param.Variable)  # works in tf_mode too
+    assert tv.shape == (7, 3) and tw.shape == (4, 7, 2)
+    # q_mu takes the first `size` columns, q_sqrt the rest
+    mu_t = m.v.q_mu._tensor
+    assert mu_t.node.inputs[0].node.attrs["offset"] == 0 if mu_t.node.op == "reshape" else True
+    sq = m.v.q_sqrt._tensor
+    src = sq if sq.node.op == "strided" else sq.node.inputs[0]
+    assert src.node.attrs["offset"] == 3 and src.shape == (7, 3)
+    assert m.w.q_sqrt._tensor.shape == (4, 7, 2, 2)
+    # an unfed LOCAL variational is an error (reference model.py:103-105)
+    m2 = hb.model.Model()
+    m2.z = hb.variationals.Normal([2], collections=hb.param.graph_key.LOCAL)
+    with pytest.raises(ValueError, match="not fed"):
+        with m2.tf_mode():
+            m2.z
+
+
+def test_kl_tree_and_collections():
+    m = hb.model.Model()
+    assert isinstance(m.KL(), np.ndarray) and m.KL() == 0  # no variational: numpy zero (param.py:557-558)
+    m.a = hb.variationals.Normal([3])
+    m.b = hb.variationals.Gaussian([2], collections=["other"])
+    with m.tf_mode():
+        kl_all = m.KL()
+        kl_other = m.KL("other")
+    assert isinstance(kl_all, G.Tensor) and kl_all.size == 1
+    assert isinstance(kl_other, G.Tensor)
+    ops = {n.op for n in G.topo_order([kl_other])}
+    assert "diag_sample_kl" in ops
+    assert len([n for n in G.topo_order([kl_other]) if n.op == "diag_sample_kl"]) == 1
+    assert len([n for n in G.topo_order([kl_all]) if n.op == "diag_sample_kl"]) == 2
+
+
+def test_data_and_minibatch_data():
+    # reference testing/test_data.py
+    d = hb.param.Data(np.ones((3, 2)))
+    assert np.all(d.value == 1)
+    with pytest.raises(ValueError):
+        d.assign(np.ones((4, 2)))
+    with pytest.raises(NotImplementedError):
+        hb.param.Data(np.array(["a"]))
+    mb = hb.param.MinibatchData(np.arange(20).reshape(10, 2))
+    assert mb.data_size == 10 and mb.shape == [2]
+    fd = mb.get_feed_dict(np.array([1, 3]))
+    assert np.array_equal(list(fd.values())[0], [[2, 3], [6, 7]])
+    assert mb.get_feed_dict(None) == {}
+
+    class M(hb.model.Model):
+        def setUp(self):
+            self.a = hb.param.MinibatchData(np.zeros((10, 1)))
+            self.b = hb.param.MinibatchData(np.zeros((11, 1)))
+
+    with pytest.raises(ValueError, match="not the same size"):
+        M().validate()
+
+
+def test_settings_push_pop_and_clip():
+    # reference testing/test_tf_wraps.py:10-42
+    assert hb.settings.numerics.jitter_level == 1e-5 and hb.settings.numerics.clip_by_value is False
+    x = G.leaf("data", (3,), var=None)
+    assert hb.tf_wraps.clip(x) is x
+    cfg = hb.settings.get_settings()
+    cfg.numerics.clip_by_value = True
+    cfg.numerics.jitter_level = 3e-4
+    with hb.settings.temp_settings(cfg):
+        assert hb.settings.numerics.jitter_level == 3e-4
+        c = hb.tf_wraps.clip(x)
+        assert c.node.attrs["f"] == "CLIP" and c.node.attrs["p"][:2] == (-50.0, 50.0)
+    assert hb.settings.numerics.jitter_level == 1e-5
+
+
+def test_indexer_and_autooptimize_cache():
+    np.random.seed(0)
+    idx = hb.session.Indexer()
+    idx.setUp(100)
+    assert idx.train_size == 90 and idx.test_size == 10
+    assert set(idx.train_index(500)).isdisjoint(set(idx.test_index(50)))
+
+    class M(hb.model.Model):
+        def setUp(self, k=1):
+            self.k = k
+            self.p = hb.param.Variable([2])
+
+        @hb.model.AutoOptimize()
+        def f(self):
+            return -tf.reduce_sum(tf.square(self.p))
+
+    m = M(k=3)  # setUp(**kw) (reference testing/test_model.py:137-146)
+    assert m.k == 3
+    assert m.f() is m.f()
+    assert hasattr(m, "_f_AF_optimizer")
+
+
+def test_transforms_roundtrip_and_log_jacobian():
+    # reference testing/test_transforms.py:39-75 (numerical Jacobian instead of TF's)
+    import graph_oracle as GO
+
+    x = np.random.RandomState(0).randn(6)
+    for t in (hb.transforms.Identity(), hb.transforms.Exp(), hb.transforms.Log1pe(), hb.transforms.Logistic(7.3, 19.4)):
+        y = t.forward(x)
+        assert np.allclose(t.backward(y), x, atol=1e-4)
+        leaf = G.leaf("data", x.shape, var=None)
+        fw, lj = t.tf_forward(leaf), t.tf_log_jacobian(leaf)
+        vals = GO.evaluate([fw, lj], {leaf: x})
+        assert np.allclose(vals[fw].numpy(), y, atol=1e-10)
+        h = 1e-6
+        num = np.sum(np.log((t.forward(x + h) - t.forward(x - h)) / (2 * h)))
+        assert np.isclose(vals[lj].numpy().sum(), num, atol=1e-5)
+
+
+# ---------------------------------------------------------------- data parallel (gloo, world_size 2)
+_DP_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from henbun_amd import parallel
+dist.init_process_group("gloo")
+rank, world = parallel.world()
+assert world == 2
+ids = parallel.rng_stream_ids(rank)
+gathered = [None, None]
+dist.all_gather_object(gathered, ids)
+assert gathered[0]["global"] == gathered[1]["global"] == 0
+assert gathered[0]["local"] != gathered[1]["local"] and gathered[0]["index"] != gathered[1]["index"]
+assert len({v for g in gathered for k, v in g.items() if k != "global"}) == 4
+spans = [parallel.shard_rows(1001, r, world) for r in range(world)]
+assert spans[0][0] == 0 and spans[-1][1] == 1001 and spans[0][1] == spans[1][0]
+# flat-gradient exchange: segments summed in place, mean folded into the Adam scale
+g = torch.arange(10, dtype=torch.float64) * (rank + 1)
+parallel.allreduce_gradient(g, [(0, 4), (6, 4)])
+exp = torch.arange(10, dtype=torch.float64) * 3
+exp[4:6] = torch.arange(4, 6, dtype=torch.float64) * (rank + 1)   # outside the segments: untouched
+assert torch.equal(g, exp), (rank, g)
+assert parallel.gradient_scale(world, "mean") == 0.5 and parallel.gradient_scale(world, "sum") == 1.0
+# a mean-reduced step equals the single-process step on the pooled gradient
+theta = torch.ones(10, dtype=torch.float64)
+theta -= 0.1 * parallel.gradient_scale(world, "mean") * g
+ref = torch.ones(10, dtype=torch.float64) - 0.1 * 0.5 * exp
+assert torch.allclose(theta, ref)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_data_parallel_helpers_gloo_two_ranks(tmp_path):
+    script = tmp_path / "dp.py"
+    script.write_text(_DP_SCRIPT % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
