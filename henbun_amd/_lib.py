@@ -40,6 +40,7 @@ _RESTYPES = {"hb_last_error_string": c_char_p, "hb_sgp_ws_elems": c_long}
 # entry points that exist as _f32 and _f64
 _TYPED = {
     "hb_ewise": [I, I, P, P, I, P, I, P, P, P],
+    "hb_ewise_prog": [I, P, P, I, P, P, I, P, P, P, I, P, P],
     "hb_reduce": [I, P, P, L, L, L, P, L, P],
     "hb_copy_nd": [P, P, P, P, I, P, P],
     "hb_fill": [P, L, D, P],

@@ -191,6 +191,145 @@ extern "C" int hb_ewise_f64(int op, int nin, const void* const* in, const long* 
 }
 
 // ---------------------------------------------------------------------------
+// fused elementwise program: a whole cluster of elementwise graph nodes (same
+// broadcast iteration space) evaluated by ONE launch.  Each thread interprets a
+// short register program for its element; inputs are read with broadcast
+// strides, outputs whose shape is smaller than the iteration space are written
+// only by the threads whose index along the broadcast dims is 0.
+// On the ELBO path these chains act on scalars or [1,n] rows and are purely
+// launch-bound (~4.5 us per launch in a hipGraph), so collapsing ~30 launches
+// into a handful matters more than per-element speed.
+// ---------------------------------------------------------------------------
+#define HB_PROG_MAX_INSTR 48
+#define HB_PROG_MAX_IN 8
+#define HB_PROG_MAX_OUT 6
+#define HB_PROG_MAX_DIMS 4
+#define HB_PROG_MAX_REGS 64
+
+struct ProgArgs {
+  int ninstr, nin, nout, ndim;
+  long n;
+  int shape[HB_PROG_MAX_DIMS];
+  long istr[HB_PROG_MAX_IN][HB_PROG_MAX_DIMS];
+  long ostr[HB_PROG_MAX_OUT][HB_PROG_MAX_DIMS];
+  const void* in[HB_PROG_MAX_IN];
+  void* out[HB_PROG_MAX_OUT];
+  int out_reg[HB_PROG_MAX_OUT];
+  short code[HB_PROG_MAX_INSTR][5];  // op, dst, a, b, c
+  double params[HB_PROG_MAX_INSTR][2];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) ew_prog_kernel(ProgArgs A) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += stride) {
+    int idx[HB_PROG_MAX_DIMS] = {0, 0, 0, 0};
+    long r = i;
+#pragma unroll
+    for (int d = HB_PROG_MAX_DIMS - 1; d >= 0; --d) {
+      if (d < A.ndim) {
+        const long q = r / A.shape[d];
+        idx[d] = (int)(r - q * A.shape[d]);
+        r = q;
+      }
+    }
+    T reg[HB_PROG_MAX_REGS];
+    for (int k = 0; k < A.nin; ++k) {
+      long off = 0;
+#pragma unroll
+      for (int d = 0; d < HB_PROG_MAX_DIMS; ++d) off += (long)idx[d] * A.istr[k][d];
+      reg[k] = ((const T*)A.in[k])[off];
+    }
+    for (int q = 0; q < A.ninstr; ++q) {
+      const int op = A.code[q][0], dst = A.code[q][1];
+      const T a = reg[A.code[q][2]], b = reg[A.code[q][3]], c = reg[A.code[q][4]];
+      // the 4-input op carries its 4th operand's register number in params[q][0]
+      const T d = (op == HB_EW_GAUSS_LOGPDF_GRAD) ? reg[(int)A.params[q][0]] : T(0);
+      T o0 = T(0), o1 = T(0), o2 = T(0);
+      ew_apply<T>(op, a, b, c, d, A.params[q], o0, o1, o2);
+      reg[dst] = o0;
+      if (op == HB_EW_GAUSS_LOGPDF_GRAD) {
+        reg[dst + 1] = o1;
+        reg[dst + 2] = o2;
+      }
+    }
+    for (int k = 0; k < A.nout; ++k) {
+      long off = 0;
+      bool write = true;
+#pragma unroll
+      for (int d = 0; d < HB_PROG_MAX_DIMS; ++d) {
+        if (d < A.ndim) {
+          if (A.ostr[k][d] == 0 && A.shape[d] > 1 && idx[d] != 0) write = false;  // broadcast dim: index 0 writes
+          off += (long)idx[d] * A.ostr[k][d];
+        }
+      }
+      if (write) ((T*)A.out[k])[off] = reg[A.out_reg[k]];
+    }
+  }
+}
+
+template <typename T>
+static int ew_prog_launch(int ninstr, const int* code, const double* params, int nin, const void* const* in,
+                          const long* istrides, int nout, void* const* out, const int* out_regs, const long* ostrides,
+                          int ndim, const long* shape, hipStream_t stream) {
+  HB_REQUIRE(ninstr >= 1 && ninstr <= HB_PROG_MAX_INSTR, "hb_ewise_prog: %d instructions (max %d)", ninstr,
+             HB_PROG_MAX_INSTR);
+  HB_REQUIRE(nin >= 0 && nin <= HB_PROG_MAX_IN && nout >= 1 && nout <= HB_PROG_MAX_OUT, "hb_ewise_prog: bad nin/nout");
+  HB_REQUIRE(ndim >= 0 && ndim <= HB_PROG_MAX_DIMS, "hb_ewise_prog: ndim=%d out of range", ndim);
+  ProgArgs A;
+  A.ninstr = ninstr; A.nin = nin; A.nout = nout; A.ndim = ndim;
+  long n = 1;
+  for (int d = 0; d < HB_PROG_MAX_DIMS; ++d) {
+    A.shape[d] = d < ndim ? (int)shape[d] : 1;
+    if (d < ndim) {
+      HB_REQUIRE(shape[d] >= 0, "hb_ewise_prog: negative dim");
+      n *= shape[d];
+    }
+  }
+  if (n == 0) return 0;
+  A.n = n;
+  for (int k = 0; k < HB_PROG_MAX_IN; ++k) {
+    A.in[k] = k < nin ? in[k] : nullptr;
+    for (int d = 0; d < HB_PROG_MAX_DIMS; ++d) A.istr[k][d] = (k < nin && d < ndim) ? istrides[k * ndim + d] : 0;
+  }
+  for (int k = 0; k < HB_PROG_MAX_OUT; ++k) {
+    A.out[k] = k < nout ? out[k] : nullptr;
+    A.out_reg[k] = k < nout ? out_regs[k] : 0;
+    for (int d = 0; d < HB_PROG_MAX_DIMS; ++d) A.ostr[k][d] = (k < nout && d < ndim) ? ostrides[k * ndim + d] : 0;
+  }
+  int maxreg = nin;
+  for (int q = 0; q < ninstr; ++q) {
+    for (int f = 0; f < 5; ++f) A.code[q][f] = (short)code[q * 5 + f];
+    A.params[q][0] = params[q * 2];
+    A.params[q][1] = params[q * 2 + 1];
+    const int extra = code[q * 5] == HB_EW_GAUSS_LOGPDF_GRAD ? 2 : 0;
+    HB_REQUIRE(code[q * 5 + 1] >= 0 && code[q * 5 + 1] + extra < HB_PROG_MAX_REGS, "hb_ewise_prog: register out of range");
+    for (int f = 2; f < 5; ++f)
+      HB_REQUIRE(code[q * 5 + f] >= 0 && code[q * 5 + f] < HB_PROG_MAX_REGS, "hb_ewise_prog: operand register out of range");
+    if (extra) HB_REQUIRE(params[q * 2] >= 0 && params[q * 2] < HB_PROG_MAX_REGS, "hb_ewise_prog: 4th operand register out of range");
+    if (code[q * 5 + 1] + extra + 1 > maxreg) maxreg = code[q * 5 + 1] + extra + 1;
+  }
+  for (int k = 0; k < nout; ++k)
+    HB_REQUIRE(out_regs[k] >= 0 && out_regs[k] < maxreg, "hb_ewise_prog: output register never written");
+  hipLaunchKernelGGL(ew_prog_kernel<T>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, A);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hb_ewise_prog_f32(int ninstr, const int* code, const double* params, int nin, const void* const* in,
+                                 const long* istrides, int nout, void* const* out, const int* out_regs,
+                                 const long* ostrides, int ndim, const long* shape, void* stream) {
+  return ew_prog_launch<float>(ninstr, code, params, nin, in, istrides, nout, out, out_regs, ostrides, ndim, shape,
+                               (hipStream_t)stream);
+}
+extern "C" int hb_ewise_prog_f64(int ninstr, const int* code, const double* params, int nin, const void* const* in,
+                                 const long* istrides, int nout, void* const* out, const int* out_regs,
+                                 const long* ostrides, int ndim, const long* shape, void* stream) {
+  return ew_prog_launch<double>(ninstr, code, params, nin, in, istrides, nout, out, out_regs, ostrides, ndim, shape,
+                                (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
 // reductions over the middle axis of a contiguous [K1, R, K2] view
 // ---------------------------------------------------------------------------
 template <typename T, int OP>

@@ -28,6 +28,9 @@
 #pragma once
 #include "common.cuh"
 
+#define HB_KC 0  // operand source contiguous along k
+#define HB_MC 1  // operand source contiguous along m (A) / n (B)
+
 template <typename T, int BM_, int BN_, int BK_, int WM_, int WN_>
 struct TileGemm {
   typedef Mma<T> MM;
@@ -167,6 +170,129 @@ struct TileGemm {
       }
       // LDS writes of `nxt` visible + everyone done reading `cur`; global
       // loads stay in flight across the barrier (no vmcnt wait).
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+      __builtin_amdgcn_s_barrier();
+      cur ^= 1;
+    }
+  }
+
+  // ---------------------------------------------------------------------------
+  // Vectorised operand path.  Same pipeline as run(), but every thread moves
+  // 16-byte groups (VEC = 4 floats / 2 doubles): one global load, one address
+  // computation and one mask per group instead of per element -- on gfx950 the
+  // fp32 MFMA shares the vector ALU, so every VALU instruction saved in the
+  // loaders is MFMA issue time won back (profiles/r01_ablate_sgpA_loop.txt).
+  //
+  // Operand modes:
+  //   HB_KC  source is k-contiguous (row-major A(m,:) / B^T(n,:)): the group is
+  //          VEC consecutive k of one row/column; stashed transposed as VEC
+  //          ds_write_b32 into the k-major LDS tile.
+  //   HB_MC  source is contiguous along m (or n): the group is VEC consecutive
+  //          rows/columns of one k; stashed with ONE ds_write_b128.
+  // Functors (VT = ext_vector(VEC)):
+  //   la(m, k) -> RawA (any POD; usually VT)   fa(RawA, m, k) -> VT
+  //   lb(k, n) -> RawB                         fb(RawB, k, n) -> VT
+  // with (m,k) / (k,n) the group's FIRST element.  Requirements (checked by the
+  // host launchers, which fall back to run() otherwise): (kend - kbeg) % BK == 0,
+  // 16-byte aligned group addresses.
+  // ---------------------------------------------------------------------------
+  static constexpr int VEC = 16 / sizeof(T);
+  typedef T VT __attribute__((ext_vector_type(VEC)));
+  static constexpr int GA = (BM * BK / VEC) / NT, GB = (BN * BK / VEC) / NT;
+  static constexpr int NG = GA + GB;
+
+  template <int AMODE, int BMODE, class LA, class FA, class LB, class FB>
+  __device__ __forceinline__ void run_vec(int kbeg, int kend, LA la, FA fa, LB lb, FB fb, T* __restrict__ lds) {
+    static_assert((BM * BK / VEC) % NT == 0 && (BN * BK / VEC) % NT == 0, "vector fill must divide evenly");
+    static_assert(BM % VEC == 0 && BN % VEC == 0 && BK % VEC == 0 && LDA % VEC == 0 && LDB % VEC == 0, "alignment");
+    if (kbeg >= kend) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int wm = w / WN, wn = w % WN;
+    const int am = wm * WTM + (lane % MM::TM), ak = lane / MM::TM;
+    const int bn = wn * WTN + (lane % MM::TN), bk = lane / MM::TN;
+    typedef decltype(la(0, 0)) RawA;
+    typedef decltype(lb(0, 0)) RawB;
+    RawA ra[GA];
+    RawB rb[GB];
+
+    // group g of this thread -> first (m, kk) / (kk, n) inside the tile
+    auto a_m = [&](int g) { const int i = g * NT + tid; return AMODE == HB_KC ? i / (BK / VEC) : (i % (BM / VEC)) * VEC; };
+    auto a_kk = [&](int g) { const int i = g * NT + tid; return AMODE == HB_KC ? (i % (BK / VEC)) * VEC : i / (BM / VEC); };
+    auto b_n = [&](int g) { const int i = g * NT + tid; return BMODE == HB_KC ? i / (BK / VEC) : (i % (BN / VEC)) * VEC; };
+    auto b_kk = [&](int g) { const int i = g * NT + tid; return BMODE == HB_KC ? (i % (BK / VEC)) * VEC : i / (BN / VEC); };
+
+    auto fetch_one = [&](int g, int k0) {
+      // past the end the tile is never consumed: re-read the last tile instead of running off the operand
+      const int kc = k0 < kend ? k0 : kend - BK;
+      if (g < GA) {
+        ra[g < GA ? g : 0] = la(a_m(g), kc + a_kk(g));
+      } else {
+        const int gb = g - GA;
+        rb[gb >= 0 ? gb : 0] = lb(kc + b_kk(gb), b_n(gb));
+      }
+    };
+    auto stash_one = [&](int g, int k0, T* buf) {
+      const int kc = k0 < kend ? k0 : kend - BK;
+      if (g < GA) {
+        const int m = a_m(g), kk = a_kk(g);
+        const VT v = fa(ra[g < GA ? g : 0], m, kc + kk);
+        if (AMODE == HB_KC) {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) buf[(kk + q) * LDA + m] = v[q];
+        } else {
+          *reinterpret_cast<VT*>(&buf[kk * LDA + m]) = v;
+        }
+      } else {
+        const int gb = g - GA;
+        const int n = b_n(gb), kk = b_kk(gb);
+        const VT v = fb(rb[gb >= 0 ? gb : 0], kc + kk, n);
+        if (BMODE == HB_KC) {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) buf[BK * LDA + (kk + q) * LDB + n] = v[q];
+        } else {
+          *reinterpret_cast<VT*>(&buf[BK * LDA + kk * LDB + n]) = v;
+        }
+      }
+    };
+
+#pragma unroll
+    for (int g = 0; g < NG; ++g) fetch_one(g, kbeg);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) stash_one(g, kbeg, lds);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) fetch_one(g, kbeg + BK);
+    __syncthreads();
+
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      const T* __restrict__ As = lds + cur * BUF_ELEMS;
+      const T* __restrict__ Bs = As + BK * LDA;
+      T* __restrict__ nxt = lds + (cur ^ 1) * BUF_ELEMS;
+      T a[NS][RM], b[NS][RN];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int i = 0; i < RM; ++i) a[s][i] = As[(s * MM::TK + ak) * LDA + am + i * MM::TM];
+#pragma unroll
+        for (int j = 0; j < RN; ++j) b[s][j] = Bs[(s * MM::TK + bk) * LDB + bn + j * MM::TN];
+      }
+      // keep ALL fragment reads issued here: the compiler otherwise sinks each ds_read in front of
+      // its MFMA and pays the LDS latency once per MFMA group instead of once per k-step
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j) acc[i][j] = MM::mma(a[s][i], b[s][j], acc[i][j]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          if (g * NS / NG == s) {
+            stash_one(g, k0 + BK, nxt);
+            fetch_one(g, k0 + 2 * BK);
+          }
+      }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
       __builtin_amdgcn_s_barrier();
       cur ^= 1;

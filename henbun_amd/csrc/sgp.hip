@@ -59,8 +59,19 @@ struct SgpArgs {
 template <typename T> __device__ __forceinline__ T hb_exp_fast(T x);
 template <> __device__ __forceinline__ float hb_exp_fast<float>(float x) { return __expf(x); }
 template <> __device__ __forceinline__ double hb_exp_fast<double>(double x) { return exp(x); }
+// exp(-r2/2) = 2^(-(s*r)^2) with s = sqrt(log2(e)/2): coordinates staged pre-multiplied by s/ell make the
+// RBF value a single v_exp_f32 of the negated squared difference.
+#define SGP_EXP2_SCALE 0.84932180028801904272
+template <typename T> __device__ __forceinline__ T hb_exp2_neg(T x);
+template <> __device__ __forceinline__ float hb_exp2_neg<float>(float x) { return __builtin_amdgcn_exp2f(-x); }
+template <> __device__ __forceinline__ double hb_exp2_neg<double>(double x) { return exp2(-x); }
 
 template <typename T, int D>
+struct SgpZ {
+  T z[D];
+};
+
+template <typename T, int D, bool FAST>
 __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
   typedef TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2> G;
   __shared__ T lds[G::LDS_ELEMS + (D > 0 ? SGP_ZS_MAX : 1)];
@@ -83,9 +94,24 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
   T xs[D > 0 ? D : 1];
   if (D > 0) {
 #pragma unroll
-    for (int q = 0; q < D; ++q) xs[q] = x[jc * D + q] / ell[a.dl == 1 ? 0 : q];
-    for (int t = threadIdx.x; t < M * D; t += blockDim.x) zs[t] = z[t] / ell[a.dl == 1 ? 0 : (t % D)];
+    for (int q = 0; q < D; ++q) xs[q] = x[jc * D + q] * (T(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : q]);
+    for (int t = threadIdx.x; t < M * D; t += blockDim.x) zs[t] = z[t] * (T(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : (t % D)]);
     __syncthreads();
+  }
+
+  typedef typename TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2>::VT VT;
+  constexpr int VEC = TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2>::VEC;
+  // vector path: this thread's B-operand group is always the same VEC columns
+  T xv[VEC][D > 0 ? D : 1];
+  if (FAST) {
+    const int n4 = col0 + (threadIdx.x % (SGP_BN / VEC)) * VEC;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      const int cc = n4 + q < n ? n4 + q : n - 1;  // out-of-range columns compute garbage that is never stored
+#pragma unroll
+      for (int dd = 0; dd < (D > 0 ? D : 1); ++dd)
+        xv[q][dd] = x[cc * (D > 0 ? D : 1) + dd] * (T(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd]);
+    }
   }
 
   for (int half = 0; half < 2; ++half) {
@@ -119,10 +145,49 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
           r2 += t * t;
         }
       }
-      const T val = hb_exp_fast<T>(T(-0.5) * r2);
+      const T val = D > 0 ? hb_exp2_neg<T>(r2) : hb_exp_fast<T>(T(-0.5) * r2);
       return jok ? val : T(0);
     };
-    g.template run<true, false>(0, kend, la, fa, lb, fb, lds);
+    if constexpr (FAST) {
+      // vector path (D >= 1, M % 16 == 0): W rows by 16-byte loads with the triangular mask per
+      // component; the RBF block is synthesised 4 columns at a time (this thread's 4 columns are fixed)
+      auto la4 = [&](int m, int k) -> VT {
+        const int r = row0 + m;
+        return *reinterpret_cast<const VT*>(&W[(r < M ? r : Mm1) * M + k]);
+      };
+      auto fa4 = [&](VT raw, int m, int k) -> VT {
+        const int r = row0 + m;
+        VT v;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = ((r < M) & (k + q <= r)) ? raw[q] : T(0);
+        return v;
+      };
+      // the scaled inducing coordinate of row k is the B operand's "raw" value: read from LDS one
+      // iteration ahead, like a global load, so its latency is off the critical path
+      auto lb4 = [&](int k, int nn) -> SgpZ<T, (D > 0 ? D : 1)> {
+        SgpZ<T, (D > 0 ? D : 1)> r;
+#pragma unroll
+        for (int dd = 0; dd < (D > 0 ? D : 1); ++dd) r.z[dd] = zs[k * D + dd];
+        return r;
+      };
+      auto fb4 = [&](SgpZ<T, (D > 0 ? D : 1)> raw, int k, int nn) -> VT {
+        VT v;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          T r2 = T(0);
+#pragma unroll
+          for (int dd = 0; dd < (D > 0 ? D : 1); ++dd) {
+            const T t = raw.z[dd] - xv[q][dd];
+            r2 += t * t;
+          }
+          v[q] = hb_exp2_neg<T>(r2);
+        }
+        return v;
+      };
+      g.template run_vec<HB_KC, HB_MC>(0, kend, la4, fa4, lb4, fb4, lds);
+    } else {
+      g.template run<true, false>(0, kend, la, fa, lb, fb, lds);
+    }
     g.for_each([&](int row, int col, T v) {
       const int r = row0 + row, c = col0 + col;
       if (r < M && c < n) A[(long)r * n + c] = v;
@@ -130,13 +195,42 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
   }
 }
 
+// D dispatch: z staged in LDS when d <= SGP_DREG; vector operand path when, in
+// addition, M is a multiple of 16 and W is 16-byte aligned.
+template <typename T>
+static int sgp_A_launch(const SgpArgs<T>& a, dim3 grid, hipStream_t stream) {
+  const bool lds_z = a.d <= SGP_DREG && a.M * a.d <= SGP_ZS_MAX;
+  const bool vec = lds_z && a.M % 16 == 0 && ((uintptr_t)a.W % 16 == 0);
+#define HB_SGP_A(D_)                                                                          \
+  do {                                                                                        \
+    if (vec)                                                                                  \
+      hipLaunchKernelGGL((sgp_A_kernel<T, D_, true>), grid, dim3(256), 0, stream, a);         \
+    else                                                                                      \
+      hipLaunchKernelGGL((sgp_A_kernel<T, D_, false>), grid, dim3(256), 0, stream, a);        \
+  } while (0)
+  if (lds_z && a.d == 1)
+    HB_SGP_A(1);
+  else if (lds_z && a.d == 2)
+    HB_SGP_A(2);
+  else if (lds_z && a.d == 3)
+    HB_SGP_A(3);
+  else if (lds_z && a.d == 4)
+    HB_SGP_A(4);
+  else
+    hipLaunchKernelGGL((sgp_A_kernel<T, 0, false>), grid, dim3(256), 0, stream, a);
+#undef HB_SGP_A
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
 // per column j: mean_p = sum_m u_pm A_mj ; s = sum_m A_mj^2 ; v = 1 - s ;
-// f_p = mean_p + sqrt|v| eps_j.   Block = 32 columns x 8 row groups.
+// f_p = mean_p + sqrt|v| eps_j.   Block = 32 columns x 8 row groups; ONE pass over A
+// accumulates s and up to 4 latent-function means (P > 4: further passes for the rest).
 template <typename T>
 __global__ void __launch_bounds__(256) sgp_finish_kernel(const T* __restrict__ A, const T* __restrict__ u,
                                                          const T* __restrict__ eps, T* __restrict__ f,
                                                          T* __restrict__ v, long n, long M, long P, int mode) {
-  __shared__ T red[8][33];
+  __shared__ T red[5][8][33];
   const long e = blockIdx.y;
   A += e * M * n;
   u += e * P * M;
@@ -146,39 +240,40 @@ __global__ void __launch_bounds__(256) sgp_finish_kernel(const T* __restrict__ A
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const long j = (long)blockIdx.x * 32 + cx;
   const bool ok = j < n;
-  // s first, then one pass per latent function p
-  T acc = T(0);
-  if (ok)
-    for (long m = ry; m < M; m += 8) {
-      const T av = A[m * n + j];
-      acc += av * av;
-    }
-  red[ry][cx] = acc;
-  __syncthreads();
-  T sq = T(0);
-  if (ry == 0) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) sq += red[q][cx];
-  }
+  const long jc = ok ? j : n - 1;
   T scale = T(0);
-  if (ry == 0 && ok) {
-    const T vv = T(1) - sq;
-    v[j] = vv;
-    if (mode == HB_SGP_DIAGONAL) scale = hb_sqrt(hb_abs(vv)) * eps[j];
-  }
-  for (long p = 0; p < P; ++p) {
-    __syncthreads();
-    T macc = T(0);
-    if (ok)
-      for (long m = ry; m < M; m += 8) macc += u[p * M + m] * A[m * n + j];
-    red[ry][cx] = macc;
+  for (long p0 = 0; p0 < P || p0 == 0; p0 += 4) {
+    const int np = (int)((P - p0) < 4 ? (P - p0) : 4);
+    T sq = T(0), mac[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll 4
+    for (long m = ry; m < M; m += 8) {
+      const T av = A[m * n + jc];
+      sq += av * av;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < np) mac[q] += u[(p0 + q) * M + m] * av;
+    }
+    red[4][ry][cx] = sq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[q][ry][cx] = mac[q];
     __syncthreads();
     if (ry == 0 && ok) {
-      T mean = T(0);
+      if (p0 == 0) {
+        T ssum = T(0);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) mean += red[q][cx];
-      f[p * n + j] = mean + scale;
+        for (int q = 0; q < 8; ++q) ssum += red[4][q][cx];
+        const T vv = T(1) - ssum;
+        v[j] = vv;
+        if (mode == HB_SGP_DIAGONAL) scale = hb_sqrt(hb_abs(vv)) * eps[j];
+      }
+      for (int q = 0; q < np; ++q) {
+        T mean = T(0);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) mean += red[q][w][cx];
+        f[(p0 + q) * n + j] = mean + scale;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -233,18 +328,8 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.n = n; a.M = M; a.d = d; a.P = P;
     const int nRB = hb_cdiv(M, SGP_BM);
     dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
-    const bool fast = d <= SGP_DREG && M * d <= SGP_ZS_MAX;
-    if (fast && d == 1)
-      hipLaunchKernelGGL((sgp_A_kernel<T, 1>), grid, dim3(256), 0, stream, a);
-    else if (fast && d == 2)
-      hipLaunchKernelGGL((sgp_A_kernel<T, 2>), grid, dim3(256), 0, stream, a);
-    else if (fast && d == 3)
-      hipLaunchKernelGGL((sgp_A_kernel<T, 3>), grid, dim3(256), 0, stream, a);
-    else if (fast && d == 4)
-      hipLaunchKernelGGL((sgp_A_kernel<T, 4>), grid, dim3(256), 0, stream, a);
-    else
-      hipLaunchKernelGGL((sgp_A_kernel<T, 0>), grid, dim3(256), 0, stream, a);
-    HB_LAUNCH_CHECK();
+    int rc = sgp_A_launch<T>(a, grid, stream);
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(sgp_finish_kernel<T>, dim3(hb_cdiv(n, 32), (unsigned)E), dim3(256), 0, stream, A, u, eps, f, v, n,
                      M, P, mode);
@@ -269,19 +354,7 @@ static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, l
   a.n = n; a.M = M; a.d = d; a.P = 0;
   const int nRB = hb_cdiv(M, SGP_BM);
   dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
-  const bool fast = d <= SGP_DREG && M * d <= SGP_ZS_MAX;
-  if (fast && d == 1)
-    hipLaunchKernelGGL((sgp_A_kernel<T, 1>), grid, dim3(256), 0, stream, a);
-  else if (fast && d == 2)
-    hipLaunchKernelGGL((sgp_A_kernel<T, 2>), grid, dim3(256), 0, stream, a);
-  else if (fast && d == 3)
-    hipLaunchKernelGGL((sgp_A_kernel<T, 3>), grid, dim3(256), 0, stream, a);
-  else if (fast && d == 4)
-    hipLaunchKernelGGL((sgp_A_kernel<T, 4>), grid, dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL((sgp_A_kernel<T, 0>), grid, dim3(256), 0, stream, a);
-  HB_LAUNCH_CHECK();
-  return 0;
+  return sgp_A_launch<T>(a, grid, stream);
 }
 extern "C" int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
                             const float* W, float* A, long E, long n, long M, long d, void* stream) {
@@ -349,9 +422,15 @@ template <typename T>
 struct SgpRawB {
   T a, u;
 };
+template <typename T>
+struct SgpRawB4 {
+  typedef T VT __attribute__((ext_vector_type(16 / sizeof(T))));
+  VT a;
+  T u;
+};
 
 // Kbar = W^T Abar,  Abar_kj = sum_p u_pk fbar_pj + A_kj c_j  (built in the loader)
-template <typename T>
+template <typename T, bool FAST>
 __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
   typedef TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2> G;
   __shared__ T lds[G::LDS_ELEMS];
@@ -372,6 +451,17 @@ __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
   const T cj = c[jc];
   const bool preg = a.P == 1;
   const T fb0 = a.P > 0 ? fbar[jc] : T(0);
+  // vector path: this thread's B-operand group is always the same VEC columns
+  constexpr int VECK = TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2>::VEC;
+  const int n4 = col0 + (threadIdx.x % (SGP_BN / VECK)) * VECK;
+  const int n4c = n4 + VECK <= n ? n4 : (n >= VECK ? n - VECK : 0);
+  T c4[VECK], f4[VECK];
+#pragma unroll
+  for (int q = 0; q < VECK; ++q) {
+    const bool ok = FAST && (n4 + q < n);
+    c4[q] = ok ? c[n4 + q] : T(0);   // out-of-range columns: zero contribution (never stored anyway)
+    f4[q] = ok ? fbar[n4 + q] : T(0);
+  }
 
   for (int half = 0; half < 2; ++half) {
     const int rb = half == 0 ? (int)blockIdx.y : nRB - 1 - (int)blockIdx.y;
@@ -402,7 +492,36 @@ __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
       }
       return jok ? val : T(0);
     };
-    g.template run<false, false>(row0, M, la, fa, lb, fb, lds);
+    if constexpr (FAST) {
+      // vector path (M % 16 == 0, n % VEC == 0, P == 1): W^T and A/c/fbar by 16-byte loads
+      typedef typename G::VT VT;
+      constexpr int VEC = G::VEC;
+      auto la4 = [&](int m, int k) -> VT {
+        const int r = row0 + m;
+        return *reinterpret_cast<const VT*>(&W[k * M + (r < M ? r : M - VEC)]);
+      };
+      auto fa4 = [&](VT raw, int m, int k) -> VT {
+        VT v;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = ((row0 + m + q < M) & (k >= row0 + m + q)) ? raw[q] : T(0);
+        return v;
+      };
+      auto lb4 = [&](int k, int nn) -> SgpRawB4<T> {
+        SgpRawB4<T> r;
+        r.a = *reinterpret_cast<const typename SgpRawB4<T>::VT*>(&A[k * n + n4c]);
+        r.u = u[k];
+        return r;
+      };
+      auto fb4 = [&](SgpRawB4<T> raw, int k, int nn) -> VT {
+        VT v;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = raw.a[q] * c4[q] + raw.u * f4[q];
+        return v;
+      };
+      g.template run_vec<HB_MC, HB_MC>(row0, M, la4, fa4, lb4, fb4, lds);
+    } else {
+      g.template run<false, false>(row0, M, la, fa, lb, fb, lds);
+    }
     g.for_each([&](int row, int col, T v) {
       const int r = row0 + row, cc = col0 + col;
       if (r < M && cc < n) Kbar[(long)r * n + cc] = v;
@@ -414,6 +533,8 @@ __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
 // block reductions along the data axis).
 //   dK_mj/dz_mq   = -K_mj (z_mq - x_jq)/ell_q^2
 //   dK_mj/dell_q  =  K_mj (z_mq - x_jq)^2/ell_q^3
+// The first pass over the row handles up to SGP_DREG input dims and up to 4 latent
+// functions together (one read of Kbar[m,:] and A[m,:]); wider problems take more passes.
 template <typename T>
 __global__ void __launch_bounds__(256) sgp_rowgrad_kernel(const T* __restrict__ x, long sx, const T* __restrict__ z,
                                                           const T* __restrict__ ell, long dl,
@@ -429,45 +550,53 @@ __global__ void __launch_bounds__(256) sgp_rowgrad_kernel(const T* __restrict__ 
   Kbar += (e * M + m) * n;
   A += (e * M + m) * n;
   fbar += e * P * n;
-  // ubar
-  for (long p = 0; p < P; ++p) {
-    T acc = T(0);
-    for (long j = threadIdx.x; j < n; j += blockDim.x) acc += fbar[p * n + j] * A[j];
-    acc = block_sum(acc, smem);
-    if (threadIdx.x == 0) ubar[(e * P + p) * M + m] = acc;
-  }
-  // zbar / ell partial, SGP_DREG input dims at a time
-  for (long q0 = 0; q0 < d; q0 += SGP_DREG) {
+  const long npass_p = (P + 3) / 4, npass_q = (d + SGP_DREG - 1) / SGP_DREG;
+  const long npass = npass_p > npass_q ? npass_p : npass_q;
+  for (long pass = 0; pass < npass; ++pass) {
+    const long p0 = pass * 4, q0 = pass * SGP_DREG;
+    const int np = p0 < P ? (int)((P - p0) < 4 ? (P - p0) : 4) : 0;
+    const int nq = q0 < d ? (int)((d - q0) < SGP_DREG ? (d - q0) : SGP_DREG) : 0;
+    T uacc[4] = {T(0), T(0), T(0), T(0)};
     T zacc[SGP_DREG], lacc[SGP_DREG];
 #pragma unroll
     for (int q = 0; q < SGP_DREG; ++q) zacc[q] = lacc[q] = T(0);
+#pragma unroll 2
     for (long j = threadIdx.x; j < n; j += blockDim.x) {
-      const T* xj = x + j * d;
-      T r2 = T(0);
-      for (long q = 0; q < d; ++q) {
-        const T t = (z[q] - xj[q]) / ell[dl == 1 ? 0 : q];
-        r2 += t * t;
-      }
-      const T gk = Kbar[j] * hb_exp(T(-0.5) * r2);
+      if (np > 0) {
+        const T av = A[j];
 #pragma unroll
-      for (int q = 0; q < SGP_DREG; ++q) {
-        if (q0 + q < d) {
-          const T il = T(1) / ell[dl == 1 ? 0 : q0 + q];
-          const T t = (z[q0 + q] - xj[q0 + q]) * il;
-          zacc[q] += -gk * t * il;
-          lacc[q] += gk * t * t * il;
+        for (int q = 0; q < 4; ++q)
+          if (q < np) uacc[q] += fbar[(p0 + q) * n + j] * av;
+      }
+      if (nq > 0) {
+        const T* xj = x + j * d;
+        T r2 = T(0);
+        for (long q = 0; q < d; ++q) {
+          const T t = (z[q] - xj[q]) / ell[dl == 1 ? 0 : q];
+          r2 += t * t;
+        }
+        const T gk = Kbar[j] * hb_exp(T(-0.5) * r2);
+#pragma unroll
+        for (int q = 0; q < SGP_DREG; ++q) {
+          if (q < nq) {
+            const T il = T(1) / ell[dl == 1 ? 0 : q0 + q];
+            const T t = (z[q0 + q] - xj[q0 + q]) * il;
+            zacc[q] += -gk * t * il;
+            lacc[q] += gk * t * t * il;
+          }
         }
       }
     }
-#pragma unroll
-    for (int q = 0; q < SGP_DREG; ++q) {
-      if (q0 + q < d) {
-        const T zs = block_sum(zacc[q], smem);
-        const T ls = block_sum(lacc[q], smem);
-        if (threadIdx.x == 0) {
-          zbar[(e * M + m) * d + q0 + q] = zs;
-          ellpart[(e * M + m) * d + q0 + q] = ls;
-        }
+    for (int q = 0; q < np; ++q) {
+      const T us = block_sum(uacc[q], smem);
+      if (threadIdx.x == 0) ubar[(e * P + p0 + q) * M + m] = us;
+    }
+    for (int q = 0; q < nq; ++q) {
+      const T zs = block_sum(zacc[q], smem);
+      const T ls = block_sum(lacc[q], smem);
+      if (threadIdx.x == 0) {
+        zbar[(e * M + m) * d + q0 + q] = zs;
+        ellpart[(e * M + m) * d + q0 + q] = ls;
       }
     }
   }
@@ -581,7 +710,12 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.n = n; a.M = M; a.P = P;
     const int nRB = hb_cdiv(M, SGP_BM);
     dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
-    hipLaunchKernelGGL(sgp_kbar_kernel<T>, grid, dim3(256), 0, stream, a);
+    constexpr long VECH = 16 / sizeof(T);
+    const bool vec = P == 1 && M % 16 == 0 && n % VECH == 0 && ((uintptr_t)W % 16 == 0) && ((uintptr_t)A % 16 == 0);
+    if (vec)
+      hipLaunchKernelGGL((sgp_kbar_kernel<T, true>), grid, dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL((sgp_kbar_kernel<T, false>), grid, dim3(256), 0, stream, a);
     HB_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(sgp_rowgrad_kernel<T>, dim3((unsigned)M, (unsigned)E), dim3(256), 0, stream, x, sx, z, ell, dl,

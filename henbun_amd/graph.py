@@ -1199,6 +1199,91 @@ def gradients(loss: Tensor, wrt: Sequence[Tensor]) -> List[Optional[Tensor]]:
 # ------------------------------------------------------------------------------
 # HIP executor
 # ------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------
+# elementwise clustering: chains / groups of elementwise nodes -> one interpreted launch
+# ------------------------------------------------------------------------------
+EW_CLUSTER_MAX_ELEMS = 1 << 16   # larger tensors keep one specialised launch per op
+EW_CLUSTER_MAX_INSTR = 44
+EW_CLUSTER_MAX_IN = 8
+EW_CLUSTER_MAX_OUT = 6
+EW_CLUSTER_MAX_REGS = 60
+
+
+def _squeeze_shape(shape):
+    return tuple(d for d in shape if d != 1)
+
+
+def _merge_space(S, shape):
+    """Iteration space containing both (one must broadcast to the other), or None."""
+    try:
+        b = tuple(np.broadcast_shapes(S, shape))
+    except ValueError:
+        return None
+    size = lambda t: int(np.prod(t)) if t else 1
+    if size(b) != max(size(S), size(shape)):
+        return None
+    return b
+
+
+def _fusable(n):
+    if n.op == "ew":
+        return True
+    return n.op == "reshape" and n.outputs[0].size == 1
+
+
+class _Cluster:
+    __slots__ = ("nodes", "space", "sealed", "ninstr")
+
+    def __init__(self):
+        self.nodes, self.space, self.sealed, self.ninstr = [], (), False, 0
+
+
+def cluster_elementwise(order, enabled=True):
+    """Greedy clustering over a topological order.  A node joins the cluster of one of its
+    elementwise producers (or, failing that, any open cluster with a compatible iteration
+    space); a cluster is sealed as soon as a non-member consumes one of its values, so the
+    cluster can be emitted at its last member's position.  Returns {node id: cluster}."""
+    member = {}
+    if not enabled:
+        return member
+    open_clusters = []
+    for n in order:
+        joined = None
+        if _fusable(n) and len(_squeeze_shape(n.outputs[0].shape)) <= 4 and n.outputs[0].size <= EW_CLUSTER_MAX_ELEMS:
+            cands = []
+            for t in n.inputs:
+                c = member.get(t.node.id)
+                if c is not None and not c.sealed and c not in cands:
+                    cands.append(c)
+            cands += [c for c in reversed(open_clusters) if not c.sealed and c not in cands]
+            for c in cands:
+                sp = _merge_space(c.space, n.outputs[0].shape)
+                if sp is None or len(_squeeze_shape(sp)) > 4 or int(np.prod(sp) if sp else 1) > EW_CLUSTER_MAX_ELEMS:
+                    continue
+                if c.ninstr + 1 > EW_CLUSTER_MAX_INSTR:
+                    continue
+                # operand / result counts are re-checked when the program is built; keep a margin here
+                ext_in = {t for m in c.nodes + [n] for t in m.inputs if member.get(t.node.id) is not c and t.node is not n}
+                if len(ext_in) > EW_CLUSTER_MAX_IN or len(c.nodes) + 1 > EW_CLUSTER_MAX_OUT * 4:
+                    continue
+                joined = c
+                c.space = sp
+                break
+            if joined is None:
+                joined = _Cluster()
+                joined.space = n.outputs[0].shape
+                open_clusters.append(joined)
+            joined.nodes.append(n)
+            joined.ninstr += 1
+            member[n.id] = joined
+        # whoever consumes a cluster value from outside closes that cluster
+        for t in n.inputs:
+            c = member.get(t.node.id)
+            if c is not None and c is not joined:
+                c.sealed = True
+    return member
+
+
 class CholeskyError(ArithmeticError):
     """A Cholesky factorisation met a non-positive pivot (TensorFlow raises
     InvalidArgumentError from tf.cholesky at the same point)."""
@@ -1246,8 +1331,21 @@ class Plan:
             self._prebind(t, b)
         if prologue:
             prologue(self)
+        from ._settings import settings as _st
+
+        fuse = bool(getattr(_st.runtime, "fuse_elementwise", True))
+        self._clusters = cluster_elementwise(order, enabled=fuse)
+        consumers = {}
         for n in order:
-            self._emit(n)
+            for t in n.inputs:
+                consumers.setdefault(t, []).append(n)
+        self._consumers = consumers
+        for n in order:
+            c = self._clusters.get(n.id)
+            if c is None or len(c.nodes) < 2:
+                self._emit(n)
+            elif n is c.nodes[-1]:
+                self._emit_cluster(c)
         # outputs that could not be bound in place: explicit copy
         for t, b in list(self._bind.items()) + self._extra_copies:
             got = self._buf.get(t)
@@ -1334,6 +1432,85 @@ class Plan:
         label = n.op if n.op != "ew" else "ew:" + n.attrs["f"]
         for s in self.steps[before:]:
             self.step_labels[id(s)] = label
+
+    def _emit_cluster(self, c):
+        """One hb_ewise_prog launch for the whole cluster."""
+        H = self.H
+        members = {n.id for n in c.nodes}
+        space = tuple(c.space)
+        keep = [i for i, d in enumerate(space) if d != 1]
+        shape = [space[i] for i in keep]
+
+        def strides_of(tshape):
+            full = (1,) * (len(space) - len(tshape)) + tuple(tshape)
+            st, acc = [0] * len(space), 1
+            for d in range(len(space) - 1, -1, -1):
+                st[d] = acc if full[d] != 1 else 0
+                acc *= full[d]
+            return [st[i] for i in keep]
+
+        in_regs, inputs, istr = {}, [], []
+        reg_of = {}
+        code, params = [], []
+        next_reg = [0]
+
+        def operand(t):
+            if t.node.id in members:
+                return reg_of[t]
+            r = in_regs.get(t)
+            if r is None:
+                r = len(inputs)
+                in_regs[t] = r
+                inputs.append(self.buf(t))
+                istr.append(strides_of(t.shape))
+            return r
+
+        # first pass: collect external inputs so that their registers come first
+        for n in c.nodes:
+            for t in n.inputs:
+                if t.node.id not in members:
+                    operand(t)
+        next_reg[0] = len(inputs)
+        for n in c.nodes:
+            ops = [operand(t) for t in n.inputs]
+            dst = next_reg[0]
+            if n.op == "reshape":
+                code.append([H.EW["COPY"], dst, ops[0], 0, 0])
+                params.append([0.0, 0.0])
+                reg_of[n.outputs[0]] = dst
+                next_reg[0] += 1
+                continue
+            f, p = n.attrs["f"], list(n.attrs["p"]) + [0.0, 0.0]
+            if f == "GAUSS_LOGPDF_GRAD":
+                code.append([H.EW[f], dst, ops[0], ops[1], ops[2]])
+                params.append([float(ops[3]), 0.0])
+                for k, o in enumerate(n.outputs):
+                    reg_of[o] = dst + k
+                next_reg[0] += 3
+            else:
+                ops = (ops + [0, 0, 0])[:3]
+                code.append([H.EW[f], dst, ops[0], ops[1], ops[2]])
+                params.append([p[0], p[1]])
+                reg_of[n.outputs[0]] = dst
+                next_reg[0] += 1
+        outs, out_regs, ostr = [], [], []
+        for n in c.nodes:
+            for o in n.outputs:
+                used_outside = o in self.outputs or any(x.id not in members for x in self._consumers.get(o, []))
+                if used_outside:
+                    outs.append(self.out(o))
+                    out_regs.append(reg_of[o])
+                    ostr.append(strides_of(o.shape))
+        ok = (len(code) <= 48 and len(inputs) <= EW_CLUSTER_MAX_IN and 1 <= len(outs) <= EW_CLUSTER_MAX_OUT
+              and next_reg[0] <= EW_CLUSTER_MAX_REGS and len(shape) <= 4)
+        if not ok:
+            for n in c.nodes:  # too wide for one program: fall back to one launch per node
+                self._emit(n)
+            return
+        prog = H.EwiseProgram(code, params, inputs, istr, outs, out_regs, ostr, shape)
+        step = prog.launch
+        self.steps.append(step)
+        self.step_labels[id(step)] = "ew_cluster[%d]" % len(c.nodes)
 
     def inject_noise(self, t: Tensor, value):
         """Overwrite a random_normal leaf with a fixed draw (parity runs)."""

@@ -120,6 +120,34 @@ def ewise(op, inputs, nout=1, params=None, out=None):
     return outs[0] if nout == 1 else tuple(outs)
 
 
+class EwiseProgram:
+    """A prepared hb_ewise_prog launch (all host-side argument arrays built once)."""
+
+    def __init__(self, code, params, inputs, istrides, outputs, out_regs, ostrides, shape):
+        from ctypes import c_int
+
+        self.suf = _suf(outputs[0])
+        self.ninstr = len(code)
+        self.code = (c_int * (5 * len(code)))(*[int(v) for ins in code for v in ins])
+        self.params = (c_double * (2 * len(code)))(*[float(v) for pr in params for v in pr])
+        self.nin = len(inputs)
+        self.inputs = (c_void_p * max(self.nin, 1))(*[t.data_ptr() for t in inputs])
+        self.nd = len(shape)
+        flat_is = [s for st in istrides for s in st]
+        self.istr = _larr(flat_is) if flat_is else _larr([0])
+        self.nout = len(outputs)
+        self.outputs = (c_void_p * self.nout)(*[t.data_ptr() for t in outputs])
+        self.out_regs = (c_int * self.nout)(*[int(r) for r in out_regs])
+        flat_os = [s for st in ostrides for s in st]
+        self.ostr = _larr(flat_os) if flat_os else _larr([0])
+        self.shape = _larr(shape) if shape else _larr([1])
+        self._keep = (inputs, outputs)
+
+    def launch(self):
+        _lib.lib().call("hb_ewise_prog" + self.suf, self.ninstr, self.code, self.params, self.nin, self.inputs,
+                        self.istr, self.nout, self.outputs, self.out_regs, self.ostr, self.nd, self.shape, stream())
+
+
 def reduce_mid(x, K1, R, K2, op=RED_SUM, out=None):
     """out[K1,K2] = reduce_R x[K1,R,K2] (x contiguous, any shape with K1*R*K2 elements)."""
     _chk(x)

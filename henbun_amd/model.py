@@ -184,7 +184,7 @@ class Optimizer:
     def _settings_key(self):
         n = settings.numerics
         return (n.jitter_level, n.clip_by_value, n.clip_value_min, n.clip_value_max,
-                str(settings.runtime.index_source))
+                str(settings.runtime.index_source), bool(settings.runtime.fuse_elementwise))
 
     def _get_plan(self, kind, minibatch, training=True):
         sess = self.model._session

@@ -81,6 +81,20 @@ int hb_ewise_f32(int op, int nin, const void* const* in, const long* istrides, i
 int hb_ewise_f64(int op, int nin, const void* const* in, const long* istrides, int nout,
                  void* const* out, int ndim, const long* shape, const double* params, void* stream);
 
+/* A whole cluster of elementwise ops in one launch: a register program interpreted per element
+ * of the broadcast iteration space `shape[ndim]` (ndim <= 4).  Registers 0..nin-1 hold the inputs
+ * (read with `istrides`); instruction q = code[q] = {op, dst, a, b, c} (HB_EW_* op on registers a,b,c;
+ * HB_EW_GAUSS_LOGPDF_GRAD takes the register number of its 4th operand in params[q][0] and writes
+ * dst..dst+2) with params[q][2]; output k = register out_regs[k] stored with `ostrides` (a 0 stride on a dim of extent > 1
+ * marks a broadcast dim: only index 0 writes).  All array arguments are (host) arrays.  Replaces the
+ * chains of tiny TF elementwise ops of the reference's graph at one launch per chain. */
+int hb_ewise_prog_f32(int ninstr, const int* code, const double* params, int nin, const void* const* in,
+                      const long* istrides, int nout, void* const* out, const int* out_regs,
+                      const long* ostrides, int ndim, const long* shape, void* stream);
+int hb_ewise_prog_f64(int ninstr, const int* code, const double* params, int nin, const void* const* in,
+                      const long* istrides, int nout, void* const* out, const int* out_regs,
+                      const long* ostrides, int ndim, const long* shape, void* stream);
+
 enum { HB_RED_SUM = 0, HB_RED_MAX = 1 };
 /* out[K1,K2] = reduce over R of contiguous in[K1,R,K2]  (tf.reduce_sum / reduce_max) */
 int hb_reduce_f32(int op, const float* in, float* out, long K1, long R, long K2, float* ws,

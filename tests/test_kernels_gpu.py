@@ -513,3 +513,37 @@ def test_graph_capture_replay(H):
     for _ in range(5):
         opt.step([O.T(np.ones(100))])
     assert_close(theta, ref, dict(rtol=1e-5, atol=1e-6))
+
+
+# ------------------------------------------------------------------ fused elementwise program
+@pytest.mark.parametrize("p", ["f32", "f64"])
+def test_ewise_program(H, p):
+    """out0 = softplus(a)+1e-6 (scalar, broadcast input); out1 = gauss_logpdf(y, f*sqrt(out0), v) [1,n];
+    out2..4 = its gradient w.r.t. (x, mu, var) given g -- one launch, 3 register inputs reused."""
+    dt, tol = DT[p], TOL[p]
+    rng = np.random.RandomState(0)
+    n = 300
+    a, v = rng.randn(1), np.abs(rng.randn(1)) + 0.5
+    y, f, g = rng.randn(1, n), rng.randn(1, n), rng.randn(1, n)
+    ins = [dev(a, dt), dev(v, dt), dev(y, dt), dev(f, dt), dev(g, dt)]
+    E = H.EW
+    code = [[E["SOFTPLUS"], 5, 0, 0, 0], [E["AFFINE"], 6, 5, 0, 0], [E["SQRT"], 7, 6, 0, 0], [E["MUL"], 8, 3, 7, 0],
+            [E["GAUSS_LOGPDF"], 9, 2, 8, 1], [E["GAUSS_LOGPDF_GRAD"], 10, 2, 8, 1]]
+    params = [[0, 0], [1.0, 1e-6], [0, 0], [0, 0], [0, 0], [4.0, 0]]  # 4th operand of the grad op = register 4 (g)
+    outs = [torch.empty(1, dtype=dt, device="cuda")] + [torch.empty(1, n, dtype=dt, device="cuda") for _ in range(4)]
+    istr = [[0], [0], [1], [1], [1]]
+    ostr = [[0], [1], [1], [1], [1]]
+    prog = H.EwiseProgram(code, params, ins, istr, outs, [6, 9, 10, 11, 12], ostr, [n])
+    prog.launch()
+    ta, tv, ty, tf_, tg = [torch.as_tensor(t) for t in (a, v, y, f, g)]
+    kv = torch.nn.functional.softplus(ta) + 1e-6
+    mu = (tf_ * kv.sqrt()).requires_grad_(True)
+    tyr, tvr = ty.clone().requires_grad_(True), tv.clone().requires_grad_(True)
+    lp = O.gaussian(tyr, mu, tvr)
+    gx, gmu, gv = torch.autograd.grad(lp, [tyr, mu, tvr], tg)
+    assert_close(outs[0], kv, tol)
+    assert_close(outs[1], lp, tol)
+    assert_close(outs[2], gx, tol if p == "f64" else dict(rtol=1e-3, atol=1e-4))
+    assert_close(outs[3], gmu, tol if p == "f64" else dict(rtol=1e-3, atol=1e-4))
+    # per-element d/dvar (autograd sums over the broadcast): compare the sum
+    assert_close(host(outs[4]).sum().reshape(1), gv, tol if p == "f64" else dict(rtol=1e-3, atol=1e-3))

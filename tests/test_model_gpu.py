@@ -99,12 +99,14 @@ def test_svgp_fp32_tracks_fp64():
         assert rel_err(grads[mine], ref[theirs].numpy()) <= 5e-2, mine
 
 
-@pytest.mark.parametrize("capture", [True, False])
-def test_svgp_adam_trajectory_matches_oracle(capture):
-    """10 Adam steps at fixed noise/minibatch == the oracle's TF-formula Adam on autograd gradients."""
+@pytest.mark.parametrize("capture,fuse", [(True, True), (False, True), (True, False)])
+def test_svgp_adam_trajectory_matches_oracle(capture, fuse):
+    """10 Adam steps at fixed noise/minibatch == the oracle's TF-formula Adam on autograd gradients
+    (hipGraph replay or eager launches; elementwise clusters fused into one launch or not)."""
     cfg = hb.settings.get_settings()
     cfg.numerics.jitter_level = 1e-5
     cfg.runtime.graph_capture = capture
+    cfg.runtime.fuse_elementwise = fuse
     with hb.settings.temp_settings(cfg):
         m, data = make_svgp(1500, 48, 400, "diagonal", "float64", seed=3)
         opt = m.ELBO()
