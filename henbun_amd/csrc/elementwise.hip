@@ -204,7 +204,7 @@ extern "C" int hb_ewise_f64(int op, int nin, const void* const* in, const long* 
 #define HB_PROG_MAX_IN 8
 #define HB_PROG_MAX_OUT 6
 #define HB_PROG_MAX_DIMS 4
-#define HB_PROG_MAX_REGS 64
+#define HB_PROG_MAX_REGS 40
 
 struct ProgArgs {
   int ninstr, nin, nout, ndim;
@@ -221,6 +221,7 @@ struct ProgArgs {
 
 template <typename T>
 __global__ void __launch_bounds__(256) ew_prog_kernel(ProgArgs A) {
+  __shared__ T regs[HB_PROG_MAX_REGS][256];
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += stride) {
     int idx[HB_PROG_MAX_DIMS] = {0, 0, 0, 0};
@@ -233,24 +234,27 @@ __global__ void __launch_bounds__(256) ew_prog_kernel(ProgArgs A) {
         r = q;
       }
     }
-    T reg[HB_PROG_MAX_REGS];
+    // the register file lives in LDS ([reg][thread]: conflict-free), not in a private array: runtime-
+    // indexed private arrays go to scratch memory, whose set-up alone doubled the launch cost
+    T(*reg_)[256] = regs;
+#define reg(r_) reg_[r_][threadIdx.x]
     for (int k = 0; k < A.nin; ++k) {
       long off = 0;
 #pragma unroll
       for (int d = 0; d < HB_PROG_MAX_DIMS; ++d) off += (long)idx[d] * A.istr[k][d];
-      reg[k] = ((const T*)A.in[k])[off];
+      reg(k) = ((const T*)A.in[k])[off];
     }
     for (int q = 0; q < A.ninstr; ++q) {
       const int op = A.code[q][0], dst = A.code[q][1];
-      const T a = reg[A.code[q][2]], b = reg[A.code[q][3]], c = reg[A.code[q][4]];
+      const T a = reg(A.code[q][2]), b = reg(A.code[q][3]), c = reg(A.code[q][4]);
       // the 4-input op carries its 4th operand's register number in params[q][0]
-      const T d = (op == HB_EW_GAUSS_LOGPDF_GRAD) ? reg[(int)A.params[q][0]] : T(0);
+      const T d = (op == HB_EW_GAUSS_LOGPDF_GRAD) ? reg((int)A.params[q][0]) : T(0);
       T o0 = T(0), o1 = T(0), o2 = T(0);
       ew_apply<T>(op, a, b, c, d, A.params[q], o0, o1, o2);
-      reg[dst] = o0;
+      reg(dst) = o0;
       if (op == HB_EW_GAUSS_LOGPDF_GRAD) {
-        reg[dst + 1] = o1;
-        reg[dst + 2] = o2;
+        reg(dst + 1) = o1;
+        reg(dst + 2) = o2;
       }
     }
     for (int k = 0; k < A.nout; ++k) {
@@ -263,9 +267,10 @@ __global__ void __launch_bounds__(256) ew_prog_kernel(ProgArgs A) {
           off += (long)idx[d] * A.ostr[k][d];
         }
       }
-      if (write) ((T*)A.out[k])[off] = reg[A.out_reg[k]];
+      if (write) ((T*)A.out[k])[off] = reg(A.out_reg[k]);
     }
   }
+#undef reg
 }
 
 template <typename T>
@@ -356,7 +361,16 @@ __global__ void __launch_bounds__(256) reduce_rows_kernel(const T* __restrict__ 
   if (end > R) end = R;
   const T* row = in + k1 * R;
   T acc = red_identity<T, OP>();
-  for (long i = beg + threadIdx.x; i < end; i += blockDim.x) acc = red_combine<T, OP>(acc, row[i]);
+  long i = beg + threadIdx.x;
+  // 8 independent loads in flight per thread: a single block reducing a long row is latency-bound
+  for (; i + 7 * (long)blockDim.x < end; i += 8 * (long)blockDim.x) {
+    T v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = row[i + q * (long)blockDim.x];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc = red_combine<T, OP>(acc, v[q]);
+  }
+  for (; i < end; i += blockDim.x) acc = red_combine<T, OP>(acc, row[i]);
   if (OP == HB_RED_SUM)
     acc = block_sum(acc, smem);
   else

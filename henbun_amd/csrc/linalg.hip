@@ -21,7 +21,7 @@ struct MmArgs {
   T alpha, beta;
   const T* bias;
   long sBias;
-  int act, flags, S;
+  int act, flags, S, tile;
   T* ws;
 };
 
@@ -35,18 +35,18 @@ __device__ __forceinline__ T apply_act(int act, T v) {
   }
 }
 
-template <typename T, bool TA, bool TB, bool FAST>
+template <typename T, bool TA, bool TB, bool FAST, int BT>
 __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
-  typedef TileGemm<T, 64, 64, 16, 2, 2> G;
+  typedef TileGemm<T, BT, BT, 16, 2, 2> G;
   __shared__ T lds[G::LDS_ELEMS];
   const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
   const int lda = (int)a.lda, ldb = (int)a.ldb;
-  const int tiles_n = (N + 63) / 64;
-  const int row0 = (blockIdx.x / tiles_n) * 64;
-  const int col0 = (blockIdx.x % tiles_n) * 64;
+  const int tiles_n = (N + BT - 1) / BT;
+  const int row0 = (blockIdx.x / tiles_n) * BT;
+  const int col0 = (blockIdx.x % tiles_n) * BT;
   const long b = blockIdx.y;
   const int s = blockIdx.z;
-  if ((a.flags & HB_MM_LOWER_OUT) && col0 > row0 + 63) return;
+  if ((a.flags & HB_MM_LOWER_OUT) && col0 > row0 + BT - 1) return;
   int kchunk = (K + a.S - 1) / a.S;
   kchunk = ((kchunk + G::BK - 1) / G::BK) * G::BK;
   const int kbeg = s * kchunk;
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
     const long b = t / (a.M * a.N);
     const long rem = t - b * a.M * a.N;
     const long r = rem / a.N, c = rem - r * a.N;
-    if ((a.flags & HB_MM_LOWER_OUT) && (c / 64) * 64 > (r / 64) * 64 + 63) continue;
+    if ((a.flags & HB_MM_LOWER_OUT) && (c / a.tile) * a.tile > (r / a.tile) * a.tile + a.tile - 1) continue;
     T acc = T(0);
     for (int s = 0; s < a.S; ++s) acc += a.ws[(long)s * total + t];
     if (a.bias) acc += a.bias[b * a.sBias + c];
@@ -153,7 +153,10 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   a.bias = bias; a.sBias = sBias;
   a.act = act; a.flags = flags;
   a.ws = ws;
-  const long tiles = (long)hb_cdiv(M, 64) * hb_cdiv(N, 64);
+  // large outputs: 128x128 tiles (64x64 per wave: 4 MFMAs per fragment pair) cut the per-MFMA staging cost
+  const int BT = (M >= 256 && N >= 256) ? 128 : 64;
+  a.tile = BT;
+  const long tiles = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
   int S = 1;
   if (ws && tiles * batch < 192 && K >= 256) {
     // few output tiles: spread the contraction over the idle CUs (each slice >= 128 deep)
@@ -171,12 +174,19 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % VEC == 0 && ldb % VEC == 0 &&
                        sA % VEC == 0 && sB % VEC == 0;
   const bool fast = aligned && K % 16 == 0 && K > 0 && (!transA || M % VEC == 0) && (transB || N % VEC == 0);
-#define HB_MM_LAUNCH(TA_, TB_)                                                                      \
+#define HB_MM_LAUNCH2(TA_, TB_, F_)                                                                 \
   do {                                                                                              \
-    if (fast)                                                                                       \
-      hipLaunchKernelGGL((matmul_kernel<T, TA_, TB_, true>), grid, dim3(256), 0, stream, a);        \
+    if (BT == 128)                                                                                  \
+      hipLaunchKernelGGL((matmul_kernel<T, TA_, TB_, F_, 128>), grid, dim3(256), 0, stream, a);     \
     else                                                                                            \
-      hipLaunchKernelGGL((matmul_kernel<T, TA_, TB_, false>), grid, dim3(256), 0, stream, a);       \
+      hipLaunchKernelGGL((matmul_kernel<T, TA_, TB_, F_, 64>), grid, dim3(256), 0, stream, a);      \
+  } while (0)
+#define HB_MM_LAUNCH(TA_, TB_)            \
+  do {                                    \
+    if (fast)                             \
+      HB_MM_LAUNCH2(TA_, TB_, true);      \
+    else                                  \
+      HB_MM_LAUNCH2(TA_, TB_, false);     \
   } while (0)
   if (!transA && !transB)
     HB_MM_LAUNCH(false, false);
@@ -187,6 +197,7 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   else
     HB_MM_LAUNCH(true, true);
 #undef HB_MM_LAUNCH
+#undef HB_MM_LAUNCH2
   HB_LAUNCH_CHECK();
   if (S > 1) {
     hipLaunchKernelGGL(matmul_splitk_finish_kernel<T>, dim3(hb_stream_grid(batch * M * N, 256)), dim3(256), 0, stream,

@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) sgp_rng_fill_kernel(uint64_t* state, long
 
 extern "C" long hb_sgp_ws_elems(long E, long n, long M, long d, long P) {
   (void)P;
-  return E * n + E * M * d + 8 * E * M * M;
+  return E * n + E * M * d + 32 * E * M * M;
 }
 
 template <typename T>
@@ -700,7 +700,7 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   T* c = ws;
   T* ellpart = ws + E * n;
   T* mmws = ellpart + E * M * d;
-  const long mmws_elems = 8 * E * M * M;
+  const long mmws_elems = 32 * E * M * M;
   if (n > 0) {
     hipLaunchKernelGGL(sgp_prep_kernel<T>, dim3(hb_stream_grid(E * n, 256)), dim3(256), 0, stream, eps, v, fbar, c, E, n,
                        P, mode);

@@ -1206,7 +1206,7 @@ EW_CLUSTER_MAX_ELEMS = 1 << 16   # larger tensors keep one specialised launch pe
 EW_CLUSTER_MAX_INSTR = 44
 EW_CLUSTER_MAX_IN = 8
 EW_CLUSTER_MAX_OUT = 6
-EW_CLUSTER_MAX_REGS = 60
+EW_CLUSTER_MAX_REGS = 38
 
 
 def _squeeze_shape(shape):
