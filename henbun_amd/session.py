@@ -131,6 +131,9 @@ class Session:
                 host[o:o + s] = np.asarray(v._host_raw, dtype=self.np_dtype).reshape(-1)
                 v._assigned = False
         self.theta = self.torch.as_tensor(host).to(self.device)
+        if self.world_size > 1:
+            # data parallel: every rank must start from rank 0's parameters
+            self.torch.distributed.broadcast(self.theta, 0)
         self._layout = layout
         self._offsets = {id(v): (o, s) for v, o, s in layout}
         self.layout_version += 1
@@ -138,10 +141,14 @@ class Session:
     def initialize(self):
         """Upload pending (assigned) values; afterwards nothing is pending."""
         self.ensure_layout()
+        dirty = False
         for v, o, s in self._layout:
             if v._assigned:
                 self.write_raw(v, v._host_raw)
                 v.finalize()
+                dirty = True
+        if dirty and self.world_size > 1:
+            self.torch.distributed.broadcast(self.theta, 0)
 
     def param_view(self, v):
         o, s = self._offsets[id(v)]

@@ -413,3 +413,25 @@ def finite_difference(fn, params, key, idx, h=1e-6):
     flat[idx] = old - h
     fm = fn(p).item()
     return (fp - fm) / (2 * h)
+
+
+def expert_elbo(params, X, Y, N_total, noises, eps, jitter=1e-5):
+    """Two sparse-GP experts + sparse-GP gate (notebooks/Expert_GPR.ipynb:139-147, sparse form).
+
+    params: for g in (s, l, r): z_g [M,d], ell_raw_g [1], q_mu_g [M], q_sqrt_g [M]; k_var_raw, k_var_r_raw,
+    var_raw.  noises: {g: u [M]}; eps: [n,3] residual noise columns (s, l, r)."""
+    fs, kl = {}, 0.0
+    for i, g in enumerate(("s", "l", "r")):
+        mu, sq = params["q_mu_" + g], params["q_sqrt_" + g]
+        xs = sample_diag(mu, sq, noises[g])
+        kl = kl + kl_normal(sq, noises[g], xs, "diagonal")
+        ell = log1pe_forward(params["ell_raw_" + g])
+        fs[g] = sparse_samples(X, xs.reshape(1, -1), params["z_" + g], ell, jitter, "diagonal", eps[:, i])
+    k_var = log1pe_forward(params["k_var_raw"])
+    k_var_r = log1pe_forward(params["k_var_r_raw"])
+    var = log1pe_forward(params["var_raw"])
+    frac = torch.sigmoid(fs["r"] * torch.sqrt(k_var_r))
+    f = (frac * fs["s"] + (1.0 - frac) * fs["l"]) * k_var
+    n = X.shape[0]
+    ll = torch.sum(gaussian(Y.transpose(0, 1), f, var))
+    return (N_total / n) * ll - kl

@@ -76,3 +76,40 @@ def svgp_data(N, M, seed=0, domain=None, dtype=np.float64):
     Y = np.sin(X) + 0.3 * rng.randn(N, 1)
     Z = np.linspace(0, domain, M)[:, None]
     return X.astype(dtype), Y.astype(dtype), Z.astype(dtype)
+
+
+class ExpertGPR(hb.model.Model):
+    """Mixture of two sparse-GP experts with a sparse-GP gate: the sparse form of
+    notebooks/Expert_GPR.ipynb:101-160 (three independent GPs with their own kernels;
+    f = (sigmoid(f_r) f_s + (1 - sigmoid(f_r)) f_l) * k_var  -- times k_var, not its root,
+    as the notebook writes it)."""
+
+    def setUp(self, X, Y, Z, ells=(0.3, 2.0, 1.0), eps=None):
+        self.N = X.shape[0]
+        self.X = hb.param.MinibatchData(X)
+        self.Y = hb.param.MinibatchData(Y)
+        self.gp_s = hb.gp.SparseGP(kern=hb.gp.kernels.UnitRBF(np.ones(1) * ells[0]), z=Z)
+        self.gp_l = hb.gp.SparseGP(kern=hb.gp.kernels.UnitRBF(np.ones(1) * ells[1]), z=Z)
+        self.gp_r = hb.gp.SparseGP(kern=hb.gp.kernels.UnitRBF(np.ones(1) * ells[2]), z=Z)
+        M = Z.shape[0]
+        self.u_s = hb.variationals.Normal(shape=[1, M])
+        self.u_l = hb.variationals.Normal(shape=[1, M])
+        self.u_r = hb.variationals.Normal(shape=[1, M])
+        self.k_var = hb.param.Variable([1], transform=hb.transforms.positive)
+        self.k_var_r = hb.param.Variable([1], transform=hb.transforms.positive)
+        self.var = hb.param.Variable([1], transform=hb.transforms.positive)
+        # injected residual noise, one column per GP (parity runs)
+        self.eps = None if eps is None else hb.param.MinibatchData(eps)
+
+    @hb.model.AutoOptimize()
+    def ELBO(self):
+        e = self.eps
+        es, el, er = (None, None, None) if e is None else (e[:, 0], e[:, 1], e[:, 2])
+        f_s = self.gp_s.samples(self.X, self.u_s, eps=es)
+        f_l = self.gp_l.samples(self.X, self.u_l, eps=el)
+        f_r = self.gp_r.samples(self.X, self.u_r, eps=er) * tf.sqrt(self.k_var_r)
+        frac = tf.sigmoid(f_r)
+        f = (frac * f_s + (1.0 - frac) * f_l) * self.k_var
+        n = tf.shape(self.X)[0]
+        ll = tf.reduce_sum(hb.densities.gaussian(tf.transpose(self.Y), f, self.var))
+        return (self.N / n) * ll - self.KL()

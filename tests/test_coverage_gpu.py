@@ -1,0 +1,217 @@
+"""GPU parity for the remaining hot-path-adjacent surface (SURVEY.md 8a rows a13, a15, a18-a21, a23,
+a25, a26; 8f rows 2-4): densities, generic SparseGP branches, CsymRBF, the expert mixture of the
+reference notebook, Gaussian / variational-weight networks, prediction-style Model.run."""
+import numpy as np
+import pytest
+import torch
+
+import henbun_amd as hb
+import henbun_oracle as O
+from henbun_amd import graph as G
+
+from models import ExpertGPR, svgp_data
+
+pytestmark = pytest.mark.gpu
+tf = hb.tf
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64).reshape(-1), np.asarray(b, dtype=np.float64).reshape(-1)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_densities_on_device(golden):
+    # reference testing/test_densities.py:11-75 (atol 1e-5), test_tf_wraps.py:45-59
+    g = golden
+    m = hb.model.Model(dtype="float64")
+    lp0 = hb.densities.gaussian(g["d_a"], 0.0, 2.0)
+    lp1 = hb.densities.student_t(g["d_b"], 0.0, 2.0, 3.0)
+    mix = hb.densities.bimixture(g["d_frac"], lp0, lp1)
+    st_t = hb.densities.student_t(g["s_x"], g["s_mu"], g["s_scale"], g["s_nu"])
+    lse = hb.tf_wraps.log_sum_exp(G.constant(g["lse_in"]), 1)
+    assert np.allclose(m.run(lp0), g["d_logp0"], atol=1e-10)
+    assert np.allclose(m.run(lp1), g["d_logp1"], atol=1e-10)
+    assert np.allclose(m.run(mix), g["d_mix"], atol=1e-10)
+    assert np.allclose(m.run(st_t), g["s_logp_nuT"], atol=1e-9)
+    assert np.allclose(m.run(lse), g["lse_axis1"], atol=1e-10)
+    rng = np.random.RandomState(0)
+    A = rng.randn(4, 4)
+    S = A @ A.T + 4 * np.eye(4)
+    x, mu = rng.randn(4), rng.randn(4)
+    ref = O.multivariate_normal(O.T(x), O.T(mu), O.T(np.linalg.cholesky(S))).item()
+    got = m.run(hb.densities.multivariate_normal(x, mu, np.linalg.cholesky(S)))
+    assert np.isclose(float(got), ref, rtol=1e-10)
+    # fp32 path of the same ops at the reference's tolerance
+    m32 = hb.model.Model(dtype="float32")
+    assert np.allclose(m32.run(hb.densities.student_t(g["s_x"], g["s_mu"], g["s_scale"], 3.0)), g["s_logp_nu3"], atol=1e-5)
+
+
+def test_sparse_gp_generic_branches_and_csym_on_device(golden):
+    """3-D x, 'fullrank' residual and the CsymRBF kernel take the composed path
+    (reference gp/gp.py:123-143,167-172; kernels.py:113-131) -- same values as the oracle."""
+    np.random.seed(3)
+    rng = np.random.RandomState(0)
+    cfg = hb.settings.get_settings()
+    cfg.numerics.jitter_level = 1e-4
+    with hb.settings.temp_settings(cfg):
+        for kern_cls, K, Kd in ((hb.gp.kernels.UnitRBF, O.rbf_K, None),
+                                (hb.gp.kernels.UnitCsymRBF, O.csym_rbf_K, O.csym_rbf_Kdiag)):
+            m = hb.model.Model(dtype="float64")
+            z = np.linspace(-2.0, 2.0, 20).reshape(-1, 2)
+            m.gp = hb.gp.SparseGP(z=z, kern=kern_cls(lengthscales=np.ones(1) * 0.8))
+            m.u = hb.variationals.Normal(shape=[4, 10])
+            x2, x3 = rng.randn(7, 2), rng.randn(4, 7, 2)
+            uval = rng.randn(40)
+            m.u.inject_noise(uval)
+            e1, e3, ef = rng.randn(7), rng.randn(4, 7), rng.randn(4, 7)
+            with m.tf_mode():
+                d2 = m.gp.samples(x2, m.u, "diagonal", eps=e1)
+                n3 = m.gp.samples(x3, m.u, "neglected")
+                d3 = m.gp.samples(x3, m.u, "diagonal", eps=e3)
+                f2 = m.gp.samples(x2, m.u, "fullrank", eps=ef)
+                kxx = m.gp.kern.K(x3)
+                kd = m.gp.kern.Kdiag(G.constant(x2))
+            m.initialize()
+            s = m._session
+            ell = O.log1pe_forward(O.T(s.read_raw(m.gp.kern.lengthscales)))
+            us = O.sample_diag(O.T(s.read_raw(m.u.q_mu)), O.T(s.read_raw(m.u.q_sqrt)), O.T(uval)).reshape(4, 10)
+            zt = O.T(s.read_raw(m.gp.z))
+            kdiag = None if Kd is None else (lambda xx: Kd(xx, ell))
+            ref = lambda x, mode, e: O.sparse_samples(O.T(x), us, zt, ell, 1e-4, mode, None if e is None else O.T(e),
+                                                      K=K, Kdiag=kdiag).numpy()
+            assert np.allclose(m.run(d2), ref(x2, "diagonal", e1), atol=1e-8)
+            assert np.allclose(m.run(n3), ref(x3, "neglected", None), atol=1e-8)
+            assert np.allclose(m.run(d3), ref(x3, "diagonal", e3), atol=1e-8)
+            assert np.allclose(m.run(f2), ref(x2, "fullrank", ef), atol=1e-7)
+            assert np.allclose(m.run(kxx), K(O.T(x3), None, ell).numpy(), atol=1e-10)
+            if Kd is not None:
+                assert np.allclose(m.run(kd), Kd(O.T(x2), ell).numpy(), atol=1e-10)
+
+
+def test_no_nan_with_small_jitter_fp32():
+    # reference testing/test_gp.py:10-29: m = 600 random inducing points, n = 400, fp32, jitter 1e-5
+    np.random.seed(0)
+    rng = np.random.RandomState(0)
+    m = hb.model.Model(dtype="float32")
+    m.sparse_gp = hb.gp.SparseGP(z=np.sort(rng.uniform(-3, 3, (600, 1)), axis=0) * 10,
+                                 kern=hb.gp.kernels.UnitRBF(lengthscales=np.ones(1)))
+    m.u = hb.variationals.Normal(shape=[1, 600])
+    x = rng.randn(400, 1) * 10
+    with m.tf_mode():
+        a = m.run(m.sparse_gp.samples(x, m.u, "neglected"))
+        b = m.run(m.sparse_gp.samples(x, m.u, "diagonal"))
+    assert a.shape == (1, 400) and not np.any(np.isnan(a)) and not np.any(np.isnan(b))
+
+
+def test_expert_mixture_parity():
+    """Sparse form of notebooks/Expert_GPR.ipynb: three independent GPs, sigmoid gate, x k_var."""
+    np.random.seed(1)
+    rng = np.random.RandomState(1)
+    N, M, n = 1500, 40, 300
+    X = np.sort(rng.uniform(0, 20, (N, 1)), axis=0)
+    Y = np.where(X < 10, np.sin(3 * X), 0.3 * np.sin(0.5 * X)) + 0.1 * rng.randn(N, 1)
+    Z = np.linspace(0, 20, M)[:, None]
+    eps = rng.randn(N, 3)
+    cfg = hb.settings.get_settings()
+    cfg.numerics.jitter_level = 3e-4  # the notebook's setting (Expert_GPR.ipynb:203)
+    with hb.settings.temp_settings(cfg):
+        m = ExpertGPR(X=X, Y=Y, Z=Z, eps=eps, dtype="float64")
+        noises = {g: rng.randn(M) for g in "slr"}
+        m.u_s.inject_noise(noises["s"])
+        m.u_l.inject_noise(noises["l"])
+        m.u_r.inject_noise(noises["r"])
+        idx = rng.randint(0, N, n)
+        opt = m.ELBO()
+        opt.compile()
+        val, grads = opt.gradients(minibatch_size=n, indices=idx)
+        s = m._session
+        params = {"k_var_raw": O.T(s.read_raw(m.k_var)), "k_var_r_raw": O.T(s.read_raw(m.k_var_r)),
+                  "var_raw": O.T(s.read_raw(m.var))}
+        names = {"model.k_var": "k_var_raw", "model.k_var_r": "k_var_r_raw", "model.var": "var_raw"}
+        for g in "slr":
+            gp, u = getattr(m, "gp_" + g), getattr(m, "u_" + g)
+            params["z_" + g] = O.T(s.read_raw(gp.z))
+            params["ell_raw_" + g] = O.T(s.read_raw(gp.kern.lengthscales))
+            params["q_mu_" + g] = O.T(s.read_raw(u.q_mu))
+            params["q_sqrt_" + g] = O.T(s.read_raw(u.q_sqrt))
+            names.update({"model.gp_%s.z" % g: "z_" + g, "model.gp_%s.kern.lengthscales" % g: "ell_raw_" + g,
+                          "model.u_%s.q_mu" % g: "q_mu_" + g, "model.u_%s.q_sqrt" % g: "q_sqrt_" + g})
+        fn = lambda p: O.expert_elbo(p, O.T(X[idx]), O.T(Y[idx]), float(N), {g: O.T(v) for g, v in noises.items()},
+                                     O.T(eps[idx]), jitter=3e-4)
+        ref_val, ref = O.grads_of(fn, params)
+    assert abs(val - ref_val.item()) <= 1e-5 * abs(ref_val.item())
+    for mine, theirs in names.items():
+        assert rel_err(grads[mine], ref[theirs].numpy()) <= 1e-5, mine
+    # and it trains with in-kernel noise
+    for g in "slr":
+        getattr(m, "u_" + g).inject_noise(None)
+    m.eps = None
+
+
+def test_gaussian_variational_and_variational_network_weights():
+    """variationals.Gaussian (scale * Normal, reference variationals.py:232-291) and NeuralNet with
+    Variational weights (nn.py:37,51-54): values match the oracle at injected noise; KL collects all."""
+    np.random.seed(0)
+    rng = np.random.RandomState(0)
+
+    class M(hb.model.Model):
+        def setUp(self):
+            self.g = hb.variationals.Gaussian([3, 2], mean=2.0, stddev=0.5)
+            self.net = hb.nn.NeuralNet([3, 4, 2], variable_types=hb.variationals.Normal, stddev=0.5)
+
+        @hb.model.AutoOptimize()
+        def obj(self):
+            x = tf.constant(np.linspace(-1, 1, 15).reshape(5, 3))
+            return tf.reduce_sum(tf.square(self.net(x))) + tf.reduce_sum(self.g) - self.KL()
+
+    m = M(dtype="float64")
+    noise = {}
+    for v in (m.g, m.net.matbias0.w, m.net.matbias0.b, m.net.matbias1.w, m.net.matbias1.b):
+        noise[v] = rng.randn(v.size)
+        v.inject_noise(noise[v])
+    val = m.obj().run()
+    s = m._session
+    m.initialize()
+
+    def sample(v):
+        mu, sq = O.T(s.read_raw(v.q_mu)), O.T(s.read_raw(v.q_sqrt))
+        u = O.T(noise[v])
+        x = O.sample_diag(mu, sq, u)
+        return x, O.kl_normal(sq, u, x, "diagonal")
+
+    xg, kl = sample(m.g)
+    scale = O.log1pe_forward(O.T(s.read_raw(m.g.scale)))
+    tot = torch.sum(scale * xg.reshape(3, 2))
+    ws = []
+    for mb in (m.net.matbias0, m.net.matbias1):
+        xw, k1 = sample(mb.w)
+        xb, k2 = sample(mb.b)
+        kl = kl + k1 + k2
+        ws.append((xw.reshape(mb.w._shape), xb.reshape(mb.b._shape)))
+    x = O.T(np.linspace(-1, 1, 15).reshape(5, 3))
+    y = O.neural_net(x, [w for w, _ in ws], [b for _, b in ws])
+    ref = (torch.sum(y * y) + tot - kl).item()
+    assert np.isclose(val, ref, rtol=1e-10)
+    m.obj().compile(optimizer=tf.train.AdamOptimizer(0.01))
+    for v in noise:
+        v.inject_noise(None)
+    m.obj().optimize(maxiter=20)  # runs with in-kernel noise for every variational leaf
+
+
+def test_prediction_style_evaluation_and_heldout_objective():
+    """Model.run(tensor) posterior draws at new inputs and run(training=False)."""
+    np.random.seed(0)
+    from models import SVGP
+
+    X, Y, Z = svgp_data(3000, 48, 0)
+    m = SVGP(X=X, Y=Y, Z=Z, dtype="float64")
+    m.ELBO().compile(optimizer=tf.train.AdamOptimizer(0.01))
+    m.ELBO().optimize(maxiter=200, minibatch_size=512)
+    xs = np.linspace(0, 24, 50)[:, None]
+    with m.tf_mode():
+        draws = np.stack([m.run(m.gp.samples(xs, m.u, "neglected") * tf.sqrt(m.k_var)) for _ in range(20)])
+    assert draws.shape == (20, 1, 50) and np.all(np.isfinite(draws))
+    assert draws.std(0).mean() > 0  # a fresh posterior draw per call
+    assert np.mean((draws.mean(0)[0] - np.sin(xs[:, 0])) ** 2) < 0.3  # learned something about sin(x)
+    held = [m.ELBO().run(minibatch_size=256, training=False) for _ in range(3)]
+    assert np.all(np.isfinite(held))
