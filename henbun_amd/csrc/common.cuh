@@ -53,6 +53,47 @@ static inline int hb_stream_grid(long n, int block) {
 }
 
 // ---------------------------------------------------------------------------
+// Device-side zero fill / copy.  hipMemsetAsync / hipMemcpyAsync are NOT used on
+// any path that may run inside a hipGraph capture: measured on ROCm 7.2 / gfx950,
+// a captured 32-byte hipMemsetAsync replayed an 8-byte pattern of stale host
+// stack contents instead of zero (the Cholesky `info` words of a batch of 8).
+// Plain kernels capture as kernel nodes with their arguments by value.
+// ---------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) hb_zero_words_kernel(uint32_t* __restrict__ p, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) p[t] = 0u;
+}
+static __global__ void __launch_bounds__(256) hb_zero_quads_kernel(uint4* __restrict__ p, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const uint4 z = {0u, 0u, 0u, 0u};
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) p[t] = z;
+}
+static __global__ void __launch_bounds__(256) hb_copy_words_kernel(const uint32_t* __restrict__ s,
+                                                                  uint32_t* __restrict__ d, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) d[t] = s[t];
+}
+// bytes must be a multiple of 4 (all callers pass whole float / double / int arrays)
+static inline hipError_t hb_zero_async(void* p, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return hipSuccess;
+  if (bytes % 16 == 0 && ((uintptr_t)p % 16) == 0) {
+    const long n = (long)(bytes / 16);
+    hipLaunchKernelGGL(hb_zero_quads_kernel, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, (uint4*)p, n);
+  } else {
+    const long n = (long)(bytes / 4);
+    hipLaunchKernelGGL(hb_zero_words_kernel, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, (uint32_t*)p, n);
+  }
+  return hipGetLastError();
+}
+static inline hipError_t hb_copy_async(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return hipSuccess;
+  const long n = (long)(bytes / 4);
+  hipLaunchKernelGGL(hb_copy_words_kernel, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, (const uint32_t*)src,
+                     (uint32_t*)dst, n);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // wave / block reductions (sum, max).  Deterministic (no atomics).
 // ---------------------------------------------------------------------------
 template <typename T>

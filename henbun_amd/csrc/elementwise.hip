@@ -414,7 +414,7 @@ static int reduce_launch(const T* in, T* out, long K1, long R, long K2, T* ws, l
   if (K1 * K2 == 0) return 0;
   if (R == 0) {
     // empty reduction: fill identity (sum -> 0) through a trivial launch
-    hipMemsetAsync(out, 0, sizeof(T) * K1 * K2, stream);
+    HB_HIP(hb_zero_async(out, sizeof(T) * K1 * K2, stream));
     return 0;
   }
   if (K2 == 1) {

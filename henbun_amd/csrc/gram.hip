@@ -28,38 +28,40 @@ __device__ __forceinline__ T gram_value(int kind, const T* __restrict__ xi, cons
 template <typename T>
 __global__ void __launch_bounds__(256) gram_fwd_kernel(int kind, const T* __restrict__ X, long sX,
                                                        const T* __restrict__ X2, long sX2, const T* __restrict__ ell,
-                                                       long dl, T* __restrict__ K, long B, long n, long n2, long d) {
+                                                       long sEll, long dl, T* __restrict__ K, long B, long n, long n2,
+                                                       long d) {
   const long total = B * n * n2;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const long b = t / (n * n2);
     const long rem = t - b * n * n2;
     const long i = rem / n2, j = rem - i * n2;
-    K[t] = gram_value<T>(kind, X + b * sX + i * d, X2 + b * sX2 + j * d, ell, dl, d);
+    K[t] = gram_value<T>(kind, X + b * sX + i * d, X2 + b * sX2 + j * d, ell + b * sEll, dl, d);
   }
 }
 
 template <typename T>
-static int gram_fwd(int kind, const T* X, long sX, const T* X2, long sX2, const T* ell, long dl, T* K, long B, long n,
-                    long n2, long d, hipStream_t stream) {
+static int gram_fwd(int kind, const T* X, long sX, const T* X2, long sX2, const T* ell, long sEll, long dl, T* K,
+                    long B, long n, long n2, long d, hipStream_t stream) {
   HB_REQUIRE(kind >= HB_KERN_RBF && kind <= HB_KERN_SQDIST, "hb_gram_fwd: unknown kernel kind %d", kind);
   HB_REQUIRE(B >= 0 && n >= 0 && n2 >= 0 && d >= 1, "hb_gram_fwd: bad extents");
   HB_REQUIRE(dl == 1 || dl == d, "hb_gram_fwd: lengthscales must have 1 or d=%ld entries, got %ld", d, dl);
   HB_REQUIRE(X && X2 && ell && K, "hb_gram_fwd: NULL pointer");
   const long total = B * n * n2;
   if (total == 0) return 0;
+  HB_REQUIRE(sEll == 0 || sEll == dl, "hb_gram_fwd: lengthscale batch stride must be 0 or dl");
   hipLaunchKernelGGL(gram_fwd_kernel<T>, dim3(hb_stream_grid(total, 256)), dim3(256), 0, stream, kind, X, sX, X2, sX2,
-                     ell, dl, K, B, n, n2, d);
+                     ell, sEll, dl, K, B, n, n2, d);
   HB_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int hb_gram_fwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
-                               long dl, float* K, long B, long n, long n2, long d, void* stream) {
-  return gram_fwd<float>(kind, X, sX, X2, sX2, ell, dl, K, B, n, n2, d, (hipStream_t)stream);
+                               long sEll, long dl, float* K, long B, long n, long n2, long d, void* stream) {
+  return gram_fwd<float>(kind, X, sX, X2, sX2, ell, sEll, dl, K, B, n, n2, d, (hipStream_t)stream);
 }
 extern "C" int hb_gram_fwd_f64(int kind, const double* X, long sX, const double* X2, long sX2, const double* ell,
-                               long dl, double* K, long B, long n, long n2, long d, void* stream) {
-  return gram_fwd<double>(kind, X, sX, X2, sX2, ell, dl, K, B, n, n2, d, (hipStream_t)stream);
+                               long sEll, long dl, double* K, long B, long n, long n2, long d, void* stream) {
+  return gram_fwd<double>(kind, X, sX, X2, sX2, ell, sEll, dl, K, B, n, n2, d, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -76,12 +78,13 @@ extern "C" int hb_gram_fwd_f64(int kind, const double* X, long sX, const double*
 template <typename T>
 __global__ void __launch_bounds__(256)
 gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const T* __restrict__ X2, long sX2,
-                     const T* __restrict__ ell, long dl, const T* __restrict__ Kbar, T* __restrict__ out,
+                     const T* __restrict__ ell, long sEll, long dl, const T* __restrict__ Kbar, T* __restrict__ out,
                      T* __restrict__ ell_partial, long n, long n2, long d) {
   // side 0: block row i of X, loop j over X2; side 1: block row j of X2, loop i over X.
   __shared__ T smem[16];
   const long b = blockIdx.y;
   const long row = blockIdx.x;
+  ell += b * sEll;
   const long nother = side == 0 ? n2 : n;
   const T* xs = side == 0 ? X + b * sX + row * d : X2 + b * sX2 + row * d;
   for (long k0 = 0; k0 < d; k0 += HB_GRAM_MAXD) {
@@ -139,6 +142,8 @@ __global__ void __launch_bounds__(256) gram_ell_finish_kernel(const T* __restric
                                                               T* __restrict__ ellbar) {
   __shared__ T smem[16];
   const long c = blockIdx.x;  // < dl
+  partial += (long)blockIdx.y * rows * d;  // per-batch lengthscales: one group of rows per batch entry
+  ellbar += (long)blockIdx.y * dl;
   T acc = T(0);
   if (dl == 1) {
     for (long t = threadIdx.x; t < rows * d; t += blockDim.x) acc += partial[t];
@@ -150,48 +155,53 @@ __global__ void __launch_bounds__(256) gram_ell_finish_kernel(const T* __restric
 }
 
 template <typename T>
-static int gram_bwd(int kind, const T* X, long sX, const T* X2, long sX2, const T* ell, long dl, const T* Kbar,
-                    T* Xbar, T* X2bar, T* ellbar, long B, long n, long n2, long d, T* ws, hipStream_t stream) {
+static int gram_bwd(int kind, const T* X, long sX, const T* X2, long sX2, const T* ell, long sEll, long dl,
+                    const T* Kbar, T* Xbar, T* X2bar, T* ellbar, long B, long n, long n2, long d, T* ws,
+                    hipStream_t stream) {
   HB_REQUIRE(kind >= HB_KERN_RBF && kind <= HB_KERN_SQDIST, "hb_gram_bwd: unknown kernel kind %d", kind);
   HB_REQUIRE(B >= 0 && n >= 0 && n2 >= 0 && d >= 1, "hb_gram_bwd: bad extents");
   HB_REQUIRE(dl == 1 || dl == d, "hb_gram_bwd: lengthscales must have 1 or d entries");
+  HB_REQUIRE(sEll == 0 || sEll == dl, "hb_gram_bwd: lengthscale batch stride must be 0 or dl");
   HB_REQUIRE(X && X2 && ell && Kbar, "hb_gram_bwd: NULL pointer");
   HB_REQUIRE(!ellbar || ws, "hb_gram_bwd: ellbar needs workspace");
   HB_REQUIRE(B <= 65535, "hb_gram_bwd: batch too large");
   if (B == 0) return 0;
   if (n == 0 || n2 == 0) {
-    if (Xbar && n > 0) HB_HIP(hipMemsetAsync(Xbar, 0, sizeof(T) * B * n * d, stream));
-    if (X2bar && n2 > 0) HB_HIP(hipMemsetAsync(X2bar, 0, sizeof(T) * B * n2 * d, stream));
-    if (ellbar) HB_HIP(hipMemsetAsync(ellbar, 0, sizeof(T) * dl, stream));
+    if (Xbar && n > 0) HB_HIP(hb_zero_async(Xbar, sizeof(T) * B * n * d, stream));
+    if (X2bar && n2 > 0) HB_HIP(hb_zero_async(X2bar, sizeof(T) * B * n2 * d, stream));
+    if (ellbar) HB_HIP(hb_zero_async(ellbar, sizeof(T) * dl * (sEll != 0 ? B : 1), stream));
     return 0;
   }
   // side 0 pass also produces the lengthscale partials
   if (Xbar || ellbar) {
-    hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n, B), dim3(256), 0, stream, kind, 0, X, sX, X2, sX2, ell, dl,
-                       Kbar, Xbar, ellbar ? ws : (T*)nullptr, n, n2, d);
+    hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n, B), dim3(256), 0, stream, kind, 0, X, sX, X2, sX2, ell, sEll,
+                       dl, Kbar, Xbar, ellbar ? ws : (T*)nullptr, n, n2, d);
     HB_LAUNCH_CHECK();
     if (ellbar) {
       // d(K)/d(ell) = sum lacc (positive sign; see header comment)
-      hipLaunchKernelGGL(gram_ell_finish_kernel<T>, dim3(dl), dim3(256), 0, stream, ws, B * n, d, dl, ellbar);
+      if (sEll != 0)
+        hipLaunchKernelGGL(gram_ell_finish_kernel<T>, dim3(dl, B), dim3(256), 0, stream, ws, n, d, dl, ellbar);
+      else
+        hipLaunchKernelGGL(gram_ell_finish_kernel<T>, dim3(dl, 1), dim3(256), 0, stream, ws, B * n, d, dl, ellbar);
       HB_LAUNCH_CHECK();
     }
   }
   if (X2bar) {
-    hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n2, B), dim3(256), 0, stream, kind, 1, X, sX, X2, sX2, ell, dl,
-                       Kbar, X2bar, (T*)nullptr, n, n2, d);
+    hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n2, B), dim3(256), 0, stream, kind, 1, X, sX, X2, sX2, ell, sEll,
+                       dl, Kbar, X2bar, (T*)nullptr, n, n2, d);
     HB_LAUNCH_CHECK();
   }
   return 0;
 }
 extern "C" int hb_gram_bwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
-                               long dl, const float* Kbar, float* Xbar, float* X2bar, float* ellbar, long B, long n,
-                               long n2, long d, float* ws, void* stream) {
-  return gram_bwd<float>(kind, X, sX, X2, sX2, ell, dl, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws,
+                               long sEll, long dl, const float* Kbar, float* Xbar, float* X2bar, float* ellbar,
+                               long B, long n, long n2, long d, float* ws, void* stream) {
+  return gram_bwd<float>(kind, X, sX, X2, sX2, ell, sEll, dl, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws,
                          (hipStream_t)stream);
 }
 extern "C" int hb_gram_bwd_f64(int kind, const double* X, long sX, const double* X2, long sX2, const double* ell,
-                               long dl, const double* Kbar, double* Xbar, double* X2bar, double* ellbar, long B,
-                               long n, long n2, long d, double* ws, void* stream) {
-  return gram_bwd<double>(kind, X, sX, X2, sX2, ell, dl, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws,
+                               long sEll, long dl, const double* Kbar, double* Xbar, double* X2bar, double* ellbar,
+                               long B, long n, long n2, long d, double* ws, void* stream) {
+  return gram_bwd<double>(kind, X, sX, X2, sX2, ell, sEll, dl, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws,
                           (hipStream_t)stream);
 }

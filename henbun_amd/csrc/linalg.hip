@@ -405,8 +405,13 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(const T* __restrict__ A
   HB_STAMP(2);
   if (threadIdx.x < 64) {
     const int fail = potrf32_lds<T>(Cs, LsT, invd, threadIdx.x);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && fail != 0 && fail <= nb) {
-      if (*info == 0) *info = (int)(j0 + fail);
+    // info: block 0 of every panel launch is its only writer; the first panel resets it
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const int bad = (fail != 0 && fail <= nb) ? (int)(j0 + fail) : 0;
+      if (j0 == 0)
+        *info = bad;
+      else if (bad != 0 && *info == 0)
+        *info = bad;
     }
   }
   __syncthreads();
@@ -467,7 +472,10 @@ static int cholesky_launch(const T* A, T* L, long B, long M, int* info, hipStrea
   HB_REQUIRE(B <= 65535, "hb_cholesky: batch too large");
   HB_REQUIRE(M * M < 2147483647L, "hb_cholesky: matrix too large for 32-bit indexing");
   if (B == 0) return 0;
-  HB_HIP(hipMemsetAsync(info, 0, sizeof(int) * B, stream));
+  if (M == 0) {
+    HB_HIP(hb_zero_async(info, sizeof(int) * B, stream));
+    return 0;
+  }
   const bool fast = ((uintptr_t)L % 16 == 0) && M % (16 / (long)sizeof(T)) == 0;
   for (long j0 = 0; j0 < M; j0 += CH_NB) {
     const long below = M - j0 - CH_NB;
@@ -655,7 +663,7 @@ static int trinv_launch(const T* L, T* W, long B, long M, T* ws, hipStream_t str
   HB_REQUIRE(M * M < 2147483647L, "hb_trinv: matrix too large for 32-bit indexing");
   if (B * M == 0) return 0;
   HB_REQUIRE(M <= CH_NB || ws, "hb_trinv: workspace of B*M*M elements required");
-  HB_HIP(hipMemsetAsync(W, 0, sizeof(T) * B * M * M, stream));
+  HB_HIP(hb_zero_async(W, sizeof(T) * B * M * M, stream));
   // vector path: every k-range of the level kernels is a multiple of 16 once M is
   const bool fast = ((uintptr_t)L % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)ws % 16 == 0) && M % 16 == 0;
   const int nblk = hb_cdiv(M, CH_NB);

@@ -319,7 +319,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
       HB_LAUNCH_CHECK();
       eps = eps_out;
     } else if (eps_out && eps_out != eps_in) {
-      HB_HIP(hipMemcpyAsync(eps_out, eps_in, sizeof(T) * E * n, hipMemcpyDeviceToDevice, stream));
+      HB_HIP(hb_copy_async(eps_out, eps_in, sizeof(T) * E * n, stream));
     }
   }
   if (M > 0) {
@@ -737,7 +737,7 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     hipLaunchKernelGGL(sgp_tril_kernel<T>, dim3(hb_stream_grid(E * M * M, 256)), dim3(256), 0, stream, Lbar, E, M);
     HB_LAUNCH_CHECK();
   } else {
-    HB_HIP(hipMemsetAsync(Lbar, 0, sizeof(T) * E * M * M, stream));
+    HB_HIP(hb_zero_async(Lbar, sizeof(T) * E * M * M, stream));
   }
   return 0;
 }

@@ -222,7 +222,7 @@ static int fullrank_fwd(const T* mu, const T* S, const T* u_in, uint64_t* rng, l
     }
     u = u_out;
   } else if (u_out && u_out != u_in && n > 0) {
-    HB_HIP(hipMemcpyAsync(u_out, u_in, sizeof(T) * n, hipMemcpyDeviceToDevice, stream));
+    HB_HIP(hb_copy_async(u_out, u_in, sizeof(T) * n, stream));
   }
   int grid;
   if (size > 64) {

@@ -37,7 +37,7 @@ class SparseGP(GP):
         z = np.asarray(z)
         self.z = Variable(shape=z.shape, collections=collections)
         self.z = z  # deferred assignment of the initial inducing locations
-        self.m = len(z)
+        self.m = z.shape[-2]  # z is [m,d], or [E,m,d] for E independent GPs evaluated as one batch
 
     def _z(self):
         return object.__getattribute__(self, "z").tensor()

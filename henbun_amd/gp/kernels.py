@@ -35,8 +35,13 @@ class UnitStationary(Kern):
         self.scoped_keys.extend(["square_dist", "euclid_dist", "Cholesky"])
 
     def _ell(self):
+        """Lengthscales as [dl], or [E, dl] when a 2-D array was given: E independent kernels
+        evaluated as one batch (one per expert; builder extension, SURVEY.md cfg 5)."""
         ls = object.__getattribute__(self, "lengthscales")
-        return G.reshape(ls.tensor(), [-1])
+        t = ls.tensor()
+        if len(t.shape) == 2 and t.shape[0] > 1:
+            return t
+        return G.reshape(t, [-1])
 
     def square_dist(self, X, X2=None):
         """r^2 between X [n,d]/[N,n,d] and X2 (reference gp/kernels.py:54-84)."""

@@ -1002,12 +1002,31 @@ KERN_KINDS = {"rbf": 0, "csym_rbf": 1, "sqdist": 2}
 
 def gram(X, X2, ell, kind="rbf") -> Tensor:
     """Stationary Gram matrix K(X, X2) (reference gp/kernels.py:54-131); X, X2
-    are [n,d] or [B,n,d] (a 2-D operand is shared by the batch)."""
+    are [n,d] or [B,n,d] (a 2-D operand is shared by the batch); ell is [dl]
+    (one kernel) or [B,dl] (an independent kernel per batch entry: experts)."""
     X, X2, ell = as_tensor(X), as_tensor(X2), as_tensor(ell)
     if X.shape[-1] != X2.shape[-1]:
         raise ValueError("gram: input dimensions differ")
     lead = X.shape[:-2] if len(X.shape) >= len(X2.shape) else X2.shape[:-2]
+    if len(ell.shape) == 2 and ell.shape[0] > 1:
+        if lead and int(np.prod(lead)) != ell.shape[0]:
+            raise ValueError("gram: %d lengthscale sets for a batch of %s" % (ell.shape[0], lead))
+        lead = lead or (ell.shape[0],)
     return make("gram", (X, X2, ell), {"kind": kind}, [tuple(lead) + (X.shape[-2], X2.shape[-2])]).outputs[0]
+
+
+def _gram_layout(tX, tX2, tell):
+    n, d = tX.shape[-2], tX.shape[-1]
+    n2 = tX2.shape[-2]
+    BX = int(np.prod(tX.shape[:-2])) if len(tX.shape) > 2 else 1
+    BX2 = int(np.prod(tX2.shape[:-2])) if len(tX2.shape) > 2 else 1
+    BE = tell.shape[0] if (len(tell.shape) == 2 and tell.shape[0] > 1) else 1
+    B = max(BX, BX2, BE)
+    sX = n * d if (BX == B and B > 1) else 0
+    sX2 = n2 * d if (BX2 == B and B > 1) else 0
+    dl = tell.size // BE
+    sEll = dl if BE > 1 else 0
+    return B, BX, BX2, n, n2, d, sX, sX2, sEll, dl
 
 
 def _gram_emit(plan, node):
@@ -1033,20 +1052,14 @@ def _gram_grad_emit(plan, node):
     X, X2, ell, g = (plan.buf(t) for t in node.inputs)
     oX, oX2, oL = [plan.out(t) for t in node.outputs]
     k = KERN_KINDS[node.attrs["kind"]]
-    n, d = tX.shape[-2], tX.shape[-1]
-    n2 = tX2.shape[-2]
-    BX = int(np.prod(tX.shape[:-2])) if len(tX.shape) > 2 else 1
-    BX2 = int(np.prod(tX2.shape[:-2])) if len(tX2.shape) > 2 else 1
-    B = max(BX, BX2)
-    sX = n * d if (BX == B and B > 1) else 0
-    sX2 = n2 * d if (BX2 == B and B > 1) else 0
+    B, BX, BX2, n, n2, d, sX, sX2, sEll, dl = _gram_layout(tX, tX2, tell)
     # an operand shared by the batch gets its per-batch gradients summed
     tmpX = plan.scratch((B, n, d)) if (BX == 1 and B > 1) else None
     tmpX2 = plan.scratch((B, n2, d)) if (BX2 == 1 and B > 1) else None
     ws = plan.scratch((max(B * n * d, 1),))
 
     def step():
-        H.gram_bwd_raw(k, X, sX, X2, sX2, ell, g, tmpX if tmpX is not None else oX,
+        H.gram_bwd_raw(k, X, sX, X2, sX2, ell, sEll, dl, g, tmpX if tmpX is not None else oX,
                        tmpX2 if tmpX2 is not None else oX2, oL, B, n, n2, d, ws)
         if tmpX is not None:
             H.reduce_mid(tmpX, 1, B, n * d, out=oX)

@@ -66,14 +66,46 @@ def _larr(vals):
     return (c_long * len(vals))(*[int(v) for v in vals])
 
 
+_capturing = False
+
+
+def set_capturing(flag):
+    """While a hipGraph is being captured every buffer must already exist: a tensor allocated inside
+    the capture would be returned to torch's caching allocator afterwards and the graph would keep
+    replaying into memory that now belongs to something else."""
+    global _capturing
+    _capturing = bool(flag)
+
+
+def _empty(*a, **k):
+    if _capturing:
+        raise RuntimeError("henbun_amd: device allocation during hipGraph capture (an op was emitted without "
+                           "preallocated outputs/workspace)")
+    return torch.empty(*a, **k)
+
+
+def _empty_like(t):
+    if _capturing:
+        raise RuntimeError("henbun_amd: device allocation during hipGraph capture (an op was emitted without "
+                           "preallocated outputs/workspace)")
+    return torch.empty_like(t)
+
+
 _ws_cache = {}
 
 
+_ws_retired = []
+
+
 def workspace(dtype, device, elems=WS_ELEMS) -> torch.Tensor:
+    """Shared scratch for the stream-ordered launches of one stream.  A workspace that has to grow is
+    retired, never freed: captured hipGraphs may still hold its address."""
     key = (dtype, str(device), torch.cuda.current_stream().cuda_stream)
     w = _ws_cache.get(key)
     if w is None or w.numel() < elems:
-        w = torch.empty(max(elems, WS_ELEMS), dtype=dtype, device=device)
+        if w is not None:
+            _ws_retired.append(w)
+        w = _empty(max(elems, WS_ELEMS), dtype=dtype, device=device)
         _ws_cache[key] = w
     return w
 
@@ -107,7 +139,7 @@ def ewise(op, inputs, nout=1, params=None, out=None):
     for t in inputs:
         strides += _bcast_strides(tuple(t.shape), out_shape)
     if out is None:
-        outs = [torch.empty(out_shape, dtype=inputs[0].dtype, device=inputs[0].device) for _ in range(nout)]
+        outs = [_empty(out_shape, dtype=inputs[0].dtype, device=inputs[0].device) for _ in range(nout)]
     else:
         outs = list(out) if isinstance(out, (list, tuple)) else [out]
         for o in outs:
@@ -153,7 +185,7 @@ def reduce_mid(x, K1, R, K2, op=RED_SUM, out=None):
     _chk(x)
     assert x.numel() == K1 * R * K2
     if out is None:
-        out = torch.empty(K1 * K2, dtype=x.dtype, device=x.device)
+        out = _empty(K1 * K2, dtype=x.dtype, device=x.device)
     ws = workspace(x.dtype, x.device)
     _lib.lib().call("hb_reduce" + _suf(x), op, _p(x), _p(out), K1, R, K2, _p(ws), ws.numel(), stream())
     return out
@@ -182,7 +214,7 @@ def gather_rows(src, idx, perm=None, out=None, err=None):
     row = src.numel() // max(nsrc, 1)
     n = idx.numel()
     if out is None:
-        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        out = _empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     assert idx.dtype == torch.int64 and (perm is None or perm.dtype == torch.int64)
     _lib.lib().call("hb_gather_rows" + _suf(src), _p(src), nsrc, row, _p(idx), _p(perm), n, _p(out), _p(err), stream())
     return out
@@ -193,7 +225,7 @@ def matutil(x, mode, lower=-1, upper=-1, alpha=0.0, out=None):
     R, C = x.shape[-2], x.shape[-1]
     B = x.numel() // max(R * C, 1)
     if out is None:
-        out = torch.empty_like(x)
+        out = _empty_like(x)
     _lib.lib().call("hb_matutil" + _suf(x), _p(x), _p(out), B, R, C, mode, lower, upper, float(alpha), stream())
     return out
 
@@ -204,7 +236,7 @@ class Rng:
 
     def __init__(self, seed, stream_id=0, nlanes=16384, device="cuda"):
         self.nlanes = int(nlanes)
-        self.state = torch.empty(2 * self.nlanes, dtype=torch.int64, device=device)
+        self.state = _empty(2 * self.nlanes, dtype=torch.int64, device=device)
         self.seed, self.stream_id = int(seed), int(stream_id)
         self.reseed(seed, stream_id)
 
@@ -214,13 +246,13 @@ class Rng:
 
     def normal(self, shape, dtype=torch.float32, out=None):
         if out is None:
-            out = torch.empty(shape, dtype=dtype, device=self.state.device)
+            out = _empty(shape, dtype=dtype, device=self.state.device)
         _lib.lib().call("hb_rng_normal" + _suf(out), _p(self.state), self.nlanes, _p(out), out.numel(), stream())
         return out
 
     def randint(self, n, lo, hi, out=None):
         if out is None:
-            out = torch.empty(n, dtype=torch.int64, device=self.state.device)
+            out = _empty(n, dtype=torch.int64, device=self.state.device)
         _lib.lib().call("hb_rng_randint", _p(self.state), self.nlanes, _p(out), out.numel(), int(lo), int(hi), stream())
         return out
 
@@ -237,7 +269,7 @@ def diag_sample_kl_fwd(mu, s, u_in=None, rng=None, out=None):
     _chk(mu), _chk(s)
     n = mu.numel()
     if out is None:
-        x, kl, u = torch.empty_like(mu), torch.empty(1, dtype=mu.dtype, device=mu.device), torch.empty_like(mu)
+        x, kl, u = _empty_like(mu), _empty(1, dtype=mu.dtype, device=mu.device), _empty_like(mu)
     else:
         x, kl, u = out
     ws = workspace(mu.dtype, mu.device)
@@ -249,7 +281,7 @@ def diag_sample_kl_fwd(mu, s, u_in=None, rng=None, out=None):
 
 def diag_sample_kl_bwd(s, u, x, xbar, klbar, out=None):
     if out is None:
-        mubar, sbar = torch.empty_like(s), torch.empty_like(s)
+        mubar, sbar = _empty_like(s), _empty_like(s)
     else:
         mubar, sbar = out
     _lib.lib().call("hb_diag_sample_kl_bwd" + _suf(s), _p(s), _p(u), _p(x), _p(xbar), _p(klbar), _p(mubar), _p(sbar),
@@ -263,7 +295,7 @@ def fullrank_sample_kl_fwd(mu, S, u_in=None, rng=None, out=None):
     size = mu.shape[-1]
     rows = mu.numel() // max(size, 1)
     if out is None:
-        x, kl, u = torch.empty_like(mu), torch.empty(1, dtype=mu.dtype, device=mu.device), torch.empty_like(mu)
+        x, kl, u = _empty_like(mu), _empty(1, dtype=mu.dtype, device=mu.device), _empty_like(mu)
     else:
         x, kl, u = out
     ws = workspace(mu.dtype, mu.device)
@@ -277,7 +309,7 @@ def fullrank_sample_kl_bwd(S, u, x, xbar, klbar, out=None):
     size = u.shape[-1]
     rows = u.numel() // max(size, 1)
     if out is None:
-        mubar, Sbar = torch.empty_like(u), torch.empty_like(S)
+        mubar, Sbar = _empty_like(u), _empty_like(S)
     else:
         mubar, Sbar = out
     _lib.lib().call("hb_fullrank_sample_kl_bwd" + _suf(S), _p(S), _p(u), _p(x), _p(xbar), _p(klbar), _p(mubar),
@@ -293,28 +325,40 @@ def _batch_view(X, nd_tail=2):
     return B, n, d
 
 
+def _ell_layout(ell, B, d):
+    """(sEll, dl): a lengthscale tensor [dl] is shared by the batch, [B, dl] gives one kernel per batch entry."""
+    if ell.dim() >= 2 and ell.shape[0] == B and B > 1:
+        dl = ell.numel() // B
+        return dl, dl
+    return 0, ell.numel()
+
+
 def gram_fwd(X, X2, ell, kind=KERN_RBF, out=None):
-    """K[b,i,j] = k(X[b,i], X2[b,j]); X, X2: [n,d] or [B,n,d] (a 2-D operand is shared over B)."""
+    """K[b,i,j] = k(X[b,i], X2[b,j]); X, X2: [n,d] or [B,n,d] (a 2-D operand is shared over B);
+    ell: [dl] (shared) or [B, dl] (one kernel per batch entry)."""
     _chk(X), _chk(X2), _chk(ell)
     BX, n, d = _batch_view(X)
     BX2, n2, d2 = _batch_view(X2)
     assert d == d2
     B = max(BX, BX2)
+    if ell.dim() >= 2 and ell.shape[0] > 1:
+        B = max(B, ell.shape[0])
     assert BX in (1, B) and BX2 in (1, B)
     sX = n * d if (BX == B and B > 1) else 0
     sX2 = n2 * d if (BX2 == B and B > 1) else 0
-    batched = X.dim() > 2 or X2.dim() > 2
-    lead = tuple(X.shape[:-2]) if X.dim() >= X2.dim() else tuple(X2.shape[:-2])
+    sEll, dl = _ell_layout(ell, B, d)
+    batched = X.dim() > 2 or X2.dim() > 2 or sEll != 0
+    lead = tuple(X.shape[:-2]) if X.dim() > 2 else (tuple(X2.shape[:-2]) if X2.dim() > 2 else ((B,) if sEll else ()))
     if out is None:
-        out = torch.empty((lead if batched else ()) + (n, n2), dtype=X.dtype, device=X.device)
-    _lib.lib().call("hb_gram_fwd" + _suf(X), kind, _p(X), sX, _p(X2), sX2, _p(ell), ell.numel(), _p(out), B, n, n2, d,
+        out = _empty((lead if batched else ()) + (n, n2), dtype=X.dtype, device=X.device)
+    _lib.lib().call("hb_gram_fwd" + _suf(X), kind, _p(X), sX, _p(X2), sX2, _p(ell), sEll, dl, _p(out), B, n, n2, d,
                     stream())
     return out
 
 
-def gram_bwd_raw(kind, X, sX, X2, sX2, ell, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws):
+def gram_bwd_raw(kind, X, sX, X2, sX2, ell, sEll, dl, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws):
     """hb_gram_bwd on caller-provided buffers (no allocation: graph-capturable)."""
-    _lib.lib().call("hb_gram_bwd" + _suf(X), kind, _p(X), sX, _p(X2), sX2, _p(ell), ell.numel(), _p(Kbar), _p(Xbar),
+    _lib.lib().call("hb_gram_bwd" + _suf(X), kind, _p(X), sX, _p(X2), sX2, _p(ell), sEll, dl, _p(Kbar), _p(Xbar),
                     _p(X2bar), _p(ellbar), B, n, n2, d, _p(ws), stream())
 
 
@@ -325,14 +369,17 @@ def gram_bwd(X, X2, ell, Kbar, kind=KERN_RBF, need=(True, True, True)):
     BX, n, d = _batch_view(X)
     BX2, n2, _ = _batch_view(X2)
     B = max(BX, BX2)
+    if ell.dim() >= 2 and ell.shape[0] > 1:
+        B = max(B, ell.shape[0])
     sX = n * d if (BX == B and B > 1) else 0
     sX2 = n2 * d if (BX2 == B and B > 1) else 0
+    sEll, dl = _ell_layout(ell, B, d)
     dev, dt = X.device, X.dtype
-    Xbar = torch.empty((B, n, d), dtype=dt, device=dev) if need[0] else None
-    X2bar = torch.empty((B, n2, d), dtype=dt, device=dev) if need[1] else None
-    ellbar = torch.empty(ell.numel(), dtype=dt, device=dev) if need[2] else None
+    Xbar = _empty((B, n, d), dtype=dt, device=dev) if need[0] else None
+    X2bar = _empty((B, n2, d), dtype=dt, device=dev) if need[1] else None
+    ellbar = _empty(ell.numel(), dtype=dt, device=dev) if need[2] else None
     ws = workspace(dt, dev, max(B * n * d, 1))
-    gram_bwd_raw(kind, X, sX, X2, sX2, ell, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws)
+    gram_bwd_raw(kind, X, sX, X2, sX2, ell, sEll, dl, Kbar, Xbar, X2bar, ellbar, B, n, n2, d, ws)
     if Xbar is not None:
         Xbar = reduce_mid(Xbar, 1, B, n * d).reshape(X.shape) if (BX == 1 and B > 1) else Xbar.reshape(X.shape)
     if X2bar is not None:
@@ -361,7 +408,7 @@ def matmul(A, B, transA=False, transB=False, alpha=1.0, bias=None, act="none", l
     sA = A.shape[-2] * A.shape[-1] if (ba == batch and batch > 1) else 0
     sB = B.shape[-2] * B.shape[-1] if (bb == batch and batch > 1) else 0
     if out is None:
-        out = torch.empty(lead + (am, bn), dtype=A.dtype, device=A.device)
+        out = _empty(lead + (am, bn), dtype=A.dtype, device=A.device)
     sBias = 0
     if bias is not None:
         _chk(bias)
@@ -385,9 +432,9 @@ def cholesky(A, out=None, info=None):
     assert A.shape[-2] == M
     B = A.numel() // max(M * M, 1)
     if out is None:
-        out = torch.empty_like(A)
+        out = _empty_like(A)
     if info is None:
-        info = torch.empty(max(B, 1), dtype=torch.int32, device=A.device)
+        info = _empty(max(B, 1), dtype=torch.int32, device=A.device)
     _lib.lib().call("hb_cholesky" + _suf(A), _p(A), _p(out), B, M, _p(info), stream())
     return out, info
 
@@ -398,7 +445,7 @@ def trinv(L, out=None):
     M = L.shape[-1]
     B = L.numel() // max(M * M, 1)
     if out is None:
-        out = torch.empty_like(L)
+        out = _empty_like(L)
     ws = workspace(L.dtype, L.device, max(B * M * M, 1))
     _lib.lib().call("hb_trinv" + _suf(L), _p(L), _p(out), B, M, _p(ws), stream())
     return out
@@ -422,10 +469,10 @@ def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None)
     lead = (E,) if z.dim() == 3 else ()
     dev, dt = x.device, x.dtype
     if out is None:
-        f = torch.empty(lead + (P, n), dtype=dt, device=dev)
-        A = torch.empty(lead + (M, n), dtype=dt, device=dev)
-        v = torch.empty(lead + (n,), dtype=dt, device=dev)
-        eps = torch.empty(lead + (n,), dtype=dt, device=dev)
+        f = _empty(lead + (P, n), dtype=dt, device=dev)
+        A = _empty(lead + (M, n), dtype=dt, device=dev)
+        v = _empty(lead + (n,), dtype=dt, device=dev)
+        eps = _empty(lead + (n,), dtype=dt, device=dev)
     else:
         f, A, v, eps = out
     dl = ell.numel() // E
@@ -442,7 +489,7 @@ def sgp_A(x, z, ell, W, out=None):
     n = x.shape[-2]
     sx = n * d if (x.dim() == 3 and x.shape[0] == E and E > 1) else 0
     if out is None:
-        out = torch.empty(((E,) if z.dim() == 3 else ()) + (M, n), dtype=x.dtype, device=x.device)
+        out = _empty(((E,) if z.dim() == 3 else ()) + (M, n), dtype=x.dtype, device=x.device)
     _lib.lib().call("hb_sgp_A" + _suf(x), KERN_RBF, _p(x), sx, _p(z), _p(ell), ell.numel() // E, _p(W), _p(out), E, n,
                     M, d, stream())
     return out
@@ -454,12 +501,12 @@ def sgp_bwd(x, z, ell, W, u, eps, A, v, fbar, mode=SGP_DIAGONAL, need_xbar=False
     dev, dt = x.device, x.dtype
     dl = ell.numel() // E
     if out is None:
-        Kbar = torch.empty_like(A)
-        Lbar = torch.empty_like(W)
-        ubar = torch.empty_like(u)
-        zbar = torch.empty_like(z)
-        ellbar = torch.empty_like(ell)
-        xbar = torch.empty((E, n, d), dtype=dt, device=dev) if need_xbar else None
+        Kbar = _empty_like(A)
+        Lbar = _empty_like(W)
+        ubar = _empty_like(u)
+        zbar = _empty_like(z)
+        ellbar = _empty_like(ell)
+        xbar = _empty((E, n, d), dtype=dt, device=dev) if need_xbar else None
     else:
         Kbar, Lbar, ubar, zbar, ellbar, xbar = out
     wse = _lib.lib().raw("hb_sgp_ws_elems")(E, n, M, d, P)
@@ -487,8 +534,10 @@ class CapturedGraph:
 
     def begin(self):
         _lib.lib().call("hb_graph_begin_capture", stream())
+        set_capturing(True)
 
     def end(self):
+        set_capturing(False)
         _lib.lib().call("hb_graph_end_capture", stream(), ctypes.byref(self._exec))
 
     def launch(self):

@@ -180,20 +180,23 @@ int hb_fullrank_sample_kl_bwd_f64(const double* S, const double* u, const double
  *      square_dist, :110-111 UnitRBF.K, :122-131 UnitCsymRBF) -------------- */
 enum { HB_KERN_RBF = 0, HB_KERN_CSYM_RBF = 1, HB_KERN_SQDIST = 2 /* the scaled squared distance itself */ };
 /* K[b,i,j] = k(X[b,i,:], X2[b,j,:]); sX/sX2 = batch strides in elements (0 =
- * shared); ell has dl = 1 (scalar) or d entries (ARD), post-transform. */
+ * shared); ell has dl = 1 (scalar) or d entries (ARD), post-transform; sEll = 0
+ * (one kernel for the whole batch) or dl (a lengthscale vector per batch entry:
+ * independent experts). */
 int hb_gram_fwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
-                    long dl, float* K, long B, long n, long n2, long d, void* stream);
+                    long sEll, long dl, float* K, long B, long n, long n2, long d, void* stream);
 int hb_gram_fwd_f64(int kind, const double* X, long sX, const double* X2, long sX2,
-                    const double* ell, long dl, double* K, long B, long n, long n2, long d,
+                    const double* ell, long sEll, long dl, double* K, long B, long n, long n2, long d,
                     void* stream);
-/* VJP: Xbar[B,n,d], X2bar[B,n2,d] (either nullable), ellbar[dl] (nullable).
- * ws >= B*n*dl elements when ellbar != NULL. */
+/* VJP: Xbar[B,n,d], X2bar[B,n2,d] (either nullable), ellbar[dl] or [B,dl] when sEll != 0
+ * (nullable).  ws >= B*n*d elements when ellbar != NULL. */
 int hb_gram_bwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
-                    long dl, const float* Kbar, float* Xbar, float* X2bar, float* ellbar, long B,
-                    long n, long n2, long d, float* ws, void* stream);
+                    long sEll, long dl, const float* Kbar, float* Xbar, float* X2bar, float* ellbar,
+                    long B, long n, long n2, long d, float* ws, void* stream);
 int hb_gram_bwd_f64(int kind, const double* X, long sX, const double* X2, long sX2,
-                    const double* ell, long dl, const double* Kbar, double* Xbar, double* X2bar,
-                    double* ellbar, long B, long n, long n2, long d, double* ws, void* stream);
+                    const double* ell, long sEll, long dl, const double* Kbar, double* Xbar,
+                    double* X2bar, double* ellbar, long B, long n, long n2, long d, double* ws,
+                    void* stream);
 
 /* ---- dense linear algebra on MFMA (f32: v_mfma_f32_32x32x2_f32, f64:
  *      v_mfma_f64_16x16x4_f64) --------------------------------------------- */

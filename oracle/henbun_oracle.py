@@ -435,3 +435,24 @@ def expert_elbo(params, X, Y, N_total, noises, eps, jitter=1e-5):
     n = X.shape[0]
     ll = torch.sum(gaussian(Y.transpose(0, 1), f, var))
     return (N_total / n) * ll - kl
+
+
+def experts_elbo(params, X, Y, N_total, u_noise, eps, jitter=1e-5):
+    """E experts + E softmax gates (cfg 5; builder-defined generalisation of the 2-expert sigmoid form).
+
+    params: z [2E,M,d], ell_raw [2E,1], q_mu [2E*M], q_sqrt [2E*M], k_var_raw, k_var_r_raw, var_raw;
+    u_noise [2E*M]; eps [n, 2E]."""
+    E2, M = params["z"].shape[0], params["z"].shape[1]
+    E = E2 // 2
+    xs = sample_diag(params["q_mu"], params["q_sqrt"], u_noise)
+    kl = kl_normal(params["q_sqrt"], u_noise, xs, "diagonal")
+    us = xs.reshape(E2, 1, M)
+    ell = log1pe_forward(params["ell_raw"])
+    fs = [sparse_samples(X, us[e], params["z"][e], ell[e], jitter, "diagonal", eps[:, e])[0] for e in range(E2)]
+    f_e = torch.stack(fs[:E])
+    g_e = torch.stack(fs[E:]) * torch.sqrt(log1pe_forward(params["k_var_r_raw"]))
+    w = torch.softmax(g_e, dim=0)
+    f = torch.sum(w * f_e, 0, keepdim=True) * log1pe_forward(params["k_var_raw"])
+    n = X.shape[0]
+    ll = torch.sum(gaussian(Y.transpose(0, 1), f, log1pe_forward(params["var_raw"])))
+    return (N_total / n) * ll - kl

@@ -113,3 +113,40 @@ class ExpertGPR(hb.model.Model):
         n = tf.shape(self.X)[0]
         ll = tf.reduce_sum(hb.densities.gaussian(tf.transpose(self.Y), f, self.var))
         return (self.N / n) * ll - self.KL()
+
+
+class ExpertsGPR(hb.model.Model):
+    """cfg 5: E sparse-GP experts with E sparse-GP gates (softmax gating; E = 2 with r = g_2 - g_1
+    reduces to the sigmoid form of notebooks/Expert_GPR.ipynb:139-147).  The 2E independent GPs
+    -- own inducing points, own lengthscale, own q(u) -- are ONE batched SparseGP, so their Gram
+    matrices, Cholesky factors and M^2 n contractions run as single expert-batched launches."""
+
+    def setUp(self, X, Y, Z, ells, eps=None):
+        E2 = len(ells)
+        self.E = E2 // 2
+        self.N = X.shape[0]
+        self.X = hb.param.MinibatchData(X)
+        self.Y = hb.param.MinibatchData(Y)
+        M = Z.shape[0]
+        z = np.broadcast_to(Z, (E2,) + Z.shape).copy()
+        self.gp = hb.gp.SparseGP(kern=hb.gp.kernels.UnitRBF(np.asarray(ells, dtype=np.float64).reshape(E2, 1)), z=z)
+        self.u = hb.variationals.Normal(shape=[E2, 1, M])
+        self.k_var = hb.param.Variable([1], transform=hb.transforms.positive)
+        self.k_var_r = hb.param.Variable([1], transform=hb.transforms.positive)
+        self.var = hb.param.Variable([1], transform=hb.transforms.positive)
+        self.eps = None if eps is None else hb.param.MinibatchData(eps)  # [N, 2E] injected residual noise
+
+    @hb.model.AutoOptimize()
+    def ELBO(self):
+        E = self.E
+        eps = None if self.eps is None else tf.transpose(self.eps)        # [2E, n]
+        f_all = self.gp.samples(self.X, self.u, eps=eps)                   # [2E, 1, n]
+        f_e = f_all[:E, 0, :]                                              # [E, n]
+        g_e = f_all[E:, 0, :] * tf.sqrt(self.k_var_r)
+        g_max = tf.reduce_max(g_e, 0, keep_dims=True)
+        w = tf.exp(g_e - g_max)
+        w = w / tf.reduce_sum(w, 0, keep_dims=True)
+        f = tf.reduce_sum(w * f_e, 0, keep_dims=True) * self.k_var         # [1, n]
+        n = tf.shape(self.X)[0]
+        ll = tf.reduce_sum(hb.densities.gaussian(tf.transpose(self.Y), f, self.var))
+        return (self.N / n) * ll - self.KL()

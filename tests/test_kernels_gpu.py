@@ -259,6 +259,31 @@ def test_gram_bwd(H, kind, ard):
     assert_close(zb, gZ, TOL["f64"])
 
 
+@pytest.mark.parametrize("kind", ["rbf", "csym"])
+@pytest.mark.parametrize("ard", [False, True])
+def test_gram_per_batch_lengthscales(H, kind, ard):
+    """ell [B, dl]: one independent kernel per batch entry (expert-batched Gram) == a loop of singles."""
+    rng = np.random.RandomState(1)
+    B, n, n2, d = 4, 11, 6, 2
+    X, X2 = rng.randn(B, n, d), rng.randn(n2, d)
+    ell = np.exp(0.3 * rng.randn(B, d if ard else 1))
+    Kbar = rng.randn(B, n, n2)
+    tX, tX2, tl = [torch.as_tensor(t).requires_grad_(True) for t in (X, X2, ell)]
+    f = O.rbf_K if kind == "rbf" else O.csym_rbf_K
+    K = torch.stack([f(tX[b], tX2, tl[b]) for b in range(B)])
+    gX, gX2, gl = torch.autograd.grad((K * torch.as_tensor(Kbar)).sum(), [tX, tX2, tl])
+    dt = torch.float64
+    k = H.KERN_RBF if kind == "rbf" else H.KERN_CSYM_RBF
+    assert_close(H.gram_fwd(dev(X, dt), dev(X2, dt), dev(ell, dt), kind=k), K.detach(), TOL["f64"])
+    xb, x2b, lb = H.gram_bwd(dev(X, dt), dev(X2, dt), dev(ell, dt), dev(Kbar, dt), kind=k)
+    assert_close(xb, gX, TOL["f64"])
+    assert_close(x2b, gX2, TOL["f64"])
+    assert_close(lb, gl, TOL["f64"])
+    # both operands shared, only the kernels differ (the K(z_e, x) of experts on common inputs)
+    K2 = torch.stack([f(tX[0], tX2, tl[b]) for b in range(B)])
+    assert_close(H.gram_fwd(dev(X[0], dt), dev(X2, dt), dev(ell, dt), kind=k), K2.detach(), TOL["f64"])
+
+
 # ------------------------------------------------------------------ matmul
 @pytest.mark.parametrize("p", ["f32", "f64"])
 @pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])

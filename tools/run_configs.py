@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import henbun_amd as hb
-from models import SVGP, Amortised, svgp_data
+from models import SVGP, Amortised, ExpertsGPR, svgp_data
 tf = hb.tf
 
 def timed(opt, n, steps=100, warm=10):
@@ -46,7 +46,25 @@ def cfg4():
     prof = opt._plans[[k for k in opt._plans if k[0] == "opt"][0]].profile(iters=5)
     print({k: round(v[0], 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}, flush=True)
 
-for f in (cfg4, cfg3):
+def cfg5():
+    np.random.seed(0)
+    rng = np.random.RandomState(0)
+    E, M, n, N = 4, 512, 65536, 1000000
+    X, Y, Z = svgp_data(N, M, 0, domain=512.0)
+    ells = list(np.linspace(0.6, 1.2, E)) + list(np.linspace(0.8, 1.4, E))
+    m = ExpertsGPR(X=X, Y=Y, Z=Z, ells=ells, dtype="float32")
+    opt = m.ELBO(); opt.compile(optimizer=tf.train.AdamOptimizer(1e-3))
+    e0 = opt.run(minibatch_size=n)
+    print("cfg5 initial ELBO", e0, flush=True)
+    t = timed(opt, n, 50, 5)
+    e1 = opt.run(minibatch_size=n)
+    F = 2 * E * (3 * 2.0 * M * M * n)
+    print("cfg5 %d experts + %d gates x M=512 n=65536: %.2f ms/step (%.0f steps/s, %.1f M samples/s, %.1f TFLOP/s algorithmic), ELBO %.4g -> %.4g" % (E, E, t * 1e3, 1 / t, n / t * 1e-6, F / t * 1e-12, e0, e1), flush=True)
+    prof = opt._plans[[k for k in opt._plans if k[0] == "opt"][0]].profile(iters=5)
+    print({k: round(v[0], 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}, flush=True)
+
+which = sys.argv[1:] or ["cfg4", "cfg3", "cfg5"]
+for f in [globals()[w] for w in which]:
     try:
         f()
     except Exception:
