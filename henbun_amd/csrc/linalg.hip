@@ -222,36 +222,6 @@ extern "C" int hb_matmul_f64(const double* A, const double* B, double* C, long b
                                sBias, act, flags, ws, ws_elems, (hipStream_t)stream);
 }
 
-// ===========================================================================
-// Cholesky: left-looking, one launch per 32-column panel.
-//
-// Launch j (panel columns [j0, j0+32)): workgroup g owns the 32 diagonal rows
-// (every workgroup recomputes the diagonal block -- cheaper than a cross-
-// workgroup hand-off) plus 96 rows below; it forms
-//   C = A[rows, panel] - L[rows, 0:j0] L[panel, 0:j0]^T        (MFMA)
-// factors the 32x32 diagonal block with ONE wave working in LDS (no workgroup
-// barriers in the 32-step loop), then solves its rows against it.
-// ===========================================================================
-// In-kernel phase stamps: compiled in only by tools/chol_stamps.hip (diagnostic build).
-#ifndef HB_STAMP
-#define HB_STAMP(i)
-#endif
-
-#define CH_NB 32
-#define CH_RB 96
-#define CH_LD (CH_NB + 4)  // LDS row stride of the panel tile: keeps rows 16-byte aligned for vector reads
-
-__device__ __forceinline__ float bcast_lane(float v, int src) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
-}
-__device__ __forceinline__ double bcast_lane(double v, int src) {
-  const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-  const long long r = ((long long)hi << 32) | (unsigned int)lo;
-  return __builtin_bit_cast(double, r);
-}
-
 // l = sqrt(d), inv = 1/l.  fp32: one v_rsq_f32 (1 ulp) + one multiply instead of the IEEE sqrt and
 // divide sequences (~25 instructions on the critical path of every column); fp64 keeps the exact forms.
 __device__ __forceinline__ void pivot_sqrt(float d, float& l, float& inv) {
@@ -263,69 +233,20 @@ __device__ __forceinline__ void pivot_sqrt(double d, double& l, double& inv) {
   inv = 1.0 / l;
 }
 
-// Factor the 32x32 SPD block whose lower triangle sits in Ls[0..31][0..31] (row
-// stride CH_LD, 16-byte aligned rows), in place, with ONE wave; also leaves
-// L^T in LsT and 1/l_kk in invd for the row solves.
-//
-// Left-looking, fully unrolled.  Lane r owns row r: `a[k]` is its input entry,
-// `l[k]` its finished entries.  Step k forms column k,
-//     c_r = a_rk - sum_{j<k} l_rj * l_kj ,
-// where row k of L (the l_kj) is the same for every lane: entries 0..k-2 were
-// written to LDS at least two steps earlier and are fetched -- one step AHEAD,
-// so their latency is off the critical path -- with 16-byte uniform-address
-// reads (LDS broadcast -> VGPRs, no SGPR pressure); the newest entry l_{k,k-1}
-// comes by a single v_readlane from lane k.  The dot product runs on four
-// partial sums (a lone wave retires a dependent FMA only every ~8 cycles).
-// Returns k+1 of the first non-positive pivot (0 = ok).
 template <typename T>
-__device__ __forceinline__ int potrf32_lds(T (*Ls)[CH_LD], T (*LsT)[CH_LD], T* invd, int lane) {
-  constexpr int VEC = 16 / sizeof(T);
-  constexpr int NV = CH_NB / VEC;
-  typedef T VT __attribute__((ext_vector_type(VEC)));
-  const int r = lane & 31;
-  T a[CH_NB], l[CH_NB];
-#pragma unroll
-  for (int j = 0; j < CH_NB; j += VEC) {
-    const VT v = *reinterpret_cast<const VT*>(&Ls[r][j]);
-#pragma unroll
-    for (int q = 0; q < VEC; ++q) a[j + q] = v[q];
+__global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, long B, long M) {
+  const int Mi = (int)M;
+  const long total = B * M * M;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int rem = (int)(t % (M * M));
+    const int i = rem / Mi, j = rem - i * Mi;
+    if (j > i) L[t] = T(0);
   }
-  int fail = 0;
-  VT cur[NV], nxt[NV];
-#pragma unroll
-  for (int k = 0; k < CH_NB; ++k) {
-    T acc[4] = {a[k], T(0), T(0), T(0)};
-    if (k > 0) {
-      T lrow[CH_NB];
-#pragma unroll
-      for (int j = 0; j + 1 < k; j += VEC)
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) lrow[j + q] = cur[j / VEC][q];
-      lrow[k - 1] = bcast_lane(l[k - 1], k);
-#pragma unroll
-      for (int j = 0; j < k; ++j) acc[j & 3] -= l[j] * lrow[j];
-    }
-    // prefetch row k+1, entries 0..k-1 (all written by step k-1 at the latest; same-wave DS ops are ordered)
-    if (k + 1 < CH_NB) {
-#pragma unroll
-      for (int j = 0; j < k; j += VEC) nxt[j / VEC] = *reinterpret_cast<const VT*>(&Ls[k + 1][j]);
-    }
-    const T c = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    const T d = bcast_lane(c, k);
-    if (fail == 0 && !(d > T(0))) fail = k + 1;
-    T lkk, inv;
-    pivot_sqrt(d, lkk, inv);
-    l[k] = (r == k) ? lkk : c * inv;
-    if (lane < CH_NB) {
-      Ls[r][k] = l[k];
-      LsT[k][r] = l[k];
-      if (r == k) invd[k] = inv;
-    }
-#pragma unroll
-    for (int q = 0; q < NV; ++q) cur[q] = nxt[q];
-  }
-  return fail;
 }
+
+#define CH_NB 32
+#define CH_LD (CH_NB + 4)  // LDS row stride: keeps rows 16-byte aligned for vector reads
 
 // x L^T = t for one row per thread (x returned in t): right-looking forward
 // substitution, so the 31-k updates of step k are independent FMAs; column k
@@ -357,111 +278,296 @@ __device__ __forceinline__ void trsolve_row32(T (&t)[CH_NB], const T (*LsT)[CH_L
   }
 }
 
-template <typename T, bool FAST>
-__global__ void __launch_bounds__(256) chol_panel_kernel(const T* __restrict__ Ain, T* __restrict__ L, long M, long j0,
-                                                         int* __restrict__ info) {
-  typedef TileGemm<T, 128, 32, 32, 4, 1> G;
-  __shared__ T lds[G::LDS_ELEMS];
-  __shared__ __attribute__((aligned(16))) T Cs[128][CH_LD];
-  __shared__ __attribute__((aligned(16))) T LsT[CH_NB][CH_LD];
-  __shared__ __attribute__((aligned(16))) T invd[CH_NB];
-  const long b = blockIdx.y;
-  Ain += b * M * M;
-  L += b * M * M;
-  info += b;
-  const int Mi = (int)M, j0i = (int)j0;
-  const int nb = (Mi - j0i) < CH_NB ? (Mi - j0i) : CH_NB;
-  const int r0 = j0i + CH_NB + blockIdx.x * CH_RB;
-  auto rvalid = [&](int m) -> bool { return m < CH_NB ? m < nb : (r0 + (m - CH_NB)) < Mi; };
-  // global row of tile row m, clamped to a safe row when invalid
-  auto grow = [&](int m) -> int { return rvalid(m) ? (m < CH_NB ? j0i + m : r0 + (m - CH_NB)) : j0i; };
-  HB_STAMP(0);
-  G g;
-  g.zero();
-  auto la = [&](int m, int k) -> T { return L[grow(m) * Mi + k]; };
-  auto fa = [&](T raw, int m, int k) -> T { return rvalid(m) ? raw : T(0); };
-  auto lb = [&](int k, int n) -> T { return L[(j0i + (n < nb ? n : nb - 1)) * Mi + k]; };
-  auto fb = [&](T raw, int k, int n) -> T { return n < nb ? raw : T(0); };
-  if constexpr (FAST) {
-    typedef typename G::VT VT;
-    const VT zero = {};
-    auto la4 = [&](int m, int k) -> VT { return *reinterpret_cast<const VT*>(&L[grow(m) * Mi + k]); };
-    auto fa4 = [&](VT raw, int m, int k) -> VT { return rvalid(m) ? raw : zero; };
-    auto lb4 = [&](int k, int n) -> VT { return *reinterpret_cast<const VT*>(&L[(j0i + (n < nb ? n : nb - 1)) * Mi + k]); };
-    auto fb4 = [&](VT raw, int k, int n) -> VT { return n < nb ? raw : zero; };
-    g.template run_vec<HB_KC, HB_KC>(0, j0i, la4, fa4, lb4, fb4, lds);
-  } else {
-    g.template run<true, true>(0, j0i, la, fa, lb, fb, lds);
-  }
-  HB_STAMP(1);
-  g.for_each([&](int row, int col, T v) {
-    const bool ok = rvalid(row) && col < nb;
-    const T aval = Ain[(long)grow(row) * M + j0 + (col < nb ? col : nb - 1)];
-    T c = ok ? aval - v : T(0);
-    if (row < CH_NB && row >= nb && col == row) c = T(1);  // identity padding of a ragged last panel
-    Cs[row][col] = c;
-  });
-  __syncthreads();
-  HB_STAMP(2);
-  if (threadIdx.x < 64) {
-    const int fail = potrf32_lds<T>(Cs, LsT, invd, threadIdx.x);
-    // info: block 0 of every panel launch is its only writer; the first panel resets it
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      const int bad = (fail != 0 && fail <= nb) ? (int)(j0 + fail) : 0;
-      if (j0 == 0)
-        *info = bad;
-      else if (bad != 0 && *info == 0)
-        *info = bad;
-    }
-  }
-  __syncthreads();
-  HB_STAMP(3);
-  // panel rows: x L_jj^T = c
-  if (threadIdx.x < CH_RB) {
-    const int m = CH_NB + threadIdx.x;
-    const long r = (long)r0 + threadIdx.x;
-    if (r < M) {
-      constexpr int VEC = 16 / sizeof(T);
-      typedef T VT __attribute__((ext_vector_type(VEC)));
-      T xr[CH_NB];
-#pragma unroll
-      for (int c = 0; c < CH_NB; c += VEC) {
-        const VT v = *reinterpret_cast<const VT*>(&Cs[m][c]);
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) xr[c + q] = v[q];
-      }
-      trsolve_row32<T>(xr, LsT, invd);
-      T* dst = L + r * M + j0;
-      if (nb == CH_NB) {
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c) dst[c] = xr[c];
-      } else {
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c)
-          if (c < nb) dst[c] = xr[c];
-      }
-    }
-  }
-  HB_STAMP(4);
-  if (blockIdx.x == 0) {
-    // diagonal block, strict upper part zeroed (the rest of the upper triangle is cleared once, after the last panel)
-    for (int idx = threadIdx.x; idx < CH_NB * CH_NB; idx += blockDim.x) {
-      const int i = idx / CH_NB, j = idx % CH_NB;
-      if (i < nb && j < nb) L[(j0 + i) * M + j0 + j] = j <= i ? Cs[i][j] : T(0);
-    }
-  }
-  HB_STAMP(5);
+// ===========================================================================
+// Cholesky, right-looking: one launch per 32-column block k; every launch is
+// a single global-load round trip deep.
+//
+//   launch k:  every remaining tile (i, j >= k) takes the rank-32 update by
+//              panel k-1,  T_ij -= L[i, k-1] L[j, k-1]^T   (16 f32 MFMAs / wave,
+//              operands straight from global memory into MFMA fragments -- the
+//              contraction index is permuted so that each lane reads 64
+//              contiguous bytes);  the workgroups of block column k then factor
+//              it: the 32x32 diagonal block (recomputed by each of them, cheaper
+//              than a cross-workgroup hand-off) and 96 rows below it, stacked
+//              in LDS and processed in four 8-column steps:
+//                potrf8   8x8 diagonal block factored redundantly by every lane
+//                         in registers (no cross-lane traffic, no barriers);
+//                solve    one thread per row, 8 columns (28 FMAs);
+//                update   the remaining columns by rank-8 MFMA, accumulators
+//                         staying in registers across the four steps.
+//
+// The whole trailing matrix is rewritten by every launch (11 MB in total at
+// M = 512: noise), which spreads the O(M^3) work over all CUs and leaves
+// load -> 16 MFMAs -> potrf/solve -> store on the critical path of a launch
+// instead of a K = j0 deep contraction on four CUs (the left-looking form this
+// replaces: 17.4 us average per panel, profiles/r01_chol_panel_phase_stamps.txt).
+//
+// Storage: results go to L.  A tile is read from A on its first touch (k <= 1)
+// and from L afterwards.  Until its column is factored, a DIAGONAL tile (j, j)
+// lives in the unused upper tile (j-1, j): the factor workgroups of launch j all
+// read it while one of them writes the factored block to (j, j).  The upper
+// triangle is cleared by tril_inplace_kernel after the last launch.
+// ===========================================================================
+#define CR_B 32         // block size
+#define CR_ROWS 128     // stacked panel: diagonal block + 96 rows
+#define CR_LD 36        // LDS row stride (rows stay 16-byte aligned)
+#define CR_FROWS 96     // rows below the diagonal block per factor workgroup
+
+static inline int chol_rl_factor_strips(int nblk, int k) {
+  const int below = nblk - k - 1;
+  return below > 0 ? (below + 2) / 3 : 1;
+}
+static inline int chol_rl_grid(int nblk, int k) {
+  int g = chol_rl_factor_strips(nblk, k);
+  if (k > 0)
+    for (int j = k + 1; j < nblk; ++j) g += (nblk - j + 3) / 4;
+  return g;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, long B, long M) {
-  const int Mi = (int)M;
-  const long total = B * M * M;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int rem = (int)(t % (M * M));
-    const int i = rem / Mi, j = rem - i * Mi;
-    if (j > i) L[t] = T(0);
+template <typename T, bool FAST>
+__global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain, T* __restrict__ L, int M, int k,
+                                                      int* __restrict__ info) {
+  typedef Mma<T> MM;
+  constexpr int TM = MM::TM;        // 32 (f32) | 16 (f64)
+  constexpr int KH = 64 / TM;       // lanes groups along the contraction index: 2 | 4
+  constexpr int RT = CR_B / TM;     // MFMA tiles per 32: 1 | 2
+  constexpr int CK = CR_B / KH;     // contraction entries per lane, rank-32 update: 16 | 8   (64 bytes)
+  constexpr int PK = 8 / KH;        // contraction entries per lane, rank-8 update:   4 | 2   (16 bytes)
+  constexpr int VEC = 16 / (int)sizeof(T);
+  typedef T VT __attribute__((ext_vector_type(VEC)));
+  __shared__ __attribute__((aligned(16))) T Cs[CR_ROWS][CR_LD];
+
+  const long boff = (long)blockIdx.y * M * M;
+  Ain += boff;
+  L += boff;
+  info += blockIdx.y;
+  const int nblk = (M + CR_B - 1) / CR_B;
+  // workgroup -> (block column j, strip s)
+  int j = k, s = blockIdx.x;
+  {
+    const int below = nblk - k - 1;
+    int cnt = below > 0 ? (below + 2) / 3 : 1;
+    while (s >= cnt) {
+      s -= cnt;
+      ++j;
+      cnt = (nblk - j + 3) / 4;
+    }
+  }
+  const bool factor = (j == k);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane % TM, h = lane / TM;
+  int bi = factor ? (w == 0 ? k : k + 1 + 3 * s + (w - 1)) : j + 4 * s + w;
+  const bool live = bi < nblk;
+  bi = live ? bi : nblk - 1;
+  const int Mm1 = M - 1;
+  const int row0 = bi * CR_B, col0 = j * CR_B;
+  // where this tile currently lives (see "Storage" above)
+  const T* src = (k <= 1) ? Ain : L;
+  const int hrow0 = (k >= 2 && bi == j) ? (j - 1) * CR_B : row0;
+
+  typename MM::Acc acc[RT][RT];
+#pragma unroll
+  for (int si = 0; si < RT; ++si)
+#pragma unroll
+    for (int sj = 0; sj < RT; ++sj)
+#pragma unroll
+      for (int r = 0; r < MM::NACC; ++r) {
+        const int tr = si * TM + MM::acc_row(lane, r), tc = sj * TM + MM::acc_col(lane);
+        int gr = hrow0 + tr, gc = col0 + tc;
+        if (!FAST) {
+          // clamp by the TRUE row (the home of a diagonal tile is shifted up by one block)
+          gr = (row0 + tr) < M ? gr : hrow0 + (Mm1 - row0);
+          gc = gc < M ? gc : Mm1;
+        }
+        acc[si][sj][r] = src[gr * M + gc];
+      }
+
+  if (k > 0) {
+    // rank-32 update by panel k-1; lane (li, h) contracts over entries [h*CK, (h+1)*CK) of the panel row
+    const int pc = (k - 1) * CR_B + h * CK;
+    T a[RT][CK], bq[RT][CK];
+#pragma unroll
+    for (int si = 0; si < RT; ++si) {
+      int ra = row0 + si * TM + li, rb = col0 + si * TM + li;
+      if (!FAST) {
+        ra = ra < M ? ra : Mm1;
+        rb = rb < M ? rb : Mm1;
+      }
+      const T* pa = L + ra * M + pc;
+      const T* pb = L + rb * M + pc;
+      if (FAST) {
+#pragma unroll
+        for (int q = 0; q < CK; q += VEC) {
+          const VT va = *reinterpret_cast<const VT*>(pa + q);
+          const VT vb = *reinterpret_cast<const VT*>(pb + q);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            a[si][q + e] = -va[e];
+            bq[si][q + e] = vb[e];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < CK; ++q) {
+          a[si][q] = -pa[q];
+          bq[si][q] = pb[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CK; ++q)
+#pragma unroll
+      for (int si = 0; si < RT; ++si)
+#pragma unroll
+        for (int sj = 0; sj < RT; ++sj) acc[si][sj] = MM::mma(a[si][q], bq[sj][q], acc[si][sj]);
+  }
+
+  if (!factor) {
+    if (live) {
+#pragma unroll
+      for (int si = 0; si < RT; ++si)
+#pragma unroll
+        for (int sj = 0; sj < RT; ++sj)
+#pragma unroll
+          for (int r = 0; r < MM::NACC; ++r) {
+            const int tr = si * TM + MM::acc_row(lane, r), tc = sj * TM + MM::acc_col(lane);
+            if (FAST || ((row0 + tr) < M && (col0 + tc) < M)) {
+              const int wr = (bi == j ? (j - 1) * CR_B : row0) + tr;
+              L[wr * M + col0 + tc] = acc[si][sj][r];
+            }
+          }
+    }
+    return;
+  }
+
+  // ---- factor block column k: stacked panel rows [32w, 32w+32) belong to wave w ----
+  const int nb = (M - k * CR_B) < CR_B ? (M - k * CR_B) : CR_B;
+  int fail = 0;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    // publish columns [8kb, 8kb+8) of the accumulators
+#pragma unroll
+    for (int si = 0; si < RT; ++si)
+#pragma unroll
+      for (int sj = 0; sj < RT; ++sj) {
+        const int tc = sj * TM + MM::acc_col(lane);
+        if ((tc >> 3) == kb) {
+#pragma unroll
+          for (int r = 0; r < MM::NACC; ++r) {
+            const int tr = si * TM + MM::acc_row(lane, r);
+            T v = acc[si][sj][r];
+            if (!FAST && w == 0 && (tr >= nb || tc >= nb)) v = (tr == tc) ? T(1) : T(0);  // identity padding
+            Cs[w * CR_B + tr][tc] = v;
+          }
+        }
+      }
+    __syncthreads();
+    // potrf8: every lane (of the two waves that own rows) factors the 8x8 diagonal block
+    // Cs[8kb.., 8kb..] in registers
+    if (tid < CR_ROWS) {
+    T p[8][8], pinv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int q = 0; q < 8; q += VEC) {
+        const VT v = *reinterpret_cast<const VT*>(&Cs[8 * kb + i][8 * kb + q]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) p[i][q + e] = v[e];
+      }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const T d = p[c][c];
+      if (fail == 0 && !(d > T(0))) fail = 8 * kb + c + 1;
+      T lcc, inv;
+      pivot_sqrt(d, lcc, inv);
+      p[c][c] = lcc;
+      pinv[c] = inv;
+#pragma unroll
+      for (int i = c + 1; i < 8; ++i) p[i][c] *= inv;
+#pragma unroll
+      for (int c2 = c + 1; c2 < 8; ++c2)
+#pragma unroll
+        for (int i = c2; i < 8; ++i) p[i][c2] -= p[i][c] * p[c2][c];
+    }
+    // solve: thread t owns stacked row t;  x L_kk^T = c  over the 8 columns of this step
+    {
+      T x[8];
+#pragma unroll
+      for (int q = 0; q < 8; q += VEC) {
+        const VT v = *reinterpret_cast<const VT*>(&Cs[tid][8 * kb + q]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x[q + e] = v[e];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        T t = x[c];
+#pragma unroll
+        for (int i = 0; i < c; ++i) t -= x[i] * p[c][i];
+        x[c] = t * pinv[c];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q += VEC) {
+        VT v;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = x[q + e];
+        *reinterpret_cast<VT*>(&Cs[tid][8 * kb + q]) = v;
+      }
+    }
+    }
+    __syncthreads();
+    if (kb < 3) {
+      // rank-8 update of the columns to the right: acc -= X[:, 8kb:8kb+8] X_D[cols, 8kb:8kb+8]^T
+      T a2[RT][PK], b2[RT][PK];
+#pragma unroll
+      for (int si = 0; si < RT; ++si) {
+        const VT va = *reinterpret_cast<const VT*>(&Cs[w * CR_B + si * TM + li][8 * kb + h * PK]);
+        const int dr = si * TM + li;  // row of the diagonal block = column of the panel
+        const VT vb = *reinterpret_cast<const VT*>(&Cs[dr][8 * kb + h * PK]);
+        const bool right = dr >= 8 * (kb + 1);
+        static_assert(PK % VEC == 0 || VEC % PK == 0, "fragment chunk");
+#pragma unroll
+        for (int e = 0; e < PK; ++e) {
+          a2[si][e] = -va[e];
+          b2[si][e] = right ? vb[e] : T(0);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < PK; ++e)
+#pragma unroll
+        for (int si = 0; si < RT; ++si)
+#pragma unroll
+          for (int sj = 0; sj < RT; ++sj) acc[si][sj] = MM::mma(a2[si][e], b2[sj][e], acc[si][sj]);
+    }
+  }
+  if (s == 0 && tid == 0) {
+    // block 0 of the factor column is the only writer of info; launch 0 resets it
+    const int bad = (fail != 0 && fail <= nb) ? k * CR_B + fail : 0;
+    if (k == 0)
+      *info = bad;
+    else if (bad != 0 && *info == 0)
+      *info = bad;
+  }
+  // store the stacked panel: diagonal block (strip 0 only, strict upper part zero) + this strip's rows
+  constexpr int VPR = CR_B / VEC;  // 16-byte groups per row
+  for (int idx = tid; idx < CR_ROWS * VPR; idx += 256) {
+    const int pr = idx / VPR, c = (idx % VPR) * VEC;
+    const bool diag = pr < CR_B;
+    const int gr = diag ? k * CR_B + pr : (k + 1) * CR_B + CR_FROWS * s + (pr - CR_B);
+    if (diag ? (s != 0 || pr >= nb) : gr >= M) continue;
+    VT v = *reinterpret_cast<const VT*>(&Cs[pr][c]);
+    if (diag) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (c + e > pr) v[e] = T(0);
+    }
+    T* dst = L + gr * M + k * CR_B + c;
+    if (FAST) {
+      *reinterpret_cast<VT*>(dst) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (c + e < nb) dst[e] = v[e];
+    }
   }
 }
 
@@ -476,22 +582,24 @@ static int cholesky_launch(const T* A, T* L, long B, long M, int* info, hipStrea
     HB_HIP(hb_zero_async(info, sizeof(int) * B, stream));
     return 0;
   }
-  const bool fast = ((uintptr_t)L % 16 == 0) && M % (16 / (long)sizeof(T)) == 0;
-  for (long j0 = 0; j0 < M; j0 += CH_NB) {
-    const long below = M - j0 - CH_NB;
-    const int gx = below > 0 ? hb_cdiv(below, CH_RB) : 1;
-    if (fast)
-      hipLaunchKernelGGL((chol_panel_kernel<T, true>), dim3(gx, (unsigned)B), dim3(256), 0, stream, A, L, M, j0, info);
-    else
-      hipLaunchKernelGGL((chol_panel_kernel<T, false>), dim3(gx, (unsigned)B), dim3(256), 0, stream, A, L, M, j0, info);
-    HB_LAUNCH_CHECK();
-  }
-  if (M > CH_NB) {
+  HB_REQUIRE((const void*)A != (const void*)L, "hb_cholesky: A and L must not alias");
+  {
+    const int nblk = hb_cdiv(M, CR_B);
+    const bool fast = ((uintptr_t)L % 16 == 0) && ((uintptr_t)A % 16 == 0) && M % CR_B == 0;
+    for (int k = 0; k < nblk; ++k) {
+      dim3 grid((unsigned)chol_rl_grid(nblk, k), (unsigned)B);
+      if (fast)
+        hipLaunchKernelGGL((chol_rl_kernel<T, true>), grid, dim3(256), 0, stream, A, L, (int)M, k, info);
+      else
+        hipLaunchKernelGGL((chol_rl_kernel<T, false>), grid, dim3(256), 0, stream, A, L, (int)M, k, info);
+      HB_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, B, M);
     HB_LAUNCH_CHECK();
+    return 0;
   }
-  return 0;
 }
+
 extern "C" int hb_cholesky_f32(const float* A, float* L, long B, long M, int* info, void* stream) {
   return cholesky_launch<float>(A, L, B, M, info, (hipStream_t)stream);
 }

@@ -435,6 +435,12 @@ def cholesky(A, out=None, info=None):
         out = _empty_like(A)
     if info is None:
         info = _empty(max(B, 1), dtype=torch.int32, device=A.device)
+    if out.data_ptr() == A.data_ptr() and A.numel():
+        # the C entry point forbids aliasing; in-place requests go through a copy (eager use only)
+        tmp = _empty_like(A)
+        _lib.lib().call("hb_cholesky" + _suf(A), _p(A), _p(tmp), B, M, _p(info), stream())
+        ewise("COPY", [tmp], out=out)
+        return out, info
     _lib.lib().call("hb_cholesky" + _suf(A), _p(A), _p(out), B, M, _p(info), stream())
     return out, info
 

@@ -219,7 +219,9 @@ int hb_matmul_f64(const double* A, const double* B, double* C, long batch, long 
 
 /* K4: L = chol(A), lower, batched [B,M,M]; the strict upper triangle of L is
  * zeroed; info[B] (device) receives 0 or k+1.  Replaces tf.cholesky
- * (reference gp/kernels.py:101; gp/gp.py:135).  A and L may alias. */
+ * (reference gp/kernels.py:101; gp/gp.py:135).  A and L must NOT alias (workgroups
+ * re-read diagonal tiles of A while L is being written); only the lower triangle
+ * of A is significant beyond its diagonal tiles. */
 int hb_cholesky_f32(const float* A, float* L, long B, long M, int* info, void* stream);
 int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void* stream);
 /* W = L^{-1} (lower triangular inverse), batched.  Used in place of
