@@ -55,6 +55,7 @@ _TYPED = {
     "hb_gram_bwd": [I, P, L, P, L, P, L, L, P, P, P, P, L, L, L, L, P, P],
     "hb_matmul": [P, P, P, L, L, L, L, L, L, L, L, L, L, I, I, D, D, P, L, I, I, P, L, P],
     "hb_cholesky": [P, P, L, L, P, P],
+    "hb_cholesky_inverse": [P, P, P, L, L, P, P, P],
     "hb_trinv": [P, P, L, L, P, P],
     "hb_sgp_A": [I, P, L, P, P, L, P, P, L, L, L, L, P],
     "hb_sgp_fwd": [I, I, P, L, P, P, L, P, P, P, P, L, P, P, P, P, L, L, L, L, L, P, P],

@@ -234,14 +234,17 @@ __device__ __forceinline__ void pivot_sqrt(double d, double& l, double& inv) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, long B, long M) {
+__global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, T* __restrict__ W, long B, long M) {
   const int Mi = (int)M;
   const long total = B * M * M;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const int rem = (int)(t % (M * M));
     const int i = rem / Mi, j = rem - i * Mi;
-    if (j > i) L[t] = T(0);
+    if (j > i) {
+      L[t] = T(0);
+      if (W) W[t] = T(0);
+    }
   }
 }
 
@@ -313,23 +316,38 @@ __device__ __forceinline__ void trsolve_row32(T (&t)[CH_NB], const T (*LsT)[CH_L
 #define CR_LD 36        // LDS row stride (rows stay 16-byte aligned)
 #define CR_FROWS 96     // rows below the diagonal block per factor workgroup
 
-static inline int chol_rl_factor_strips(int nblk, int k) {
-  const int below = nblk - k - 1;
-  return below > 0 ? (below + 2) / 3 : 1;
+// Tile lists of launch k (inv: the inverse rides along, see below).
+//   factor column k : wave 0 of every workgroup takes the diagonal block; the other three
+//                     waves walk  [A blocks k+1 .. nblk-1] ++ [Y blocks 0 .. k]
+//   update column j : four waves walk  [A blocks j .. nblk-1] ++ [Y blocks 0 .. k-1]
+static inline int chol_rl_factor_strips(int nblk, int k, int inv) {
+  const int n = (nblk - k - 1) + (inv ? k + 1 : 0);
+  return n > 0 ? (n + 2) / 3 : 1;
 }
-static inline int chol_rl_grid(int nblk, int k) {
-  int g = chol_rl_factor_strips(nblk, k);
+static inline int chol_rl_grid(int nblk, int k, int inv) {
+  int g = chol_rl_factor_strips(nblk, k, inv);
   if (k > 0)
-    for (int j = k + 1; j < nblk; ++j) g += (nblk - j + 3) / 4;
+    for (int j = k + 1; j < nblk; ++j) g += (nblk - j + (inv ? k : 0) + 3) / 4;
   return g;
 }
 
+// The inverse for free: run the same elimination on the stacked matrix [A; I].
+// Its lower half converges to Y = L^-T (block recurrence
+//   Y_ck = (I_ck - sum_{j<k} Y_cj L_kj^T) L_kk^-T ),
+// i.e. the rows of the identity are just more rows "below the diagonal block":
+// they take the same rank-32 updates (a-operand from Y instead of L) and the
+// same in-LDS solves.  Y is upper block-triangular: block row c joins at launch
+// c (tile (c,c) starts as I) and tile (c,j) is first touched -- from zero -- at
+// launch c+1.  The working copy Y lives in a caller workspace (row-major, so the
+// update operands stay 64-byte contiguous per lane); every finished panel is also
+// written transposed into W = L^-1.  All of it is extra width per launch, none of
+// it is on the critical path, and hb_trinv's ten dependent launches disappear.
 template <typename T, bool FAST>
-__global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain, T* __restrict__ L, int M, int k,
-                                                      int* __restrict__ info) {
+__global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain, T* __restrict__ L, T* __restrict__ Y,
+                                                      T* __restrict__ W, int M, int k, int* __restrict__ info) {
   typedef Mma<T> MM;
   constexpr int TM = MM::TM;        // 32 (f32) | 16 (f64)
-  constexpr int KH = 64 / TM;       // lanes groups along the contraction index: 2 | 4
+  constexpr int KH = 64 / TM;       // lane groups along the contraction index: 2 | 4
   constexpr int RT = CR_B / TM;     // MFMA tiles per 32: 1 | 2
   constexpr int CK = CR_B / KH;     // contraction entries per lane, rank-32 update: 16 | 8   (64 bytes)
   constexpr int PK = 8 / KH;        // contraction entries per lane, rank-8 update:   4 | 2   (16 bytes)
@@ -340,51 +358,77 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
   const long boff = (long)blockIdx.y * M * M;
   Ain += boff;
   L += boff;
+  const bool inv = Y != nullptr;
+  if (inv) {
+    Y += boff;
+    W += boff;
+  }
   info += blockIdx.y;
   const int nblk = (M + CR_B - 1) / CR_B;
   // workgroup -> (block column j, strip s)
   int j = k, s = blockIdx.x;
   {
-    const int below = nblk - k - 1;
-    int cnt = below > 0 ? (below + 2) / 3 : 1;
+    const int nf = (nblk - k - 1) + (inv ? k + 1 : 0);
+    int cnt = nf > 0 ? (nf + 2) / 3 : 1;
     while (s >= cnt) {
       s -= cnt;
       ++j;
-      cnt = (nblk - j + 3) / 4;
+      cnt = (nblk - j + (inv ? k : 0) + 3) / 4;
     }
   }
   const bool factor = (j == k);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane % TM, h = lane / TM;
-  int bi = factor ? (w == 0 ? k : k + 1 + 3 * s + (w - 1)) : j + 4 * s + w;
-  const bool live = bi < nblk;
-  bi = live ? bi : nblk - 1;
+  // entry g of this workgroup's tile list -> (live, is a Y tile, block row)
+  auto describe = [&](int g, bool& live_, bool& yt_, int& rb_) {
+    const int nA = factor ? nblk - k - 1 : nblk - j;
+    const int nY = inv ? (factor ? k + 1 : k) : 0;
+    const int e = factor ? 3 * s + g - 1 : 4 * s + g;
+    if (factor && g == 0) {
+      live_ = true, yt_ = false, rb_ = k;
+    } else if (e < nA) {
+      live_ = true, yt_ = false, rb_ = (factor ? k + 1 : j) + e;
+    } else if (e < nA + nY) {
+      live_ = true, yt_ = true, rb_ = e - nA;
+    } else {
+      live_ = false, yt_ = false, rb_ = nblk - 1;  // idle wave: recompute a valid tile, store nothing
+    }
+  };
+  bool live, yt;
+  int bi;
+  describe(w, live, yt, bi);
   const int Mm1 = M - 1;
   const int row0 = bi * CR_B, col0 = j * CR_B;
-  // where this tile currently lives (see "Storage" above)
-  const T* src = (k <= 1) ? Ain : L;
-  const int hrow0 = (k >= 2 && bi == j) ? (j - 1) * CR_B : row0;
+  const bool ydiag = yt && bi == j;  // tile (k,k) of Y: starts as the identity, takes no update
 
   typename MM::Acc acc[RT][RT];
+  {
+    // where the tile currently lives: A on first touch (k <= 1), then L -- a diagonal tile one block up -- or Y
+    const T* src = yt ? Y : ((k <= 1) ? Ain : L);
+    const int hrow0 = (!yt && k >= 2 && bi == j) ? (j - 1) * CR_B : row0;
+    const bool fresh = yt && (ydiag || k == bi + 1);
 #pragma unroll
-  for (int si = 0; si < RT; ++si)
+    for (int si = 0; si < RT; ++si)
 #pragma unroll
-    for (int sj = 0; sj < RT; ++sj)
+      for (int sj = 0; sj < RT; ++sj)
 #pragma unroll
-      for (int r = 0; r < MM::NACC; ++r) {
-        const int tr = si * TM + MM::acc_row(lane, r), tc = sj * TM + MM::acc_col(lane);
-        int gr = hrow0 + tr, gc = col0 + tc;
-        if (!FAST) {
-          // clamp by the TRUE row (the home of a diagonal tile is shifted up by one block)
-          gr = (row0 + tr) < M ? gr : hrow0 + (Mm1 - row0);
-          gc = gc < M ? gc : Mm1;
+        for (int r = 0; r < MM::NACC; ++r) {
+          const int tr = si * TM + MM::acc_row(lane, r), tc = sj * TM + MM::acc_col(lane);
+          int gr = hrow0 + tr, gc = col0 + tc;
+          if (!FAST) {
+            // clamp by the TRUE row (the home of a diagonal tile is shifted up by one block)
+            gr = (row0 + tr) < M ? gr : hrow0 + (Mm1 - row0);
+            gc = gc < M ? gc : Mm1;
+          }
+          const T init = (ydiag && tr == tc) ? T(1) : T(0);
+          acc[si][sj][r] = fresh ? init : src[gr * M + gc];
         }
-        acc[si][sj][r] = src[gr * M + gc];
-      }
+  }
 
-  if (k > 0) {
+  if (k > 0 && !ydiag) {
     // rank-32 update by panel k-1; lane (li, h) contracts over entries [h*CK, (h+1)*CK) of the panel row
     const int pc = (k - 1) * CR_B + h * CK;
+    const T* asrc = yt ? Y : L;
     T a[RT][CK], bq[RT][CK];
 #pragma unroll
     for (int si = 0; si < RT; ++si) {
@@ -393,7 +437,7 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
         ra = ra < M ? ra : Mm1;
         rb = rb < M ? rb : Mm1;
       }
-      const T* pa = L + ra * M + pc;
+      const T* pa = asrc + ra * M + pc;
       const T* pb = L + rb * M + pc;
       if (FAST) {
 #pragma unroll
@@ -424,6 +468,8 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
 
   if (!factor) {
     if (live) {
+      T* dst = yt ? Y : L;
+      const int wrow0 = (!yt && bi == j) ? (j - 1) * CR_B : row0;
 #pragma unroll
       for (int si = 0; si < RT; ++si)
 #pragma unroll
@@ -431,10 +477,7 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
 #pragma unroll
           for (int r = 0; r < MM::NACC; ++r) {
             const int tr = si * TM + MM::acc_row(lane, r), tc = sj * TM + MM::acc_col(lane);
-            if (FAST || ((row0 + tr) < M && (col0 + tc) < M)) {
-              const int wr = (bi == j ? (j - 1) * CR_B : row0) + tr;
-              L[wr * M + col0 + tc] = acc[si][sj][r];
-            }
+            if (FAST || ((row0 + tr) < M && (col0 + tc) < M)) dst[(wrow0 + tr) * M + col0 + tc] = acc[si][sj][r];
           }
     }
     return;
@@ -462,35 +505,34 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
         }
       }
     __syncthreads();
-    // potrf8: every lane (of the two waves that own rows) factors the 8x8 diagonal block
-    // Cs[8kb.., 8kb..] in registers
     if (tid < CR_ROWS) {
-    T p[8][8], pinv[8];
+      // potrf8: every lane (of the two waves that own rows) factors the 8x8 diagonal block
+      // Cs[8kb.., 8kb..] in registers: no cross-lane traffic, no barriers
+      T p[8][8], pinv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int q = 0; q < 8; q += VEC) {
-        const VT v = *reinterpret_cast<const VT*>(&Cs[8 * kb + i][8 * kb + q]);
+        for (int q = 0; q < 8; q += VEC) {
+          const VT v = *reinterpret_cast<const VT*>(&Cs[8 * kb + i][8 * kb + q]);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) p[i][q + e] = v[e];
+          for (int e = 0; e < VEC; ++e) p[i][q + e] = v[e];
+        }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const T d = p[c][c];
+        if (fail == 0 && !(d > T(0))) fail = 8 * kb + c + 1;
+        T lcc, pi;
+        pivot_sqrt(d, lcc, pi);
+        p[c][c] = lcc;
+        pinv[c] = pi;
+#pragma unroll
+        for (int i = c + 1; i < 8; ++i) p[i][c] *= pi;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 8; ++c2)
+#pragma unroll
+          for (int i = c2; i < 8; ++i) p[i][c2] -= p[i][c] * p[c2][c];
       }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const T d = p[c][c];
-      if (fail == 0 && !(d > T(0))) fail = 8 * kb + c + 1;
-      T lcc, inv;
-      pivot_sqrt(d, lcc, inv);
-      p[c][c] = lcc;
-      pinv[c] = inv;
-#pragma unroll
-      for (int i = c + 1; i < 8; ++i) p[i][c] *= inv;
-#pragma unroll
-      for (int c2 = c + 1; c2 < 8; ++c2)
-#pragma unroll
-        for (int i = c2; i < 8; ++i) p[i][c2] -= p[i][c] * p[c2][c];
-    }
-    // solve: thread t owns stacked row t;  x L_kk^T = c  over the 8 columns of this step
-    {
+      // solve: thread t owns stacked row t;  x L_kk^T = c  over the 8 columns of this step
       T x[8];
 #pragma unroll
       for (int q = 0; q < 8; q += VEC) {
@@ -500,10 +542,10 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        T t = x[c];
+        T tt = x[c];
 #pragma unroll
-        for (int i = 0; i < c; ++i) t -= x[i] * p[c][i];
-        x[c] = t * pinv[c];
+        for (int i = 0; i < c; ++i) tt -= x[i] * p[c][i];
+        x[c] = tt * pinv[c];
       }
 #pragma unroll
       for (int q = 0; q < 8; q += VEC) {
@@ -513,18 +555,17 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
         *reinterpret_cast<VT*>(&Cs[tid][8 * kb + q]) = v;
       }
     }
-    }
     __syncthreads();
     if (kb < 3) {
       // rank-8 update of the columns to the right: acc -= X[:, 8kb:8kb+8] X_D[cols, 8kb:8kb+8]^T
       T a2[RT][PK], b2[RT][PK];
 #pragma unroll
       for (int si = 0; si < RT; ++si) {
-        const VT va = *reinterpret_cast<const VT*>(&Cs[w * CR_B + si * TM + li][8 * kb + h * PK]);
         const int dr = si * TM + li;  // row of the diagonal block = column of the panel
-        const VT vb = *reinterpret_cast<const VT*>(&Cs[dr][8 * kb + h * PK]);
         const bool right = dr >= 8 * (kb + 1);
-        static_assert(PK % VEC == 0 || VEC % PK == 0, "fragment chunk");
+        static_assert(PK == VEC, "one 16-byte LDS read per fragment");
+        const VT va = *reinterpret_cast<const VT*>(&Cs[w * CR_B + si * TM + li][8 * kb + h * PK]);
+        const VT vb = *reinterpret_cast<const VT*>(&Cs[dr][8 * kb + h * PK]);
 #pragma unroll
         for (int e = 0; e < PK; ++e) {
           a2[si][e] = -va[e];
@@ -547,34 +588,48 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
     else if (bad != 0 && *info == 0)
       *info = bad;
   }
-  // store the stacked panel: diagonal block (strip 0 only, strict upper part zero) + this strip's rows
+  // store the stacked panel, 32 rows (one wave's tile) at a time
   constexpr int VPR = CR_B / VEC;  // 16-byte groups per row
-  for (int idx = tid; idx < CR_ROWS * VPR; idx += 256) {
-    const int pr = idx / VPR, c = (idx % VPR) * VEC;
-    const bool diag = pr < CR_B;
-    const int gr = diag ? k * CR_B + pr : (k + 1) * CR_B + CR_FROWS * s + (pr - CR_B);
-    if (diag ? (s != 0 || pr >= nb) : gr >= M) continue;
-    VT v = *reinterpret_cast<const VT*>(&Cs[pr][c]);
-    if (diag) {
+#pragma unroll 1
+  for (int g = 0; g < 4; ++g) {
+    bool glive, gy;
+    int gb;
+    describe(g, glive, gy, gb);
+    if (!glive || (g == 0 && s != 0)) continue;  // the diagonal block is written by strip 0 only
+    for (int idx = tid; idx < CR_B * VPR; idx += 256) {
+      const int pr = idx / VPR, c = (idx % VPR) * VEC;
+      const int gr = gb * CR_B + pr;
+      if (gr >= M) continue;
+      VT v = *reinterpret_cast<const VT*>(&Cs[g * CR_B + pr][c]);
+      if (g == 0) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        if (c + e > pr) v[e] = T(0);
+        for (int e = 0; e < VEC; ++e)
+          if (c + e > pr) v[e] = T(0);  // strict upper part of the diagonal block
+      }
+      T* dst = (gy ? Y : L) + gr * M + k * CR_B + c;
+      if (FAST) {
+        *reinterpret_cast<VT*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (c + e < nb) dst[e] = v[e];
+      }
     }
-    T* dst = L + gr * M + k * CR_B + c;
-    if (FAST) {
-      *reinterpret_cast<VT*>(dst) = v;
-    } else {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        if (c + e < nb) dst[e] = v[e];
+    if (gy) {
+      // the finished panel of Y = L^-T, transposed into W = L^-1:  W[32k + c][32 gb + r] = Y[32 gb + r][32k + c]
+      for (int idx = tid; idx < CR_B * CR_B; idx += 256) {
+        const int r = idx % CR_B, c = idx / CR_B;
+        if (c < nb && gb * CR_B + r < M) W[(k * CR_B + c) * M + gb * CR_B + r] = Cs[g * CR_B + r][c];
+      }
     }
   }
 }
 
 template <typename T>
-static int cholesky_launch(const T* A, T* L, long B, long M, int* info, hipStream_t stream) {
+static int cholesky_launch(const T* A, T* L, T* W, T* ws, long B, long M, int* info, hipStream_t stream) {
   HB_REQUIRE(B >= 0 && M >= 0, "hb_cholesky: negative extent");
   HB_REQUIRE(A && L && info, "hb_cholesky: NULL pointer");
+  HB_REQUIRE(!W || ws, "hb_cholesky_inverse: workspace of B*M*M elements required");
   HB_REQUIRE(B <= 65535, "hb_cholesky: batch too large");
   HB_REQUIRE(M * M < 2147483647L, "hb_cholesky: matrix too large for 32-bit indexing");
   if (B == 0) return 0;
@@ -582,29 +637,41 @@ static int cholesky_launch(const T* A, T* L, long B, long M, int* info, hipStrea
     HB_HIP(hb_zero_async(info, sizeof(int) * B, stream));
     return 0;
   }
-  HB_REQUIRE((const void*)A != (const void*)L, "hb_cholesky: A and L must not alias");
-  {
-    const int nblk = hb_cdiv(M, CR_B);
-    const bool fast = ((uintptr_t)L % 16 == 0) && ((uintptr_t)A % 16 == 0) && M % CR_B == 0;
-    for (int k = 0; k < nblk; ++k) {
-      dim3 grid((unsigned)chol_rl_grid(nblk, k), (unsigned)B);
-      if (fast)
-        hipLaunchKernelGGL((chol_rl_kernel<T, true>), grid, dim3(256), 0, stream, A, L, (int)M, k, info);
-      else
-        hipLaunchKernelGGL((chol_rl_kernel<T, false>), grid, dim3(256), 0, stream, A, L, (int)M, k, info);
-      HB_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, B, M);
+  HB_REQUIRE((const void*)A != (const void*)L && (const void*)A != (const void*)W && (const void*)L != (const void*)W,
+             "hb_cholesky: A, L (and W) must not alias");
+  const int inv = W != nullptr;
+  const int nblk = hb_cdiv(M, CR_B);
+  const bool fast = ((uintptr_t)L % 16 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)ws % 16 == 0) && M % CR_B == 0;
+  for (int k = 0; k < nblk; ++k) {
+    dim3 grid((unsigned)chol_rl_grid(nblk, k, inv), (unsigned)B);
+    if (fast)
+      hipLaunchKernelGGL((chol_rl_kernel<T, true>), grid, dim3(256), 0, stream, A, L, inv ? ws : (T*)nullptr, W, (int)M, k,
+                         info);
+    else
+      hipLaunchKernelGGL((chol_rl_kernel<T, false>), grid, dim3(256), 0, stream, A, L, inv ? ws : (T*)nullptr, W, (int)M,
+                         k, info);
     HB_LAUNCH_CHECK();
-    return 0;
   }
+  hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, B, M);
+  HB_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int hb_cholesky_f32(const float* A, float* L, long B, long M, int* info, void* stream) {
-  return cholesky_launch<float>(A, L, B, M, info, (hipStream_t)stream);
+  return cholesky_launch<float>(A, L, nullptr, nullptr, B, M, info, (hipStream_t)stream);
 }
 extern "C" int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void* stream) {
-  return cholesky_launch<double>(A, L, B, M, info, (hipStream_t)stream);
+  return cholesky_launch<double>(A, L, nullptr, nullptr, B, M, info, (hipStream_t)stream);
+}
+extern "C" int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long B, long M, int* info, float* ws,
+                                       void* stream) {
+  HB_REQUIRE(W, "hb_cholesky_inverse: NULL pointer");
+  return cholesky_launch<float>(A, L, W, ws, B, M, info, (hipStream_t)stream);
+}
+extern "C" int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info, double* ws,
+                                       void* stream) {
+  HB_REQUIRE(W, "hb_cholesky_inverse: NULL pointer");
+  return cholesky_launch<double>(A, L, W, ws, B, M, info, (hipStream_t)stream);
 }
 
 // ===========================================================================

@@ -831,6 +831,15 @@ def _cholesky_emit(plan, node):
     a, out = plan.buf(node.inputs[0]), plan.out(node.outputs[0])
     B = int(np.prod(node.outputs[0].shape[:-2])) if len(node.outputs[0].shape) > 2 else 1
     info = plan.new_info(B, "cholesky#%d" % node.id)
+    # trinv(cholesky(a)) -- SparseGP's whitening, the Cholesky VJP -- is lowered to the fused
+    # factor+inverse launches: the inverse rides along for free (csrc/linalg.hip)
+    inv_node = next((c for c in plan._consumers.get(node.outputs[0], ()) if c.op == "trinv"), None)
+    if inv_node is not None and a.data_ptr() != out.data_ptr():
+        w = plan.out(inv_node.outputs[0])
+        ws = plan.scratch((max(int(np.prod(node.outputs[0].shape)), 1),))
+        plan._fused_trinv.add(inv_node.id)
+        plan.steps.append(lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws))
+        return
     plan.steps.append(lambda: H.cholesky(a, out=out, info=info))
 
 
@@ -865,9 +874,14 @@ def _trinv_vjp(node, gs):
     return [band_part(unary("NEG", t), -1, 0)]
 
 
-defop("trinv", lambda plan, node: plan.steps.append(
-    (lambda H, l, o: (lambda: H.trinv(l, out=o)))(plan.H, plan.buf(node.inputs[0]), plan.out(node.outputs[0]))),
-      _trinv_vjp)
+def _trinv_emit(plan, node):
+    if node.id in plan._fused_trinv:
+        return  # produced by the fused cholesky+inverse step
+    H, l, o = plan.H, plan.buf(node.inputs[0]), plan.out(node.outputs[0])
+    plan.steps.append(lambda: H.trinv(l, out=o))
+
+
+defop("trinv", _trinv_emit, _trinv_vjp)
 
 
 def triangular_solve(L, b, lower=True, adjoint=False) -> Tensor:
@@ -1340,6 +1354,7 @@ class Plan:
         for t in self.outputs:
             self._needed.add(t)
         self._extra_copies = []
+        self._fused_trinv = set()
         for t, b in (binds or []):
             self._prebind(t, b)
         if prologue:

@@ -445,6 +445,24 @@ def cholesky(A, out=None, info=None):
     return out, info
 
 
+def cholesky_inverse(A, out=None, inv=None, info=None, ws=None):
+    """(L, W, info): L = chol(A) and W = L^-1 from one fused launch sequence (batched over leading dims)."""
+    _chk(A)
+    M = A.shape[-1]
+    assert A.shape[-2] == M
+    B = A.numel() // max(M * M, 1)
+    if out is None:
+        out = _empty_like(A)
+    if inv is None:
+        inv = _empty_like(A)
+    if info is None:
+        info = _empty(max(B, 1), dtype=torch.int32, device=A.device)
+    if ws is None:
+        ws = workspace(A.dtype, A.device, max(B * M * M, 1))
+    _lib.lib().call("hb_cholesky_inverse" + _suf(A), _p(A), _p(out), _p(inv), B, M, _p(info), _p(ws), stream())
+    return out, inv, info
+
+
 def trinv(L, out=None):
     """W = L^{-1} for lower-triangular L, batched."""
     _chk(L)

@@ -224,6 +224,16 @@ int hb_matmul_f64(const double* A, const double* B, double* C, long batch, long 
  * of A is significant beyond its diagonal tiles. */
 int hb_cholesky_f32(const float* A, float* L, long B, long M, int* info, void* stream);
 int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void* stream);
+
+/* K4+K6 fused: L = chol(A) and W = L^-1 from the same launches (the identity is
+ * eliminated alongside A: the inverse costs extra width per launch, no extra
+ * depth).  ws: B*M*M elements.  Replaces the tf.cholesky +
+ * tf.matrix_triangular_solve(Lm, .) pair of SparseGP.samples (reference
+ * gp/gp.py:135,162,169).  A, L, W must not alias. */
+int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long B, long M, int* info, float* ws,
+                            void* stream);
+int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info,
+                            double* ws, void* stream);
 /* W = L^{-1} (lower triangular inverse), batched.  Used in place of
  * tf.matrix_triangular_solve(Lm, .) (reference gp/gp.py:162,169): the
  * reference's own batched branch forms the explicit inverse the same way.

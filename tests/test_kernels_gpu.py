@@ -363,6 +363,40 @@ def test_cholesky(H, p, M):
         assert np.allclose(Lh, ref, rtol=2e-2, atol=2e-3)
 
 
+@pytest.mark.parametrize("p", ["f32", "f64"])
+@pytest.mark.parametrize("M", [1, 7, 32, 33, 64, 65, 100, 200, 256, 512])
+def test_cholesky_inverse_fused(H, p, M):
+    """hb_cholesky_inverse: L and W = L^-1 from the same launches == separate factor + inverse."""
+    dt = DT[p]
+    rng = np.random.RandomState(M + 1)
+    A = _spd(rng, 3, M, 1e-2 if p == "f32" else 1e-5)
+    L, W, info = H.cholesky_inverse(dev(A, dt))
+    assert info.cpu().tolist() == [0, 0, 0]
+    Lh, Wh = host(L), host(W)
+    assert np.all(np.triu(Lh, 1) == 0) and np.all(np.triu(Wh, 1) == 0)
+    ref = np.linalg.cholesky(A)
+    refW = np.linalg.inv(ref)
+    if p == "f64":
+        assert np.allclose(Lh, ref, rtol=1e-8, atol=1e-9)
+        assert np.allclose(Wh, refW, rtol=1e-7, atol=1e-8 * np.abs(refW).max())
+    else:
+        assert np.allclose(Lh, ref, rtol=2e-2, atol=2e-3)
+        # W L = I to fp32 accuracy (the conditioning of L is ~sqrt of A's)
+        err = np.abs(Wh.astype(np.float64) @ Lh.astype(np.float64) - np.eye(M)).max()
+        assert err < 2e-3, err
+    # the plain factorisation is bit-identical (same kernel, inverse rows are extra width only)
+    L2, _ = H.cholesky(dev(A, dt))
+    assert torch.equal(L, L2)
+
+
+def test_cholesky_inverse_reports_failure(H):
+    rng = np.random.RandomState(0)
+    A = _spd(rng, 2, 96)
+    A[1, 50, 50] = -1.0
+    _, _, info = H.cholesky_inverse(dev(A, torch.float64))
+    assert info.cpu().tolist() == [0, 51]
+
+
 def test_cholesky_inplace_and_info(H):
     rng = np.random.RandomState(0)
     A = _spd(rng, 1, 70)[0]
