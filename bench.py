@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line: the contract fields plus
                     bounded sample (kind "port": TensorFlow is not available offline).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -139,7 +140,8 @@ def main():
     m = SVGP(X=X, Y=Y, Z=Z, dtype=args.dtype, seed=0)
     m.N = N_TOTAL  # the ELBO's N/n rescale uses the global data count
     opt = m.ELBO()
-    opt.compile(optimizer=tf.train.AdamOptimizer(1e-3))
+    with contextlib.redirect_stdout(sys.stderr):  # compile() announces itself on stdout like the reference does
+        opt.compile(optimizer=tf.train.AdamOptimizer(1e-3))
 
     def barrier():
         if world > 1:
