@@ -46,7 +46,17 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
   const int col0 = (blockIdx.x % tiles_n) * BT;
   const long b = blockIdx.y;
   const int s = blockIdx.z;
-  if ((a.flags & HB_MM_LOWER_OUT) && col0 > row0 + BT - 1) return;
+  if ((a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT)) && col0 > row0 + BT - 1) {
+    if ((a.flags & HB_MM_TRIL_OUT) && a.S == 1) {
+      // a tile wholly above the diagonal: all zero (with split-K the finish kernel writes them)
+      T* Cb = a.C + b * a.sC;
+      for (int idx = threadIdx.x; idx < BT * BT; idx += 256) {
+        const int r = row0 + idx / BT, c = col0 + idx % BT;
+        if (r < M && c < N) Cb[(long)r * a.ldc + c] = T(0);
+      }
+    }
+    return;
+  }
   int kchunk = (K + a.S - 1) / a.S;
   kchunk = ((kchunk + G::BK - 1) / G::BK) * G::BK;
   const int kbeg = s * kchunk;
@@ -106,6 +116,7 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
         if (biasb) o += biasb[c];
         o = apply_act<T>(a.act, o);
         if (a.beta != T(0)) o += a.beta * Cb[r * a.ldc + c];
+        if ((a.flags & HB_MM_TRIL_OUT) && c > r) o = T(0);
         Cb[r * a.ldc + c] = o;
       }
     });
@@ -120,12 +131,17 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
     const long b = t / (a.M * a.N);
     const long rem = t - b * a.M * a.N;
     const long r = rem / a.N, c = rem - r * a.N;
-    if ((a.flags & HB_MM_LOWER_OUT) && (c / a.tile) * a.tile > (r / a.tile) * a.tile + a.tile - 1) continue;
+    T* cp = a.C + b * a.sC + r * a.ldc + c;
+    if ((a.flags & HB_MM_TRIL_OUT) && c > r) {
+      cp[0] = T(0);
+      continue;
+    }
+    if ((a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT)) && (c / a.tile) * a.tile > (r / a.tile) * a.tile + a.tile - 1)
+      continue;
     T acc = T(0);
     for (int s = 0; s < a.S; ++s) acc += a.ws[(long)s * total + t];
     if (a.bias) acc += a.bias[b * a.sBias + c];
     acc = apply_act<T>(a.act, acc);
-    T* cp = a.C + b * a.sC + r * a.ldc + c;
     if (a.beta != T(0)) acc += a.beta * cp[0];
     cp[0] = acc;
   }
@@ -153,20 +169,26 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   a.bias = bias; a.sBias = sBias;
   a.act = act; a.flags = flags;
   a.ws = ws;
-  // large outputs: 128x128 tiles (64x64 per wave: 4 MFMAs per fragment pair) cut the per-MFMA staging cost
-  const int BT = (M >= 256 && N >= 256) ? 128 : 64;
+  // Tile / split choice.  These are latency-and-occupancy problems more often than throughput ones: a
+  // 128x128 tile (64x64 per wave: 4 MFMAs per fragment pair) has the lowest staging cost per MFMA but
+  // only pays when there are enough of them to cover the 256 CUs; otherwise 64x64 tiles, and the
+  // contraction is split until ~2.5 workgroups per CU are in flight (each slice >= 64 deep).
+  const bool lower = (flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT)) != 0;
+  const long t128 = (long)hb_cdiv(M, 128) * hb_cdiv(N, 128);
+  const int BT = (M >= 256 && N >= 256 && t128 * batch >= 200) ? 128 : 64;
   a.tile = BT;
   const long tiles = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
+  const long tr = hb_cdiv(M, BT);
+  const long active = (lower && M == N) ? tr * (tr + 1) / 2 : tiles;
   int S = 1;
-  if (ws && tiles * batch < 192 && K >= 256) {
-    // few output tiles: spread the contraction over the idle CUs (each slice >= 128 deep)
-    long s1 = K / 128;
-    long s2 = 512 / (tiles * batch);
-    long s3 = ws_elems / (batch * M * N);
-    S = (int)(s1 < s2 ? s1 : s2);
-    if (S > s3) S = (int)s3;
-    if (S > 64) S = 64;
-    if (S < 1) S = 1;
+  if (ws && active * batch < 320 && K >= 128) {
+    long s0 = 640 / (active * batch);
+    const long s1 = K / 64;
+    const long s3 = ws_elems / (batch * M * N);
+    if (s0 > s1) s0 = s1;
+    if (s0 > s3) s0 = s3;
+    if (s0 > 64) s0 = 64;
+    if (s0 >= 2) S = (int)s0;
   }
   a.S = S;
   dim3 grid((unsigned)tiles, (unsigned)batch, (unsigned)S);

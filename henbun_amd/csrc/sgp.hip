@@ -659,17 +659,6 @@ __global__ void __launch_bounds__(256) sgp_xbar_kernel(const T* __restrict__ x, 
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) sgp_tril_kernel(T* __restrict__ Lbar, long E, long M) {
-  const long total = E * M * M;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const long rem = t % (M * M);
-    const long i = rem / M, j = rem - i * M;
-    if (j > i) Lbar[t] = T(0);
-  }
-}
-
 static inline int sgp_matmul(const float* A, const float* B, float* C, long batch, long M, long N, long K, long lda,
                              long ldb, long ldc, long sA, long sB, long sC, int tA, int tB, double alpha, int flags,
                              float* ws, long wse, void* stream) {
@@ -731,11 +720,9 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   }
   // Lbar = -tril(Kbar A^T): contraction over the data axis, split-K, lower tiles only
   if (n > 0) {
-    int rc = sgp_matmul(Kbar, A, Lbar, E, M, M, n, n, n, M, M * n, M * n, M * M, 0, 1, -1.0, HB_MM_LOWER_OUT, mmws,
+    int rc = sgp_matmul(Kbar, A, Lbar, E, M, M, n, n, n, M, M * n, M * n, M * M, 0, 1, -1.0, HB_MM_TRIL_OUT, mmws,
                         mmws_elems, (void*)stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(sgp_tril_kernel<T>, dim3(hb_stream_grid(E * M * M, 256)), dim3(256), 0, stream, Lbar, E, M);
-    HB_LAUNCH_CHECK();
   } else {
     HB_HIP(hb_zero_async(Lbar, sizeof(T) * E * M * M, stream));
   }

@@ -508,6 +508,11 @@ def strided_view(x, out_shape, strides, offset=0) -> Tensor:
     """out[idx] = x.flat[offset + sum idx*strides] (materialised copy; covers
     transpose / slice / broadcast / tile).  Linear in x."""
     x = as_tensor(x)
+    out_shape = tuple(int(d) for d in out_shape)
+    # a view that keeps the memory order of every non-unit dim (e.g. the transpose of an [n,1] column) is a reshape
+    if int(offset) == 0 and int(np.prod(out_shape)) == x.size and all(
+            d == 1 or int(s) == c for d, s, c in zip(out_shape, strides, _contig_strides(out_shape))):
+        return reshape(x, out_shape)
     return make("strided", (x,), {"shape": tuple(out_shape), "strides": tuple(int(s) for s in strides),
                                   "offset": int(offset)}, [tuple(out_shape)]).outputs[0]
 
@@ -580,18 +585,39 @@ def matrix_transpose(x) -> Tensor:
 
 
 def broadcast_to(x, shape) -> Tensor:
+    """Broadcast (numpy rules).  Elementwise consumers read the small operand in place; a copy is
+    only materialised for consumers that need the full array."""
     x = as_tensor(x)
     shape = tuple(int(s) for s in shape)
     if x.shape == shape:
         return x
     nd = len(shape)
     xs = (1,) * (nd - len(x.shape)) + tuple(x.shape)
-    st = _contig_strides(xs)
-    strides = [0 if (xs[i] == 1 and shape[i] != 1) else st[i] for i in range(nd)]
     for i in range(nd):
         if xs[i] != shape[i] and xs[i] != 1:
             raise ValueError("cannot broadcast %s to %s" % (x.shape, shape))
-    return strided_view(x, shape, strides)
+    return make("bcast", (x,), {"shape": shape}, [shape]).outputs[0]
+
+
+def _bcast_emit(plan, node):
+    H = plan.H
+    t = node.outputs[0]
+    src = plan.buf(node.inputs[0])
+    nd = len(t.shape)
+    xs = (1,) * (nd - len(src.shape)) + tuple(src.shape)
+    cons = plan._consumers.get(t, [])
+    if cons and all(c.op == "ew" for c in cons) and t not in plan.outputs and t not in plan._bind:
+        plan.alias(t, src.view(xs))  # every consumer broadcasts its operands itself
+        return
+    out = plan.out(t)
+    st = _contig_strides(xs)
+    strides = [0 if (xs[i] == 1 and t.shape[i] != 1) else st[i] for i in range(nd)]
+    shp = list(t.shape)
+    ostr = _contig_strides(shp)
+    plan.steps.append(lambda: H.copy_nd(src, strides, out, ostr, shp))
+
+
+defop("bcast", _bcast_emit, lambda node, gs: [None if gs[0] is None else sum_to_shape(gs[0], node.inputs[0].shape)])
 
 
 def tile(x, multiples) -> Tensor:
@@ -1490,7 +1516,7 @@ class Plan:
                 r = len(inputs)
                 in_regs[t] = r
                 inputs.append(self.buf(t))
-                istr.append(strides_of(t.shape))
+                istr.append(strides_of(tuple(self.buf(t).shape)))  # buffer shape: a lazy broadcast aliases the small operand
             return r
 
         # first pass: collect external inputs so that their registers come first

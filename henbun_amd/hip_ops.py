@@ -29,6 +29,7 @@ EW = dict(
 RED_SUM, RED_MAX = 0, 1
 KERN_RBF, KERN_CSYM_RBF, KERN_SQDIST = 0, 1, 2
 MM_LOWER_OUT = 1
+MM_TRIL_OUT = 2
 ACT = dict(none=0, sigmoid=1, relu=2, tanh=3)
 SGP_NEGLECTED, SGP_DIAGONAL = 0, 1
 MATUTIL_BAND, MATUTIL_ADD_EYE, MATUTIL_PHI, MATUTIL_SYM = 0, 1, 2, 3
@@ -131,6 +132,10 @@ def ewise(op, inputs, nout=1, params=None, out=None):
     opc = EW[op] if isinstance(op, str) else int(op)
     inputs = [_chk(t, "input") for t in inputs]
     out_shape = tuple(torch.broadcast_shapes(*[tuple(t.shape) for t in inputs]))
+    if out is not None:
+        # explicit result buffers may be larger than the operands' common shape (operands broadcast into them)
+        o0 = out[0] if isinstance(out, (list, tuple)) else out
+        out_shape = tuple(torch.broadcast_shapes(out_shape, tuple(o0.shape)))
     if len(out_shape) > 6:
         raise ValueError("elementwise ops support at most 6 dims")
     nin = len(inputs)
@@ -391,7 +396,7 @@ def gram_bwd(X, X2, ell, Kbar, kind=KERN_RBF, need=(True, True, True)):
 
 # ---- dense linear algebra ------------------------------------------------------
 def matmul(A, B, transA=False, transB=False, alpha=1.0, bias=None, act="none", lower_out=False, out=None,
-           beta=0.0):
+           beta=0.0, tril_out=False):
     """C = act(alpha*op(A)@op(B) + bias) (+ beta*C).  A:[...,m,k], B:[...,k,n]; a 2-D operand broadcasts
     over the other's leading (batch) dims.  bias: [n] or [batch..., n]/[batch...,1,n]."""
     _chk(A), _chk(B)
@@ -421,7 +426,7 @@ def matmul(A, B, transA=False, transB=False, alpha=1.0, bias=None, act="none", l
     ws = workspace(A.dtype, A.device, 1 << 22)
     _lib.lib().call("hb_matmul" + _suf(A), _p(A), _p(B), _p(out), batch, am, bn, ak, A.shape[-1], B.shape[-1], bn,
                     sA, sB, am * bn, int(transA), int(transB), float(alpha), float(beta), _p(bias), sBias, ACT[act],
-                    MM_LOWER_OUT if lower_out else 0, _p(ws), ws.numel(), stream())
+                    (MM_LOWER_OUT if lower_out else 0) | (MM_TRIL_OUT if tril_out else 0), _p(ws), ws.numel(), stream())
     return out
 
 

@@ -200,7 +200,10 @@ int hb_gram_bwd_f64(int kind, const double* X, long sX, const double* X2, long s
 
 /* ---- dense linear algebra on MFMA (f32: v_mfma_f32_32x32x2_f32, f64:
  *      v_mfma_f64_16x16x4_f64) --------------------------------------------- */
-enum { HB_MM_LOWER_OUT = 1 /* only tiles touching the lower triangle of C are computed */ };
+enum {
+  HB_MM_LOWER_OUT = 1, /* only tiles touching the lower triangle of C are computed; the rest of C is left alone */
+  HB_MM_TRIL_OUT = 2   /* C = tril(result): as LOWER_OUT, and the strict upper triangle is written as zero */
+};
 enum { HB_ACT_NONE = 0, HB_ACT_SIGMOID = 1, HB_ACT_RELU = 2, HB_ACT_TANH = 3 };
 /* C[b] = act(alpha * op(A[b]) op(B[b]) + bias[b]) + beta * C[b], op = transpose if trans?.
  * A is M x K (after op), B is K x N, C is M x N; ld* = row strides, s* = batch

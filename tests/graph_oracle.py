@@ -84,6 +84,8 @@ def evaluate(outputs, leaf_values, noise=None):
             outs = [r]
         elif op == "reshape":
             outs = [ins[0].reshape(at["shape"])]
+        elif op == "bcast":
+            outs = [torch.broadcast_to(ins[0], tuple(at["shape"])).clone()]
         elif op == "strided":
             outs = [_strided(ins[0], at["shape"], at["strides"], at["offset"])]
         elif op == "scatter_strided":

@@ -330,6 +330,13 @@ def test_matmul_batch_bias_act_splitk_lower(H, p):
     ref = a3 @ a3.T
     il = np.tril_indices(200)
     assert np.allclose(got[il], ref[il], **(TOL[p] if p == "f64" else dict(rtol=1e-3, atol=1e-3)))
+    # tril output (direct epilogue and split-K finish): lower triangle exact, strict upper exactly zero
+    for kk in (40, 3000):
+        a4 = rng.randn(2, 200, kk)
+        got = host(H.matmul(dev(a4, dt), dev(a4, dt), transB=True, tril_out=True))
+        ref = np.tril(a4 @ np.transpose(a4, (0, 2, 1)))
+        assert np.all(np.triu(got, 1) == 0)
+        assert np.allclose(got, ref, **(TOL[p] if p == "f64" else dict(rtol=1e-3, atol=2e-2)))
     # beta accumulate
     c0 = rng.randn(6, 2)
     out = dev(np.broadcast_to(c0, (5, 6, 2)).copy(), dt)
