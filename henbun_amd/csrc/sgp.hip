@@ -44,6 +44,7 @@ struct SgpArgs {
   const T* u;   // [E, P, M]
   T* A;         // [E, M, n]
   long n, M, d, P;
+  T* part;      // [E, gridDim.y, 5, n] column partial sums (sum A^2, sum_m u_pm A_mj for p < 4) or nullptr
 };
 
 // ---------------------------------------------------------------------------
@@ -113,6 +114,17 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
         xv[q][dd] = x[cc * (D > 0 ? D : 1) + dd] * (T(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd]);
     }
   }
+
+  // fused column statistics (the `finish` pass never re-reads A): per accumulator column of this lane,
+  // [0] = sum_m A_mj^2, [1+p] = sum_m u_pm A_mj, carried across the two row blocks of the workgroup
+  typedef Mma<T> MMc;
+  constexpr int RMc = G::RM, RNc = G::RN;
+  T cs[RNc][5];
+#pragma unroll
+  for (int jj = 0; jj < RNc; ++jj)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) cs[jj][q] = T(0);
+  const int npart = a.part ? (int)a.P : 0;
 
   for (int half = 0; half < 2; ++half) {
     const int rb = half == 0 ? (int)blockIdx.y : nRB - 1 - (int)blockIdx.y;
@@ -192,6 +204,55 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
       const int r = row0 + row, c = col0 + col;
       if (r < M && c < n) A[(long)r * n + c] = v;
     });
+    if (a.part) {
+      const int lane = threadIdx.x & 63, wm = (threadIdx.x >> 6) / G::WN;
+#pragma unroll
+      for (int i = 0; i < RMc; ++i)
+#pragma unroll
+        for (int r = 0; r < MMc::NACC; ++r) {
+          const int row = row0 + wm * G::WTM + i * MMc::TM + MMc::acc_row(lane, r);
+          const int rc = row < M ? row : Mm1;  // rows past M hold zeros
+          T up[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) up[p] = p < npart ? a.u[e * a.P * a.M + (long)p * M + rc] : T(0);
+#pragma unroll
+          for (int jj = 0; jj < RNc; ++jj) {
+            const T v = g.acc[i][jj][r];
+            cs[jj][0] += v * v;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) cs[jj][1 + p] += up[p] * v;
+          }
+        }
+    }
+  }
+  if (a.part) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = w / G::WN, wn = w % G::WN;
+    // lanes that share an accumulator column differ in the bits above log2(TN)
+#pragma unroll
+    for (int jj = 0; jj < RNc; ++jj)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        T s = cs[jj][q];
+#pragma unroll
+        for (int off = MMc::TN; off < 64; off <<= 1) s += __shfl_xor(s, off);
+        cs[jj][q] = s;
+      }
+    __syncthreads();  // every wave is done with the operand buffers
+    T* red = lds;     // [2 wave rows][5][SGP_BN]
+    if (lane < MMc::TN) {
+#pragma unroll
+      for (int jj = 0; jj < RNc; ++jj)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) red[(wm * 5 + q) * SGP_BN + wn * G::WTN + jj * MMc::TN + lane] = cs[jj][q];
+    }
+    __syncthreads();
+    if (threadIdx.x < SGP_BN) {
+      const int c = col0 + threadIdx.x;
+      if (c < n) {
+        T* pp = a.part + (e * gridDim.y + blockIdx.y) * 5 * a.n + c;
+        for (int q = 0; q < 1 + npart; ++q) pp[(long)q * n] = red[q * SGP_BN + threadIdx.x] + red[(5 + q) * SGP_BN + threadIdx.x];
+      }
+    }
   }
 }
 
@@ -277,6 +338,51 @@ __global__ void __launch_bounds__(256) sgp_finish_kernel(const T* __restrict__ A
   }
 }
 
+// f, v from the column partials written by sgp_A_kernel's epilogue; eps is drawn here (the same
+// per-lane streams and pair order as sgp_rng_fill_kernel) or taken from eps_in.
+template <typename T>
+__device__ __forceinline__ void sgp_finish_one(const T* __restrict__ part, int gy, long idx, T epsv, T* __restrict__ f,
+                                               T* __restrict__ v, T* __restrict__ eps_out, long n, long P, int mode) {
+  const long e = idx / n, j = idx - e * n;
+  const T* pp = part + e * gy * 5 * n + j;
+  T s = T(0);
+  for (int y = 0; y < gy; ++y) s += pp[(long)y * 5 * n];
+  const T vv = T(1) - s;
+  v[idx] = vv;
+  if (eps_out) eps_out[idx] = epsv;
+  const T scale = mode == HB_SGP_DIAGONAL ? hb_sqrt(hb_abs(vv)) * epsv : T(0);
+  for (long p = 0; p < P; ++p) {
+    T mean = T(0);
+    for (int y = 0; y < gy; ++y) mean += pp[((long)y * 5 + 1 + p) * n];
+    f[(e * P + p) * n + j] = mean + scale;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_finish_part_kernel(const T* __restrict__ part, int gy,
+                                                              const T* __restrict__ eps_in, uint64_t* rng,
+                                                              long nlanes, T* __restrict__ eps_out, T* __restrict__ f,
+                                                              T* __restrict__ v, long total, long n, long P, int mode) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long npairs = (total + 1) / 2;
+  if (rng) {
+    if (t >= nlanes || t >= npairs) return;
+    HbRng g = rng_load(rng, nlanes, t);
+    for (long p = t; p < npairs; p += nlanes) {
+      double z0, z1;
+      g.normal2(z0, z1);
+      sgp_finish_one<T>(part, gy, 2 * p, (T)z0, f, v, eps_out, n, P, mode);
+      if (2 * p + 1 < total) sgp_finish_one<T>(part, gy, 2 * p + 1, (T)z1, f, v, eps_out, n, P, mode);
+    }
+    rng_store(rng, nlanes, t, g);
+  } else {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long idx = t; idx < total; idx += stride)
+      sgp_finish_one<T>(part, gy, idx, eps_in ? eps_in[idx] : T(0), f, v, (eps_out != eps_in) ? eps_out : nullptr, n, P,
+                        mode);
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) sgp_rng_fill_kernel(uint64_t* state, long nlanes, T* out, long n) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,14 +400,15 @@ __global__ void __launch_bounds__(256) sgp_rng_fill_kernel(uint64_t* state, long
 
 extern "C" long hb_sgp_ws_elems(long E, long n, long M, long d, long P) {
   (void)P;
-  return E * n + E * M * d + 32 * E * M * M;
+  const long gy = ((M + SGP_BM - 1) / SGP_BM + 1) / 2;
+  const long mm = 32 * E * M * M, part = 5 * E * gy * n;  // backward split-K slabs / forward column partials
+  return E * n + E * M * d + (mm > part ? mm : part);
 }
 
 template <typename T>
 static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* u,
                    const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* A, T* f, T* v, long E, long n,
                    long M, long d, long P, T* ws, hipStream_t stream) {
-  (void)ws;
   HB_REQUIRE(kind == HB_KERN_RBF, "hb_sgp_fwd: only the UnitRBF kernel is fused (kind=%d)", kind);
   HB_REQUIRE(mode == HB_SGP_NEGLECTED || mode == HB_SGP_DIAGONAL, "hb_sgp_fwd: unknown mode %d", mode);
   HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1 && P >= 0, "hb_sgp_fwd: bad extents");
@@ -310,10 +417,30 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   HB_REQUIRE(E <= 65535, "hb_sgp_fwd: too many experts");
   HB_REQUIRE(M * n < 2147483647L && M * M < 2147483647L && n * d < 2147483647L, "hb_sgp_fwd: matrix too large for 32-bit indexing");
   if (E * n == 0) return 0;
+  const bool draw = mode == HB_SGP_DIAGONAL && !eps_in;
+  if (draw) HB_REQUIRE(rng && rng_lanes > 0 && eps_out, "hb_sgp_fwd: need eps_in, or rng and eps_out");
+  const int nRB = hb_cdiv(M, SGP_BM);
+  const int gy = (nRB + 1) / 2;
+  // fused path: the contraction kernel leaves per-column partial sums, one small kernel finishes f, v (and draws eps)
+  if (M > 0 && P <= 4 && ws) {
+    SgpArgs<T> a;
+    a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = u; a.A = A;
+    a.n = n; a.M = M; a.d = d; a.P = P;
+    a.part = ws + E * n + E * M * d;
+    dim3 grid(hb_cdiv(n, SGP_BN), gy, (unsigned)E);
+    int rc = sgp_A_launch<T>(a, grid, stream);
+    if (rc) return rc;
+    const long total = E * n;
+    const int fgrid = draw ? hb_cdiv(rng_lanes, 256) : hb_stream_grid((total + 1) / 2, 256);
+    hipLaunchKernelGGL(sgp_finish_part_kernel<T>, dim3(fgrid), dim3(256), 0, stream, a.part, gy,
+                       mode == HB_SGP_DIAGONAL ? eps_in : (const T*)nullptr, draw ? rng : (uint64_t*)nullptr, rng_lanes,
+                       mode == HB_SGP_DIAGONAL ? eps_out : (T*)nullptr, f, v, total, n, P, mode);
+    HB_LAUNCH_CHECK();
+    return 0;
+  }
   const T* eps = eps_in;
   if (mode == HB_SGP_DIAGONAL) {
-    if (!eps_in) {
-      HB_REQUIRE(rng && rng_lanes > 0 && eps_out, "hb_sgp_fwd: need eps_in, or rng and eps_out");
+    if (draw) {
       hipLaunchKernelGGL(sgp_rng_fill_kernel<T>, dim3(hb_cdiv(rng_lanes, 256)), dim3(256), 0, stream, rng, rng_lanes,
                          eps_out, E * n);
       HB_LAUNCH_CHECK();
@@ -326,8 +453,8 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     SgpArgs<T> a;
     a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = u; a.A = A;
     a.n = n; a.M = M; a.d = d; a.P = P;
-    const int nRB = hb_cdiv(M, SGP_BM);
-    dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
+    a.part = nullptr;
+    dim3 grid(hb_cdiv(n, SGP_BN), gy, (unsigned)E);
     int rc = sgp_A_launch<T>(a, grid, stream);
     if (rc) return rc;
   }
@@ -352,6 +479,7 @@ static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, l
   SgpArgs<T> a;
   a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = nullptr; a.A = A;
   a.n = n; a.M = M; a.d = d; a.P = 0;
+  a.part = nullptr;
   const int nRB = hb_cdiv(M, SGP_BM);
   dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
   return sgp_A_launch<T>(a, grid, stream);
@@ -383,28 +511,20 @@ extern "C" int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, cons
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-// c_j = -eps_j sign(v_j)/sqrt|v_j| * sum_p fbar_pj   (0 for NEGLECTED)
+// c_j = -eps_j sign(v_j)/sqrt|v_j| * sum_p fbar_pj   (0 for NEGLECTED): the chain through the
+// diagonal residual  f += sqrt|v| eps,  v = 1 - colsum(A^2).
+// d sqrt|v| / dv = sign(v) / (2 sqrt|v|) is 0/0 at v == 0 (reachable in fp32 when x sits on an
+// inducing point); the reference has no guard there (gp/gp.py:131) and would propagate NaN --
+// take the sub-gradient 0 instead.
 template <typename T>
-__global__ void __launch_bounds__(256) sgp_prep_kernel(const T* __restrict__ eps, const T* __restrict__ v,
-                                                       const T* __restrict__ fbar, T* __restrict__ c, long E, long n,
-                                                       long P, int mode) {
-  const long total = E * n;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    T out = T(0);
-    if (mode == HB_SGP_DIAGONAL) {
-      const long e = t / n, j = t - e * n;
-      T cs = T(0);
-      for (long p = 0; p < P; ++p) cs += fbar[(e * P + p) * n + j];
-      // d sqrt|v| / dv = sign(v) / (2 sqrt|v|) is 0/0 at v == 0 (reachable in fp32 when
-      // x sits on an inducing point); the reference has no guard there (gp/gp.py:131) and
-      // would propagate NaN -- take the sub-gradient 0 instead.
-      const T vv = v[t];
-      const T av = hb_abs(vv);
-      out = av > T(0) ? -eps[t] * hb_sign(vv) / hb_sqrt(av) * cs : T(0);
-    }
-    c[t] = out;
-  }
+__device__ __forceinline__ T sgp_resid_coef(const T* __restrict__ eps, const T* __restrict__ v,
+                                            const T* __restrict__ fbar, long n, long P, int mode, long j) {
+  if (mode != HB_SGP_DIAGONAL) return T(0);
+  T cs = T(0);
+  for (long p = 0; p < P; ++p) cs += fbar[p * n + j];
+  const T vv = v[j];
+  const T av = hb_abs(vv);
+  return av > T(0) ? -eps[j] * hb_sign(vv) / hb_sqrt(av) * cs : T(0);
 }
 
 template <typename T>
@@ -413,9 +533,11 @@ struct SgpBwdArgs {
   const T* u;     // [E, P, M]
   const T* A;     // [E, M, n]
   const T* fbar;  // [E, P, n]
-  const T* c;     // [E, n]
+  const T* eps;   // [E, n] (DIAGONAL mode)
+  const T* v;     // [E, n]
   T* Kbar;        // [E, M, n]
   long n, M, P;
+  int mode;
 };
 
 template <typename T>
@@ -439,7 +561,8 @@ __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
   const T* u = a.u + e * a.P * a.M;
   const T* A = a.A + e * a.M * a.n;
   const T* fbar = a.fbar + e * a.P * a.n;
-  const T* c = a.c + e * a.n;
+  const T* eps = a.eps ? a.eps + e * a.n : nullptr;
+  const T* vres = a.v + e * a.n;
   T* Kbar = a.Kbar + e * a.M * a.n;
   const int M = (int)a.M, n = (int)a.n;
   const int col0 = blockIdx.x * SGP_BN;
@@ -448,7 +571,7 @@ __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
   const bool jok = jcol < n;
   const int jc = jok ? jcol : n - 1;
   const int Mm1 = M - 1;
-  const T cj = c[jc];
+  const T cj = sgp_resid_coef<T>(eps, vres, fbar, a.n, a.P, a.mode, jc);
   const bool preg = a.P == 1;
   const T fb0 = a.P > 0 ? fbar[jc] : T(0);
   // vector path: this thread's B-operand group is always the same VEC columns
@@ -459,7 +582,7 @@ __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
 #pragma unroll
   for (int q = 0; q < VECK; ++q) {
     const bool ok = FAST && (n4 + q < n);
-    c4[q] = ok ? c[n4 + q] : T(0);   // out-of-range columns: zero contribution (never stored anyway)
+    c4[q] = ok ? sgp_resid_coef<T>(eps, vres, fbar, a.n, a.P, a.mode, n4 + q) : T(0);  // out of range: no contribution
     f4[q] = ok ? fbar[n4 + q] : T(0);
   }
 
@@ -602,6 +725,93 @@ __global__ void __launch_bounds__(256) sgp_rowgrad_kernel(const T* __restrict__ 
   }
 }
 
+// Vector form of the row pass (d <= SGP_DREG, P <= 4, n a multiple of the 16-byte group, aligned
+// operands): each thread takes 16-byte groups of columns, the loop is unrolled so that the loads
+// of four groups (A, Kbar, x, fbar) are in flight together -- with two waves per SIMD the scalar
+// form above is bound by its dependent load round trips, not by bandwidth.
+template <typename T, int D>
+__global__ void __launch_bounds__(256) sgp_rowgrad_vec_kernel(const T* __restrict__ x, long sx,
+                                                              const T* __restrict__ z, const T* __restrict__ ell,
+                                                              long dl, const T* __restrict__ Kbar,
+                                                              const T* __restrict__ A, const T* __restrict__ fbar,
+                                                              T* __restrict__ zbar, T* __restrict__ ellpart,
+                                                              T* __restrict__ ubar, long n, long M, long P) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  typedef T VT __attribute__((ext_vector_type(VEC)));
+  __shared__ T smem[16];
+  const long e = blockIdx.y, m = blockIdx.x;
+  x += e * sx;
+  z += (e * M + m) * D;
+  ell += e * dl;
+  Kbar += (e * M + m) * n;
+  A += (e * M + m) * n;
+  fbar += e * P * n;
+  const int np = (int)P;
+  T zm[D], il[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    il[q] = T(1) / ell[dl == 1 ? 0 : q];
+    zm[q] = z[q] * il[q];
+  }
+  T uacc[4] = {T(0), T(0), T(0), T(0)};
+  T zacc[D], lacc[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) zacc[q] = lacc[q] = T(0);
+  const long ngroups = n / VEC;
+#pragma unroll 4
+  for (long g = threadIdx.x; g < ngroups; g += 256) {
+    const long j0 = g * VEC;
+    const VT av = *reinterpret_cast<const VT*>(A + j0);
+    const VT kv = *reinterpret_cast<const VT*>(Kbar + j0);
+    T xq[VEC][D];
+    if (D == 1) {
+      const VT xv = *reinterpret_cast<const VT*>(x + j0);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) xq[c][0] = xv[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c)
+#pragma unroll
+        for (int q = 0; q < D; ++q) xq[c][q] = x[(j0 + c) * D + q];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (p < np) {
+        const VT fv = *reinterpret_cast<const VT*>(fbar + p * n + j0);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) uacc[p] += fv[c] * av[c];
+      }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      T tt[D], r2 = T(0);
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        tt[q] = zm[q] - xq[c][q] * il[q];
+        r2 += tt[q] * tt[q];
+      }
+      const T gk = kv[c] * hb_exp_fast<T>(T(-0.5) * r2);
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        zacc[q] -= gk * tt[q];
+        lacc[q] += gk * tt[q] * tt[q];
+      }
+    }
+  }
+  for (int p = 0; p < np; ++p) {
+    const T us = block_sum(uacc[p], smem);
+    if (threadIdx.x == 0) ubar[(e * P + p) * M + m] = us;
+  }
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    const T zs = block_sum(zacc[q], smem) * il[q];
+    const T ls = block_sum(lacc[q], smem) * il[q];
+    if (threadIdx.x == 0) {
+      zbar[(e * M + m) * D + q] = zs;
+      ellpart[(e * M + m) * D + q] = ls;
+    }
+  }
+}
+
 // ellbar[e, c] = sum_m ellpart[e, m, c] (all columns when dl == 1)
 template <typename T>
 __global__ void __launch_bounds__(256) sgp_ell_finish_kernel(const T* __restrict__ part, long M, long d, long dl,
@@ -686,17 +896,13 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   HB_REQUIRE(E <= 65535, "hb_sgp_bwd: too many experts");
   HB_REQUIRE(M * n < 2147483647L && M * M < 2147483647L && n * d < 2147483647L, "hb_sgp_bwd: matrix too large for 32-bit indexing");
   if (E * M == 0) return 0;
-  T* c = ws;
-  T* ellpart = ws + E * n;
+  T* ellpart = ws + E * n;  // (the first E*n elements of ws are unused since the residual coefficient is computed in-kernel)
   T* mmws = ellpart + E * M * d;
   const long mmws_elems = 32 * E * M * M;
   if (n > 0) {
-    hipLaunchKernelGGL(sgp_prep_kernel<T>, dim3(hb_stream_grid(E * n, 256)), dim3(256), 0, stream, eps, v, fbar, c, E, n,
-                       P, mode);
-    HB_LAUNCH_CHECK();
     SgpBwdArgs<T> a;
-    a.W = W; a.u = u; a.A = A; a.fbar = fbar; a.c = c; a.Kbar = Kbar;
-    a.n = n; a.M = M; a.P = P;
+    a.W = W; a.u = u; a.A = A; a.fbar = fbar; a.eps = eps; a.v = v; a.Kbar = Kbar;
+    a.n = n; a.M = M; a.P = P; a.mode = mode;
     const int nRB = hb_cdiv(M, SGP_BM);
     dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
     constexpr long VECH = 16 / sizeof(T);
@@ -707,8 +913,28 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
       hipLaunchKernelGGL((sgp_kbar_kernel<T, false>), grid, dim3(256), 0, stream, a);
     HB_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(sgp_rowgrad_kernel<T>, dim3((unsigned)M, (unsigned)E), dim3(256), 0, stream, x, sx, z, ell, dl,
-                     Kbar, A, fbar, zbar, ellpart, ubar, n, M, d, P);
+  {
+    constexpr long VECR = 16 / sizeof(T);
+    const bool rvec = d <= SGP_DREG && P <= 4 && n > 0 && n % VECR == 0 && ((uintptr_t)A % 16 == 0) &&
+                      ((uintptr_t)Kbar % 16 == 0) && ((uintptr_t)fbar % 16 == 0) && ((uintptr_t)x % 16 == 0) &&
+                      (sx * (long)sizeof(T)) % 16 == 0;
+    dim3 rgrid((unsigned)M, (unsigned)E);
+#define HB_SGP_ROWGRAD(D_)                                                                                           \
+  hipLaunchKernelGGL((sgp_rowgrad_vec_kernel<T, D_>), rgrid, dim3(256), 0, stream, x, sx, z, ell, dl, Kbar, A, fbar, \
+                     zbar, ellpart, ubar, n, M, P)
+    if (rvec && d == 1)
+      HB_SGP_ROWGRAD(1);
+    else if (rvec && d == 2)
+      HB_SGP_ROWGRAD(2);
+    else if (rvec && d == 3)
+      HB_SGP_ROWGRAD(3);
+    else if (rvec && d == 4)
+      HB_SGP_ROWGRAD(4);
+    else
+      hipLaunchKernelGGL(sgp_rowgrad_kernel<T>, rgrid, dim3(256), 0, stream, x, sx, z, ell, dl, Kbar, A, fbar, zbar,
+                         ellpart, ubar, n, M, d, P);
+#undef HB_SGP_ROWGRAD
+  }
   HB_LAUNCH_CHECK();
   hipLaunchKernelGGL(sgp_ell_finish_kernel<T>, dim3((unsigned)dl, (unsigned)E), dim3(256), 0, stream, ellpart, M, d, dl,
                      ellbar);

@@ -17,7 +17,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) diag_fwd_kernel(const T* __restrict__ mu, const T* __restrict__ s,
                                                        const T* __restrict__ u_in, uint64_t* rng, long rng_lanes,
                                                        T* __restrict__ u_out, T* __restrict__ x,
-                                                       T* __restrict__ partial, long n) {
+                                                       T* __restrict__ partial, T* __restrict__ kl, long n) {
   __shared__ T smem[16];
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nthreads = rng ? rng_lanes : (long)gridDim.x * blockDim.x;
@@ -57,7 +57,12 @@ __global__ void __launch_bounds__(256) diag_fwd_kernel(const T* __restrict__ mu,
   }
   if (rng && active) rng_store(rng, rng_lanes, t, g);
   acc = block_sum(acc, smem);
-  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+  if (threadIdx.x == 0) {
+    if (gridDim.x == 1)
+      kl[0] = T(-0.5) * acc;  // one block covers everything: no finishing pass
+    else
+      partial[blockIdx.x] = acc;
+  }
 }
 
 template <typename T>
@@ -83,11 +88,16 @@ static int diag_fwd(const T* mu, const T* s, const T* u_in, uint64_t* rng, long 
   } else {
     grid = hb_stream_grid((n + 1) / 2, 256);
   }
+  // blocks past the last pair would only contribute zeros
+  const int need = hb_cdiv((n + 1) / 2, 256);
+  if (grid > need) grid = need > 0 ? need : 1;
   hipLaunchKernelGGL(diag_fwd_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, s, u_in, rng, rng_lanes, u_out, x, ws,
-                     n);
+                     kl, n);
   HB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(kl_finish_kernel<T>, dim3(1), dim3(256), 0, stream, ws, grid, kl);
-  HB_LAUNCH_CHECK();
+  if (grid > 1) {
+    hipLaunchKernelGGL(kl_finish_kernel<T>, dim3(1), dim3(256), 0, stream, ws, grid, kl);
+    HB_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -506,8 +506,9 @@ def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None)
         f, A, v, eps = out
     dl = ell.numel() // E
     rp, rl = _rng_args(rng)
+    ws = workspace(dt, dev, int(_lib.lib().raw("hb_sgp_ws_elems")(E, n, M, d, P)))
     _lib.lib().call("hb_sgp_fwd" + _suf(x), KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(u), _p(eps_in),
-                    rp, rl, _p(eps), _p(A), _p(f), _p(v), E, n, M, d, P, None, stream())
+                    rp, rl, _p(eps), _p(A), _p(f), _p(v), E, n, M, d, P, _p(ws), stream())
     return f, A, v, eps
 
 
