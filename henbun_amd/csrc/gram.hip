@@ -29,20 +29,21 @@ template <typename T>
 __global__ void __launch_bounds__(256) gram_fwd_kernel(int kind, const T* __restrict__ X, long sX,
                                                        const T* __restrict__ X2, long sX2, const T* __restrict__ ell,
                                                        long sEll, long dl, T* __restrict__ K, long B, long n, long n2,
-                                                       long d) {
+                                                       long d, T diag_add) {
   const long total = B * n * n2;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const long b = t / (n * n2);
     const long rem = t - b * n * n2;
     const long i = rem / n2, j = rem - i * n2;
-    K[t] = gram_value<T>(kind, X + b * sX + i * d, X2 + b * sX2 + j * d, ell + b * sEll, dl, d);
+    const T kv = gram_value<T>(kind, X + b * sX + i * d, X2 + b * sX2 + j * d, ell + b * sEll, dl, d);
+    K[t] = (i == j) ? kv + diag_add : kv;  // jitter (gp/kernels.py:101) folded in
   }
 }
 
 template <typename T>
 static int gram_fwd(int kind, const T* X, long sX, const T* X2, long sX2, const T* ell, long sEll, long dl, T* K,
-                    long B, long n, long n2, long d, hipStream_t stream) {
+                    long B, long n, long n2, long d, double diag_add, hipStream_t stream) {
   HB_REQUIRE(kind >= HB_KERN_RBF && kind <= HB_KERN_SQDIST, "hb_gram_fwd: unknown kernel kind %d", kind);
   HB_REQUIRE(B >= 0 && n >= 0 && n2 >= 0 && d >= 1, "hb_gram_fwd: bad extents");
   HB_REQUIRE(dl == 1 || dl == d, "hb_gram_fwd: lengthscales must have 1 or d=%ld entries, got %ld", d, dl);
@@ -51,17 +52,19 @@ static int gram_fwd(int kind, const T* X, long sX, const T* X2, long sX2, const 
   if (total == 0) return 0;
   HB_REQUIRE(sEll == 0 || sEll == dl, "hb_gram_fwd: lengthscale batch stride must be 0 or dl");
   hipLaunchKernelGGL(gram_fwd_kernel<T>, dim3(hb_stream_grid(total, 256)), dim3(256), 0, stream, kind, X, sX, X2, sX2,
-                     ell, sEll, dl, K, B, n, n2, d);
+                     ell, sEll, dl, K, B, n, n2, d, (T)diag_add);
   HB_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int hb_gram_fwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
-                               long sEll, long dl, float* K, long B, long n, long n2, long d, void* stream) {
-  return gram_fwd<float>(kind, X, sX, X2, sX2, ell, sEll, dl, K, B, n, n2, d, (hipStream_t)stream);
+                               long sEll, long dl, float* K, long B, long n, long n2, long d, double diag_add,
+                               void* stream) {
+  return gram_fwd<float>(kind, X, sX, X2, sX2, ell, sEll, dl, K, B, n, n2, d, diag_add, (hipStream_t)stream);
 }
 extern "C" int hb_gram_fwd_f64(int kind, const double* X, long sX, const double* X2, long sX2, const double* ell,
-                               long sEll, long dl, double* K, long B, long n, long n2, long d, void* stream) {
-  return gram_fwd<double>(kind, X, sX, X2, sX2, ell, sEll, dl, K, B, n, n2, d, (hipStream_t)stream);
+                               long sEll, long dl, double* K, long B, long n, long n2, long d, double diag_add,
+                               void* stream) {
+  return gram_fwd<double>(kind, X, sX, X2, sX2, ell, sEll, dl, K, B, n, n2, d, diag_add, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -80,20 +83,21 @@ __global__ void __launch_bounds__(256)
 gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const T* __restrict__ X2, long sX2,
                      const T* __restrict__ ell, long sEll, long dl, const T* __restrict__ Kbar, T* __restrict__ out,
                      T* __restrict__ ell_partial, long n, long n2, long d) {
-  // side 0: block row i of X, loop j over X2; side 1: block row j of X2, loop i over X.
+  // side 0: block row i of X, loop j over X2; side 1: block row j of X2, loop i over X;
+  // side 2: X2 IS X (same points): side 0 whose point gradient also takes the transposed entry Kbar[j,i],
+  // i.e. the sum of both sides in one pass (the lengthscale partial still counts every pair once).
   __shared__ T smem[16];
   const long b = blockIdx.y;
   const long row = blockIdx.x;
   ell += b * sEll;
-  const long nother = side == 0 ? n2 : n;
-  const T* xs = side == 0 ? X + b * sX + row * d : X2 + b * sX2 + row * d;
+  const long nother = side != 1 ? n2 : n;
   for (long k0 = 0; k0 < d; k0 += HB_GRAM_MAXD) {
     T gacc[HB_GRAM_MAXD], lacc[HB_GRAM_MAXD];
 #pragma unroll
     for (int k = 0; k < HB_GRAM_MAXD; ++k) gacc[k] = lacc[k] = T(0);
     for (long o = threadIdx.x; o < nother; o += blockDim.x) {
-      const long i = side == 0 ? row : o;
-      const long j = side == 0 ? o : row;
+      const long i = side != 1 ? row : o;
+      const long j = side != 1 ? o : row;
       const T* xi = X + b * sX + i * d;
       const T* xj = X2 + b * sX2 + j * d;
       T r2 = T(0), r2m = T(0);
@@ -105,18 +109,21 @@ gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const
       }
       const T kb = Kbar[(b * n + i) * n2 + j];
       // squared distance: d r2 = 2 (a-b) d(a-b), i.e. the RBF formulas with E- := -2
-      const T em = kind == HB_KERN_SQDIST ? T(-2) * kb : kb * hb_exp(T(-0.5) * r2);
-      const T ep = kind == HB_KERN_CSYM_RBF ? kb * hb_exp(T(-0.5) * r2m) : T(0);
+      const T km = kind == HB_KERN_SQDIST ? T(-2) : hb_exp(T(-0.5) * r2);
+      const T kp = kind == HB_KERN_CSYM_RBF ? hb_exp(T(-0.5) * r2m) : T(0);
+      const T em = kb * km, ep = kb * kp;
+      const T kbg = side == 2 ? kb + Kbar[(b * n + j) * n2 + i] : kb;  // point gradient: both orientations
+      const T gm = kbg * km, gp = kbg * kp;
 #pragma unroll
       for (int k = 0; k < HB_GRAM_MAXD; ++k) {
         if (k0 + k < d) {
           const T il = T(1) / ell[dl == 1 ? 0 : k0 + k];
           const T a = xi[k0 + k] * il, bb = xj[k0 + k] * il;
           const T dm = a - bb, dp = a + bb;
-          if (side == 0)
-            gacc[k] += (-dm * em - dp * ep) * il;
+          if (side != 1)
+            gacc[k] += (-dm * gm - dp * gp) * il;
           else
-            gacc[k] += (dm * em - dp * ep) * il;
+            gacc[k] += (dm * gm - dp * gp) * il;
           lacc[k] += (dm * dm * em + dp * dp * ep) * il;
         }
       }
@@ -125,11 +132,11 @@ gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const
     for (int k = 0; k < HB_GRAM_MAXD; ++k) {
       if (k0 + k < d) {
         const T g = block_sum(gacc[k], smem);
-        if (out && threadIdx.x == 0) out[(b * (side == 0 ? n : n2) + row) * d + k0 + k] = g;
+        if (out && threadIdx.x == 0) out[(b * (side != 1 ? n : n2) + row) * d + k0 + k] = g;
         if (ell_partial) {
           const T l = block_sum(lacc[k], smem);
           // partial layout [B*rows, d]; reduced (and folded to dl) afterwards
-          if (threadIdx.x == 0) ell_partial[(b * (side == 0 ? n : n2) + row) * d + k0 + k] = l;
+          if (threadIdx.x == 0) ell_partial[(b * (side != 1 ? n : n2) + row) * d + k0 + k] = l;
         }
       }
     }
@@ -172,9 +179,12 @@ static int gram_bwd(int kind, const T* X, long sX, const T* X2, long sX2, const 
     if (ellbar) HB_HIP(hb_zero_async(ellbar, sizeof(T) * dl * (sEll != 0 ? B : 1), stream));
     return 0;
   }
+  // X2bar == Xbar: X2 is X and the caller wants the total point gradient in one array
+  const bool sym = Xbar && X2bar == Xbar;
+  HB_REQUIRE(!sym || (X == X2 && sX == sX2 && n == n2), "hb_gram_bwd: Xbar == X2bar requires X2 == X");
   // side 0 pass also produces the lengthscale partials
   if (Xbar || ellbar) {
-    hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n, B), dim3(256), 0, stream, kind, 0, X, sX, X2, sX2, ell, sEll,
+    hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n, B), dim3(256), 0, stream, kind, sym ? 2 : 0, X, sX, X2, sX2, ell, sEll,
                        dl, Kbar, Xbar, ellbar ? ws : (T*)nullptr, n, n2, d);
     HB_LAUNCH_CHECK();
     if (ellbar) {
@@ -186,7 +196,7 @@ static int gram_bwd(int kind, const T* X, long sX, const T* X2, long sX2, const 
       HB_LAUNCH_CHECK();
     }
   }
-  if (X2bar) {
+  if (X2bar && !sym) {
     hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n2, B), dim3(256), 0, stream, kind, 1, X, sX, X2, sX2, ell, sEll,
                        dl, Kbar, X2bar, (T*)nullptr, n, n2, d);
     HB_LAUNCH_CHECK();

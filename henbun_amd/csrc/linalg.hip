@@ -22,6 +22,7 @@ struct MmArgs {
   const T* bias;
   long sBias;
   int act, flags, S, tile;
+  int to_ws;  // results go to the workspace slabs and the finish kernel writes C (split-K, or SYM_OUT)
   T* ws;
 };
 
@@ -35,9 +36,16 @@ __device__ __forceinline__ T apply_act(int act, T v) {
   }
 }
 
+// k-step depth.  (32 was tried for the k-contiguous/k-contiguous 128x128 case -- whole 128-byte lines per row
+// and step -- and measured slower: 62.8 vs 56.3 us on the Lbar contraction, profiles/r01_kloop_cycles.txt.)
+template <typename T, bool TA, bool TB, int BT>
+struct MmBK {
+  static constexpr int value = 16;
+};
+
 template <typename T, bool TA, bool TB, bool FAST, int BT>
 __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
-  typedef TileGemm<T, BT, BT, 16, 2, 2> G;
+  typedef TileGemm<T, BT, BT, MmBK<T, TA, TB, BT>::value, 2, 2> G;
   __shared__ T lds[G::LDS_ELEMS];
   const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
   const int lda = (int)a.lda, ldb = (int)a.ldb;
@@ -46,8 +54,8 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
   const int col0 = (blockIdx.x % tiles_n) * BT;
   const long b = blockIdx.y;
   const int s = blockIdx.z;
-  if ((a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT)) && col0 > row0 + BT - 1) {
-    if ((a.flags & HB_MM_TRIL_OUT) && a.S == 1) {
+  if ((a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && col0 > row0 + BT - 1) {
+    if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && !a.to_ws) {
       // a tile wholly above the diagonal: all zero (with split-K the finish kernel writes them)
       T* Cb = a.C + b * a.sC;
       for (int idx = threadIdx.x; idx < BT * BT; idx += 256) {
@@ -100,7 +108,7 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
   } else {
     g.template run<!TA, TB>(kbeg, kend, la, fa, lb, fb, lds);
   }
-  if (a.S > 1) {
+  if (a.to_ws) {
     T* wsb = a.ws + ((long)s * a.batch + b) * a.M * a.N;
     g.for_each([&](int row, int col, T v) {
       const long r = row0 + row, c = col0 + col;
@@ -116,7 +124,8 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
         if (biasb) o += biasb[c];
         o = apply_act<T>(a.act, o);
         if (a.beta != T(0)) o += a.beta * Cb[r * a.ldc + c];
-        if ((a.flags & HB_MM_TRIL_OUT) && c > r) o = T(0);
+        if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && c > r) o = T(0);
+        if ((a.flags & HB_MM_PHI_OUT) && c == r) o *= T(0.5);
         Cb[r * a.ldc + c] = o;
       }
     });
@@ -132,14 +141,21 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
     const long rem = t - b * a.M * a.N;
     const long r = rem / a.N, c = rem - r * a.N;
     T* cp = a.C + b * a.sC + r * a.ldc + c;
-    if ((a.flags & HB_MM_TRIL_OUT) && c > r) {
+    if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && c > r) {
       cp[0] = T(0);
       continue;
     }
-    if ((a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT)) && (c / a.tile) * a.tile > (r / a.tile) * a.tile + a.tile - 1)
-      continue;
+    if ((a.flags & HB_MM_LOWER_OUT) && (c / a.tile) * a.tile > (r / a.tile) * a.tile + a.tile - 1) continue;
     T acc = T(0);
     for (int s = 0; s < a.S; ++s) acc += a.ws[(long)s * total + t];
+    if (a.flags & HB_MM_SYM_OUT) {
+      const long tt = b * a.M * a.N + c * a.N + r;  // the mirrored element
+      T acc2 = T(0);
+      for (int s = 0; s < a.S; ++s) acc2 += a.ws[(long)s * total + tt];
+      cp[0] = T(0.5) * (acc + acc2);
+      continue;
+    }
+    if ((a.flags & HB_MM_PHI_OUT) && c == r) acc *= T(0.5);
     if (a.bias) acc += a.bias[b * a.sBias + c];
     acc = apply_act<T>(a.act, acc);
     if (a.beta != T(0)) acc += a.beta * cp[0];
@@ -173,15 +189,26 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   // 128x128 tile (64x64 per wave: 4 MFMAs per fragment pair) has the lowest staging cost per MFMA but
   // only pays when there are enough of them to cover the 256 CUs; otherwise 64x64 tiles, and the
   // contraction is split until ~2.5 workgroups per CU are in flight (each slice >= 64 deep).
-  const bool lower = (flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT)) != 0;
-  const long t128 = (long)hb_cdiv(M, 128) * hb_cdiv(N, 128);
-  const int BT = (M >= 256 && N >= 256 && t128 * batch >= 200) ? 128 : 64;
+  HB_REQUIRE(!(flags & HB_MM_SYM_OUT) || (M == N && ws && ws_elems >= batch * M * N && !bias && act == HB_ACT_NONE &&
+                                          beta == 0.0 && !(flags & ~HB_MM_SYM_OUT)),
+             "hb_matmul: SYM_OUT needs a square result, a workspace, and no other epilogue");
+  const bool lower = (flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) != 0;
+  auto active_tiles = [&](int bt) -> long {
+    const long tr = hb_cdiv(M, bt), tc = hb_cdiv(N, bt);
+    return (lower && M == N) ? tr * (tr + 1) / 2 : tr * tc;
+  };
+  int BT = 64, S = 1;
+  if (M >= 256 && N >= 256) {
+    const long a128 = active_tiles(128) * batch;
+    if (a128 >= 200) {
+      BT = 128;  // enough big tiles to cover the chip
+    }
+  }
   a.tile = BT;
   const long tiles = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
-  const long tr = hb_cdiv(M, BT);
-  const long active = (lower && M == N) ? tr * (tr + 1) / 2 : tiles;
-  int S = 1;
-  if (ws && active * batch < 320 && K >= 128) {
+  const long active = active_tiles(BT);
+  if (BT == 64 && ws && active * batch < 320 && K >= 128) {
+    // shallow or small: latency matters -- ~2.5 workgroups per CU, each slice >= 64 deep
     long s0 = 640 / (active * batch);
     const long s1 = K / 64;
     const long s3 = ws_elems / (batch * M * N);
@@ -191,6 +218,7 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
     if (s0 >= 2) S = (int)s0;
   }
   a.S = S;
+  a.to_ws = (S > 1 || (flags & HB_MM_SYM_OUT)) ? 1 : 0;
   dim3 grid((unsigned)tiles, (unsigned)batch, (unsigned)S);
   constexpr long VEC = 16 / sizeof(T);
   const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % VEC == 0 && ldb % VEC == 0 &&
@@ -221,7 +249,7 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
 #undef HB_MM_LAUNCH
 #undef HB_MM_LAUNCH2
   HB_LAUNCH_CHECK();
-  if (S > 1) {
+  if (a.to_ws) {
     hipLaunchKernelGGL(matmul_splitk_finish_kernel<T>, dim3(hb_stream_grid(batch * M * N, 256)), dim3(256), 0, stream,
                        a);
     HB_LAUNCH_CHECK();

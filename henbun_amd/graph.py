@@ -758,9 +758,27 @@ def _matmul_emit(plan, node):
     H = plan.H
     a, b = plan.buf(node.inputs[0]), plan.buf(node.inputs[1])
     bias = plan.buf(node.inputs[2]) if len(node.inputs) > 2 else None
-    out = plan.out(node.outputs[0])
     at = node.attrs
-    plan.steps.append(lambda: H.matmul(a, b, transA=at["ta"], transB=at["tb"], bias=bias, act=at["act"], out=out))
+    y = node.outputs[0]
+    # a triangular / Phi / symmetrising matutil that is the only consumer becomes the GEMM's epilogue
+    cons = plan._consumers.get(y, [])
+    epi = 0
+    if (len(cons) == 1 and cons[0].op == "matutil" and bias is None and at["act"] == "none" and y.shape[-1] == y.shape[-2]
+            and y not in plan.outputs and y not in plan._bind):
+        ma = cons[0].attrs
+        if ma["mode"] == 2:
+            epi = H.MM_PHI_OUT
+        elif ma["mode"] == 3:
+            epi = H.MM_SYM_OUT
+        elif ma["mode"] == 0 and ma["lower"] < 0 and ma["upper"] == 0:
+            epi = H.MM_TRIL_OUT
+    if epi:
+        out = plan.out(cons[0].outputs[0])
+        plan._fused_matutil.add(cons[0].id)
+    else:
+        out = plan.out(y)
+    plan.steps.append(lambda: H.matmul(a, b, transA=at["ta"], transB=at["tb"], bias=bias, act=at["act"], out=out,
+                                       epilogue=epi))
 
 
 def _sum_lead(g, t):
@@ -805,7 +823,24 @@ def matutil(x, mode, lower=-1, upper=-1, alpha=0.0) -> Tensor:
                 [x.shape]).outputs[0]
 
 
+def _known_lower(t) -> bool:
+    """True when t is lower-triangular by construction (its strict upper part is exactly zero)."""
+    n = t.node
+    if n.op in ("cholesky", "trinv"):
+        return True
+    if n.op == "sgp_grad":
+        return t.index == 0
+    if n.op == "matutil":
+        return n.attrs["mode"] == 2 or (n.attrs["mode"] == 0 and n.attrs["upper"] == 0)
+    if n.op == "stop_gradient":
+        return _known_lower(n.inputs[0])
+    return False
+
+
 def band_part(x, num_lower, num_upper):
+    x = as_tensor(x)
+    if int(num_lower) < 0 and int(num_upper) == 0 and _known_lower(x):
+        return x  # tril of a matrix that is already lower-triangular
     return matutil(x, 0, num_lower, num_upper)
 
 
@@ -814,6 +849,8 @@ def add_eye(x, alpha):
 
 
 def _matutil_emit(plan, node):
+    if node.id in plan._fused_matutil:
+        return  # folded into the producing GEMM's epilogue
     H = plan.H
     x, out = plan.buf(node.inputs[0]), plan.out(node.outputs[0])
     a = node.attrs
@@ -1072,8 +1109,18 @@ def _gram_layout(tX, tX2, tell):
 def _gram_emit(plan, node):
     H = plan.H
     X, X2, ell = (plan.buf(t) for t in node.inputs)
-    out = plan.out(node.outputs[0])
     k = KERN_KINDS[node.attrs["kind"]]
+    y = node.outputs[0]
+    # K + jitter*I (kern.Cholesky, reference gp/kernels.py:101) as the Gram kernel's own diagonal term
+    cons = plan._consumers.get(y, [])
+    if (len(cons) == 1 and cons[0].op == "matutil" and cons[0].attrs["mode"] == 1 and y.shape[-1] == y.shape[-2]
+            and y not in plan.outputs and y not in plan._bind):
+        out = plan.out(cons[0].outputs[0])
+        plan._fused_matutil.add(cons[0].id)
+        jit = cons[0].attrs["alpha"]
+        plan.steps.append(lambda: H.gram_fwd(X, X2, ell, kind=k, out=out, diag_add=jit))
+        return
+    out = plan.out(y)
     plan.steps.append(lambda: H.gram_fwd(X, X2, ell, kind=k, out=out))
 
 
@@ -1082,7 +1129,11 @@ def _gram_vjp(node, gs):
     if g is None:
         return [None, None, None]
     X, X2, ell = node.inputs
-    n = make("gram_grad", (X, X2, ell, g), {"kind": node.attrs["kind"]}, [X.shape, X2.shape, ell.shape])
+    if X is X2:
+        # K(z, z): one pass gives the total gradient w.r.t. the shared points
+        n = make("gram_grad", (X, X2, ell, g), {"kind": node.attrs["kind"], "sym": True}, [X.shape, ell.shape])
+        return [n.outputs[0], None, n.outputs[1]]
+    n = make("gram_grad", (X, X2, ell, g), {"kind": node.attrs["kind"], "sym": False}, [X.shape, X2.shape, ell.shape])
     return list(n.outputs)
 
 
@@ -1090,9 +1141,22 @@ def _gram_grad_emit(plan, node):
     H = plan.H
     tX, tX2, tell, tg = node.inputs
     X, X2, ell, g = (plan.buf(t) for t in node.inputs)
-    oX, oX2, oL = [plan.out(t) for t in node.outputs]
     k = KERN_KINDS[node.attrs["kind"]]
     B, BX, BX2, n, n2, d, sX, sX2, sEll, dl = _gram_layout(tX, tX2, tell)
+    if node.attrs.get("sym"):
+        oX, oL = [plan.out(t) for t in node.outputs]
+        tmp = plan.scratch((B, n, d)) if (BX == 1 and B > 1) else None
+        ws = plan.scratch((max(B * n * d, 1),))
+
+        def sym_step():
+            dst = tmp if tmp is not None else oX
+            H.gram_bwd_raw(k, X, sX, X2, sX2, ell, sEll, dl, g, dst, dst, oL, B, n, n2, d, ws)
+            if tmp is not None:
+                H.reduce_mid(tmp, 1, B, n * d, out=oX)
+
+        plan.steps.append(sym_step)
+        return
+    oX, oX2, oL = [plan.out(t) for t in node.outputs]
     # an operand shared by the batch gets its per-batch gradients summed
     tmpX = plan.scratch((B, n, d)) if (BX == 1 and B > 1) else None
     tmpX2 = plan.scratch((B, n2, d)) if (BX2 == 1 and B > 1) else None
@@ -1381,6 +1445,7 @@ class Plan:
             self._needed.add(t)
         self._extra_copies = []
         self._fused_trinv = set()
+        self._fused_matutil = set()
         for t, b in (binds or []):
             self._prebind(t, b)
         if prologue:

@@ -30,6 +30,8 @@ RED_SUM, RED_MAX = 0, 1
 KERN_RBF, KERN_CSYM_RBF, KERN_SQDIST = 0, 1, 2
 MM_LOWER_OUT = 1
 MM_TRIL_OUT = 2
+MM_PHI_OUT = 4
+MM_SYM_OUT = 8
 ACT = dict(none=0, sigmoid=1, relu=2, tanh=3)
 SGP_NEGLECTED, SGP_DIAGONAL = 0, 1
 MATUTIL_BAND, MATUTIL_ADD_EYE, MATUTIL_PHI, MATUTIL_SYM = 0, 1, 2, 3
@@ -338,7 +340,7 @@ def _ell_layout(ell, B, d):
     return 0, ell.numel()
 
 
-def gram_fwd(X, X2, ell, kind=KERN_RBF, out=None):
+def gram_fwd(X, X2, ell, kind=KERN_RBF, out=None, diag_add=0.0):
     """K[b,i,j] = k(X[b,i], X2[b,j]); X, X2: [n,d] or [B,n,d] (a 2-D operand is shared over B);
     ell: [dl] (shared) or [B, dl] (one kernel per batch entry)."""
     _chk(X), _chk(X2), _chk(ell)
@@ -357,7 +359,7 @@ def gram_fwd(X, X2, ell, kind=KERN_RBF, out=None):
     if out is None:
         out = _empty((lead if batched else ()) + (n, n2), dtype=X.dtype, device=X.device)
     _lib.lib().call("hb_gram_fwd" + _suf(X), kind, _p(X), sX, _p(X2), sX2, _p(ell), sEll, dl, _p(out), B, n, n2, d,
-                    stream())
+                    float(diag_add), stream())
     return out
 
 
@@ -396,7 +398,7 @@ def gram_bwd(X, X2, ell, Kbar, kind=KERN_RBF, need=(True, True, True)):
 
 # ---- dense linear algebra ------------------------------------------------------
 def matmul(A, B, transA=False, transB=False, alpha=1.0, bias=None, act="none", lower_out=False, out=None,
-           beta=0.0, tril_out=False):
+           beta=0.0, tril_out=False, epilogue=0):
     """C = act(alpha*op(A)@op(B) + bias) (+ beta*C).  A:[...,m,k], B:[...,k,n]; a 2-D operand broadcasts
     over the other's leading (batch) dims.  bias: [n] or [batch..., n]/[batch...,1,n]."""
     _chk(A), _chk(B)
@@ -426,7 +428,7 @@ def matmul(A, B, transA=False, transB=False, alpha=1.0, bias=None, act="none", l
     ws = workspace(A.dtype, A.device, 1 << 22)
     _lib.lib().call("hb_matmul" + _suf(A), _p(A), _p(B), _p(out), batch, am, bn, ak, A.shape[-1], B.shape[-1], bn,
                     sA, sB, am * bn, int(transA), int(transB), float(alpha), float(beta), _p(bias), sBias, ACT[act],
-                    (MM_LOWER_OUT if lower_out else 0) | (MM_TRIL_OUT if tril_out else 0), _p(ws), ws.numel(), stream())
+                    (MM_LOWER_OUT if lower_out else 0) | (MM_TRIL_OUT if tril_out else 0) | int(epilogue), _p(ws), ws.numel(), stream())
     return out
 
 

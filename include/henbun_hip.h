@@ -183,13 +183,16 @@ enum { HB_KERN_RBF = 0, HB_KERN_CSYM_RBF = 1, HB_KERN_SQDIST = 2 /* the scaled s
  * shared); ell has dl = 1 (scalar) or d entries (ARD), post-transform; sEll = 0
  * (one kernel for the whole batch) or dl (a lengthscale vector per batch entry:
  * independent experts). */
+/* diag_add is added to K[b,i,i] (the jitter of kern.Cholesky, gp/kernels.py:101; 0 otherwise). */
 int hb_gram_fwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
-                    long sEll, long dl, float* K, long B, long n, long n2, long d, void* stream);
+                    long sEll, long dl, float* K, long B, long n, long n2, long d, double diag_add,
+                    void* stream);
 int hb_gram_fwd_f64(int kind, const double* X, long sX, const double* X2, long sX2,
                     const double* ell, long sEll, long dl, double* K, long B, long n, long n2, long d,
-                    void* stream);
+                    double diag_add, void* stream);
 /* VJP: Xbar[B,n,d], X2bar[B,n2,d] (either nullable), ellbar[dl] or [B,dl] when sEll != 0
- * (nullable).  ws >= B*n*d elements when ellbar != NULL. */
+ * (nullable).  ws >= B*n*d elements when ellbar != NULL.  X2bar == Xbar (with X2 == X):
+ * the total gradient w.r.t. the shared points is written once. */
 int hb_gram_bwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
                     long sEll, long dl, const float* Kbar, float* Xbar, float* X2bar, float* ellbar,
                     long B, long n, long n2, long d, float* ws, void* stream);
@@ -202,7 +205,10 @@ int hb_gram_bwd_f64(int kind, const double* X, long sX, const double* X2, long s
  *      v_mfma_f64_16x16x4_f64) --------------------------------------------- */
 enum {
   HB_MM_LOWER_OUT = 1, /* only tiles touching the lower triangle of C are computed; the rest of C is left alone */
-  HB_MM_TRIL_OUT = 2   /* C = tril(result): as LOWER_OUT, and the strict upper triangle is written as zero */
+  HB_MM_TRIL_OUT = 2,  /* C = tril(result): as LOWER_OUT, and the strict upper triangle is written as zero */
+  HB_MM_PHI_OUT = 4,   /* C = Phi(result): strict lower kept, diagonal halved, strict upper zero (Cholesky VJP) */
+  HB_MM_SYM_OUT = 8    /* C = (R + R^T)/2 of the square result R (needs the workspace: ws_elems >= batch*M*N;
+                          bias/act/beta are not applied) */
 };
 enum { HB_ACT_NONE = 0, HB_ACT_SIGMOID = 1, HB_ACT_RELU = 2, HB_ACT_TANH = 3 };
 /* C[b] = act(alpha * op(A[b]) op(B[b]) + bias[b]) + beta * C[b], op = transpose if trans?.

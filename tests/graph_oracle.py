@@ -167,7 +167,8 @@ def evaluate(outputs, leaf_values, noise=None):
             kind = at["kind"]
             K = O.rbf_K(Xr, X2r, lr) if kind == "rbf" else (O.csym_rbf_K(Xr, X2r, lr) if kind == "csym_rbf"
                                                              else O.square_dist(Xr, X2r, lr))
-            outs = list(torch.autograd.grad((K * g).sum(), [Xr, X2r, lr]))
+            gX, gX2, gl = torch.autograd.grad((K * g).sum(), [Xr, X2r, lr])
+            outs = [gX + gX2, gl] if at.get("sym") else [gX, gX2, gl]
         elif op in ("sgp", "sgp_grad"):
             if op == "sgp":
                 x, z, ell, L, W, u = ins[:6]

@@ -40,7 +40,7 @@ def test_bad_arguments_are_reported_not_crashed():
     lib = _lib.lib()
     rc = lib.raw("hb_reduce_f32")(0, None, None, -1, 1, 1, None, 0, None)
     assert rc < 0 and "negative" in lib.last_error()
-    rc = lib.raw("hb_gram_fwd_f64")(7, None, 0, None, 0, None, 0, 1, None, 1, 1, 1, 1, None)
+    rc = lib.raw("hb_gram_fwd_f64")(7, None, 0, None, 0, None, 0, 1, None, 1, 1, 1, 1, 0.0, None)
     assert rc < 0 and "kind" in lib.last_error()
     with pytest.raises(_lib.HipBackendError):
         lib.call("hb_rng_randint", None, 0, None, 1, 0, 0, None)

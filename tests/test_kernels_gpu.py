@@ -337,6 +337,16 @@ def test_matmul_batch_bias_act_splitk_lower(H, p):
         ref = np.tril(a4 @ np.transpose(a4, (0, 2, 1)))
         assert np.all(np.triu(got, 1) == 0)
         assert np.allclose(got, ref, **(TOL[p] if p == "f64" else dict(rtol=1e-3, atol=2e-2)))
+    # Phi / symmetrising epilogues (Cholesky VJP), direct and split-K
+    for kk in (24, 2500):
+        a5, b5 = rng.randn(2, 130, kk), rng.randn(2, kk, 130)
+        full = a5 @ b5
+        tol5 = TOL[p] if p == "f64" else dict(rtol=1e-3, atol=2e-2)
+        phi = np.tril(full, -1) + 0.5 * np.einsum("bii->bi", full)[:, :, None] * np.eye(130)
+        got = host(H.matmul(dev(a5, dt), dev(b5, dt), epilogue=H.MM_PHI_OUT))
+        assert np.all(np.triu(got, 1) == 0) and np.allclose(got, phi, **tol5)
+        got = host(H.matmul(dev(a5, dt), dev(b5, dt), epilogue=H.MM_SYM_OUT))
+        assert np.allclose(got, 0.5 * (full + np.transpose(full, (0, 2, 1))), **tol5)
     # beta accumulate
     c0 = rng.randn(6, 2)
     out = dev(np.broadcast_to(c0, (5, 6, 2)).copy(), dt)
@@ -613,3 +623,28 @@ def test_ewise_program(H, p):
     assert_close(outs[3], gmu, tol if p == "f64" else dict(rtol=1e-3, atol=1e-4))
     # per-element d/dvar (autograd sums over the broadcast): compare the sum
     assert_close(host(outs[4]).sum().reshape(1), gv, tol if p == "f64" else dict(rtol=1e-3, atol=1e-3))
+
+
+@pytest.mark.parametrize("kind", ["rbf", "csym"])
+def test_gram_symmetric_bwd_and_jitter(H, kind):
+    """K(z, z): X2bar == Xbar gives the total point gradient in one pass; diag_add folds the jitter in."""
+    rng = np.random.RandomState(5)
+    B, n, d = 2, 23, 2
+    X = rng.randn(B, n, d)
+    ell = np.exp(0.3 * rng.randn(d))
+    Kbar = rng.randn(B, n, n)  # deliberately NOT symmetric
+    tX, tl = torch.as_tensor(X).requires_grad_(True), torch.as_tensor(ell).requires_grad_(True)
+    f = O.rbf_K if kind == "rbf" else O.csym_rbf_K
+    K = f(tX, tX, tl)
+    gX, gl = torch.autograd.grad((K * torch.as_tensor(Kbar)).sum(), [tX, tl])
+    dt = torch.float64
+    k = H.KERN_RBF if kind == "rbf" else H.KERN_CSYM_RBF
+    Xd, ld, Kd = dev(X, dt), dev(ell, dt), dev(Kbar, dt)
+    xb = torch.empty_like(Xd)
+    lb = torch.empty_like(ld)
+    ws = torch.empty(B * n * d, dtype=dt, device=Xd.device)
+    H.gram_bwd_raw(k, Xd, n * d, Xd, n * d, ld, 0, d, Kd, xb, xb, lb, B, n, n, d, ws)
+    assert_close(xb, gX, TOL["f64"])
+    assert_close(lb, gl, TOL["f64"])
+    got = H.gram_fwd(Xd, Xd, ld, kind=k, diag_add=0.25)
+    assert_close(got, K.detach() + 0.25 * torch.eye(n, dtype=dt), TOL["f64"])
