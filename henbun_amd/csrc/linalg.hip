@@ -361,6 +361,10 @@ __device__ __forceinline__ void trsolve_row32(T (&t)[CH_NB], const T (*LsT)[CH_L
 // read it while one of them writes the factored block to (j, j).  The upper
 // triangle is cleared by tril_inplace_kernel after the last launch.
 // ===========================================================================
+// In-kernel phase stamps: compiled in only by tools/chol_stamps.hip (diagnostic build).
+#ifndef HB_STAMP
+#define HB_STAMP(i)
+#endif
 #define CR_B 32         // block size
 #define CR_ROWS 128     // stacked panel: diagonal block + 96 rows
 #define CR_LD 36        // LDS row stride (rows stay 16-byte aligned)
@@ -451,6 +455,7 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
   const int row0 = bi * CR_B, col0 = j * CR_B;
   const bool ydiag = yt && bi == j;  // tile (k,k) of Y: starts as the identity, takes no update
 
+  HB_STAMP(0);
   typename MM::Acc acc[RT][RT];
   {
     // where the tile currently lives: A on first touch (k <= 1), then L -- a diagonal tile one block up -- or Y
@@ -516,6 +521,7 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
         for (int sj = 0; sj < RT; ++sj) acc[si][sj] = MM::mma(a[si][q], bq[sj][q], acc[si][sj]);
   }
 
+  HB_STAMP(1);
   if (!factor) {
     if (live) {
       T* dst = yt ? Y : L;
@@ -555,57 +561,82 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
         }
       }
     __syncthreads();
+    if (kb == 1) HB_STAMP(4);
     if (tid < CR_ROWS) {
       // potrf8: every lane (of the two waves that own rows) factors the 8x8 diagonal block
-      // Cs[8kb.., 8kb..] in registers: no cross-lane traffic, no barriers
-      T p[8][8], pinv[8];
+      // Cs[8kb.., 8kb..] in registers: no cross-lane traffic, no barriers.  The block is held by
+      // COLUMNS, two rows per register pair, so that the rank-1 updates (and the row solve below,
+      // which walks the same columns) are packed v_pk_fma_f32 on fp32.
+      typedef T T2 __attribute__((ext_vector_type(2)));
+      T2 col[8][4];  // col[c][h] = (L[2h][c], L[2h+1][c])
+      T pinv[8];
+      {
+        T p[8][8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int q = 0; q < 8; q += VEC) {
-          const VT v = *reinterpret_cast<const VT*>(&Cs[8 * kb + i][8 * kb + q]);
+          for (int q = 0; q < 8; q += VEC) {
+            const VT v = *reinterpret_cast<const VT*>(&Cs[8 * kb + i][8 * kb + q]);
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) p[i][q + e] = v[e];
-        }
+            for (int e = 0; e < VEC; ++e) p[i][q + e] = v[e];
+          }
+        // only the lower triangle is meaningful; mirror it so the pairs hold finite values
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            col[c][h][0] = (2 * h >= c) ? p[2 * h][c] : p[c][2 * h];
+            col[c][h][1] = (2 * h + 1 >= c) ? p[2 * h + 1][c] : p[c][2 * h + 1];
+          }
+      }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const T d = p[c][c];
+        const T d = col[c][c / 2][c % 2];
         if (fail == 0 && !(d > T(0))) fail = 8 * kb + c + 1;
         T lcc, pi;
         pivot_sqrt(d, lcc, pi);
-        p[c][c] = lcc;
         pinv[c] = pi;
+        const T2 pi2 = {pi, pi};
 #pragma unroll
-        for (int i = c + 1; i < 8; ++i) p[i][c] *= pi;
+        for (int h = c / 2; h < 4; ++h) col[c][h] *= pi2;
+        col[c][c / 2][c % 2] = lcc;
 #pragma unroll
-        for (int c2 = c + 1; c2 < 8; ++c2)
+        for (int c2 = c + 1; c2 < 8; ++c2) {
+          const T s = col[c][c2 / 2][c2 % 2];
+          const T2 ns = {-s, -s};
 #pragma unroll
-          for (int i = c2; i < 8; ++i) p[i][c2] -= p[i][c] * p[c2][c];
+          for (int h = c2 / 2; h < 4; ++h) col[c2][h] = __builtin_elementwise_fma(col[c][h], ns, col[c2][h]);
+        }
       }
-      // solve: thread t owns stacked row t;  x L_kk^T = c  over the 8 columns of this step
-      T x[8];
+      if (kb == 1) HB_STAMP(5);
+      // solve: thread t owns stacked row t;  x L_kk^T = c  over the 8 columns of this step, right-looking:
+      // once x_c is final, x_{c2 > c} -= x_c L[c2][c] -- the same column pairs as above
+      T2 xv[4];
+      static_assert(VEC % 2 == 0, "pairs");
 #pragma unroll
       for (int q = 0; q < 8; q += VEC) {
         const VT v = *reinterpret_cast<const VT*>(&Cs[tid][8 * kb + q]);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) x[q + e] = v[e];
+        for (int e = 0; e < VEC; ++e) xv[(q + e) / 2][(q + e) % 2] = v[e];
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        T tt = x[c];
+        const T xc = xv[c / 2][c % 2] * pinv[c];
+        const T2 nx = {-xc, -xc};
 #pragma unroll
-        for (int i = 0; i < c; ++i) tt -= x[i] * p[c][i];
-        x[c] = tt * pinv[c];
+        for (int h = c / 2; h < 4; ++h) xv[h] = __builtin_elementwise_fma(col[c][h], nx, xv[h]);
+        xv[c / 2][c % 2] = xc;
       }
 #pragma unroll
       for (int q = 0; q < 8; q += VEC) {
         VT v;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] = x[q + e];
+        for (int e = 0; e < VEC; ++e) v[e] = xv[(q + e) / 2][(q + e) % 2];
         *reinterpret_cast<VT*>(&Cs[tid][8 * kb + q]) = v;
       }
     }
     __syncthreads();
+    if (kb == 1) HB_STAMP(6);
     if (kb < 3) {
       // rank-8 update of the columns to the right: acc -= X[:, 8kb:8kb+8] X_D[cols, 8kb:8kb+8]^T
       T a2[RT][PK], b2[RT][PK];
@@ -629,7 +660,9 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
 #pragma unroll
           for (int sj = 0; sj < RT; ++sj) acc[si][sj] = MM::mma(a2[si][e], b2[sj][e], acc[si][sj]);
     }
+    if (kb == 1) HB_STAMP(7);
   }
+  HB_STAMP(2);
   if (s == 0 && tid == 0) {
     // block 0 of the factor column is the only writer of info; launch 0 resets it
     const int bad = (fail != 0 && fail <= nb) ? k * CR_B + fail : 0;
@@ -673,6 +706,7 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
       }
     }
   }
+  HB_STAMP(3);
 }
 
 template <typename T>

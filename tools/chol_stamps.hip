@@ -1,0 +1,46 @@
+// Diagnostic build of the Cholesky kernel with in-kernel phase stamps (not part of the product).
+// hipcc -O3 --offload-arch=gfx950 tools/chol_stamps.hip -o /tmp/chol_stamps && /tmp/chol_stamps
+#include <hip/hip_runtime.h>
+__device__ long long hb_stamps[64 * 8];
+__device__ int hb_stamp_k;
+#define HB_STAMP(i)                                                                       \
+  do {                                                                                    \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hb_stamps[k * 8 + (i)] = clock64(); \
+  } while (0)
+#include "../henbun_amd/csrc/runtime.hip"
+#include "../henbun_amd/csrc/linalg.hip"
+#include <stdio.h>
+#include <vector>
+#include <cmath>
+
+int main() {
+  const int M = 512;
+  std::vector<float> h(M * M);
+  for (int i = 0; i < M; ++i)
+    for (int j = 0; j < M; ++j) h[i * M + j] = expf(-0.5f * (i - j) * (i - j) * 0.25f) + (i == j ? 0.01f : 0.f);
+  float *A, *L, *W, *ws;
+  int* info;
+  (void)hipMalloc(&A, M * M * 4); (void)hipMalloc(&L, M * M * 4); (void)hipMalloc(&W, M * M * 4); (void)hipMalloc(&ws, M * M * 4);
+  (void)hipMalloc(&info, 4);
+  (void)hipMemcpy(A, h.data(), M * M * 4, hipMemcpyHostToDevice);
+  for (int inv = 0; inv < 2; ++inv) {
+    for (int rep = 0; rep < 3; ++rep) {
+      if (inv) hb_cholesky_inverse_f32(A, L, W, 1, M, info, ws, 0);
+      else hb_cholesky_f32(A, L, 1, M, info, 0);
+    }
+    (void)hipDeviceSynchronize();
+    long long st[64 * 8];
+    (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(hb_stamps), sizeof(st));
+    int hinfo;
+    (void)hipMemcpy(&hinfo, info, 4, hipMemcpyDeviceToHost);
+    printf("%s (info %d): cycles of factor workgroup 0, per launch k\n", inv ? "cholesky+inverse" : "cholesky", hinfo);
+    for (int k : {0, 1, 4, 8, 12, 15}) {
+      long long* s = st + k * 8;
+      printf("  k=%2d  load+rank32 %6lld  in-panel(4x publish/potrf8/solve/rank8) %6lld  store %6lld   total %6lld = %.2f us\n", k,
+             s[1] - s[0], s[2] - s[1], s[3] - s[2], s[3] - s[0], (s[3] - s[0]) / 2400.0);
+      printf("        step kb=1: potrf8 %5lld  solve+writeback+barrier %5lld  rank-8 MFMA %5lld  (publish+barrier of the step = rest)\n",
+             s[5] - s[4], s[6] - s[5], s[7] - s[6]);
+    }
+  }
+  return 0;
+}
