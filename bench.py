@@ -195,10 +195,23 @@ def main():
     flops = float(Mi) * Mi * n  # triangular solve A = L^-1 Kmn: M^2 n flops
     achieved = flops / (kern_us * 1e-6) * 1e-12
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "float32" else 78.6
+    # HBM-side bytes per launch of this kernel: from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE, gfx950 correction applied; profiles/r01_pmc_traffic.json) -- counters cannot be read from here
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)["kernels"]
+        want = "sgp_A_kernel<%s, 1, true>" % ("float" if args.dtype == "float32" else "double")
+        for name, rec in pmc.items():
+            if want in name:
+                traffic, traffic_src = rec["traffic_bytes"], "profiles/r01_pmc_traffic.json"
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"kernel": "sgp_A_kernel<%s,1> (A = L^-1 K(z,x), %dx%d by %d)" % ("float" if args.dtype == "float32" else "double", Mi, Mi, n),
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": None, "avg_kernel_us": kern_us,
-                "flops_per_launch": flops}
+                "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_us": kern_us,
+                "flops_per_launch": flops,
+                "algorithmic_bytes_per_launch": float(dt.itemsize) * (Mi * n + Mi * Mi / 2 + n + Mi)}
 
     breakdown = None
     try:
