@@ -43,8 +43,14 @@ struct TileGemm {
   static constexpr int EA = (BM * BK) / NT, EB = (BN * BK) / NT;
   static constexpr int NE = EA + EB;
   static constexpr int NS = BK / MM::TK;              // MFMA sub-steps per k-step
-  static constexpr int BUF_ELEMS = BK * (LDA + LDB);  // one LDS buffer
-  static constexpr int LDS_ELEMS = 2 * BUF_ELEMS;     // double buffered
+  // A k-contiguous operand (HB_KC, vector path) is staged row-major [m][LDK] instead of k-major [kk][LDA]:
+  // its 16-byte global groups go to LDS with ONE ds_write_b128 and a lane's fragments of a whole k-step
+  // are NS consecutive elements = NS/VEC ds_read_b128 (the k-major form needs NS ds_read_b32).
+  static constexpr int LDK = BK + 4;
+  static constexpr int A_ELEMS = (BM * LDK > BK * LDA) ? BM * LDK : BK * LDA;
+  static constexpr int B_ELEMS = (BN * LDK > BK * LDB) ? BN * LDK : BK * LDB;
+  static constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;  // one LDS buffer
+  static constexpr int LDS_ELEMS = 2 * BUF_ELEMS;      // double buffered
   static_assert(WTM % MM::TM == 0 && WTN % MM::TN == 0, "wave tile must be a multiple of the MFMA tile");
   static_assert((BM * BK) % NT == 0 && (BN * BK) % NT == 0, "fill must divide evenly");
   static_assert(BK % MM::TK == 0, "BK must be a multiple of the MFMA k");
@@ -238,8 +244,7 @@ struct TileGemm {
         const int m = a_m(g), kk = a_kk(g);
         const VT v = fa(ra[g < GA ? g : 0], m, kc + kk);
         if (AMODE == HB_KC) {
-#pragma unroll
-          for (int q = 0; q < VEC; ++q) buf[(kk + q) * LDA + m] = v[q];
+          *reinterpret_cast<VT*>(&buf[m * LDK + kk]) = v;
         } else {
           *reinterpret_cast<VT*>(&buf[kk * LDA + m]) = v;
         }
@@ -248,10 +253,9 @@ struct TileGemm {
         const int n = b_n(gb), kk = b_kk(gb);
         const VT v = fb(rb[gb >= 0 ? gb : 0], kc + kk, n);
         if (BMODE == HB_KC) {
-#pragma unroll
-          for (int q = 0; q < VEC; ++q) buf[BK * LDA + (kk + q) * LDB + n] = v[q];
+          *reinterpret_cast<VT*>(&buf[A_ELEMS + n * LDK + kk]) = v;
         } else {
-          *reinterpret_cast<VT*>(&buf[BK * LDA + kk * LDB + n]) = v;
+          *reinterpret_cast<VT*>(&buf[A_ELEMS + kk * LDB + n]) = v;
         }
       }
     };
@@ -267,15 +271,41 @@ struct TileGemm {
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       const T* __restrict__ As = lds + cur * BUF_ELEMS;
-      const T* __restrict__ Bs = As + BK * LDA;
+      const T* __restrict__ Bs = As + A_ELEMS;
       T* __restrict__ nxt = lds + (cur ^ 1) * BUF_ELEMS;
+      // MFMA sub-step s contracts, for the lane's k-group h = lane / T{M,N}, over k = h*NS + s (the
+      // contraction order is free as long as both operands agree): a lane's NS values are consecutive in k
+      static_assert(NS % VEC == 0 && MM::TK * NS == BK, "fragment vectors");
       T a[NS][RM], b[NS][RN];
+      if (AMODE == HB_KC) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
+        for (int i = 0; i < RM; ++i)
 #pragma unroll
-        for (int i = 0; i < RM; ++i) a[s][i] = As[(s * MM::TK + ak) * LDA + am + i * MM::TM];
+          for (int q = 0; q < NS; q += VEC) {
+            const VT v = *reinterpret_cast<const VT*>(&As[(am + i * MM::TM) * LDK + ak * NS + q]);
 #pragma unroll
-        for (int j = 0; j < RN; ++j) b[s][j] = Bs[(s * MM::TK + bk) * LDB + bn + j * MM::TN];
+            for (int e = 0; e < VEC; ++e) a[q + e][i] = v[e];
+          }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int i = 0; i < RM; ++i) a[s][i] = As[(ak * NS + s) * LDA + am + i * MM::TM];
+      }
+      if (BMODE == HB_KC) {
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int q = 0; q < NS; q += VEC) {
+            const VT v = *reinterpret_cast<const VT*>(&Bs[(bn + j * MM::TN) * LDK + bk * NS + q]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) b[q + e][j] = v[e];
+          }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int j = 0; j < RN; ++j) b[s][j] = Bs[(bk * NS + s) * LDB + bn + j * MM::TN];
       }
       // keep ALL fragment reads issued here: the compiler otherwise sinks each ds_read in front of
       // its MFMA and pays the LDS latency once per MFMA group instead of once per k-step

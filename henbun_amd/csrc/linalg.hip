@@ -46,7 +46,7 @@ struct MmBK {
 template <typename T, bool TA, bool TB, bool FAST, int BT>
 __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
   typedef TileGemm<T, BT, BT, MmBK<T, TA, TB, BT>::value, 2, 2> G;
-  __shared__ T lds[G::LDS_ELEMS];
+  __shared__ __attribute__((aligned(16))) T lds[G::LDS_ELEMS];
   const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
   const int lda = (int)a.lda, ldb = (int)a.ldb;
   const int tiles_n = (N + BT - 1) / BT;
@@ -217,9 +217,26 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
     if (s0 > 64) s0 = 64;
     if (s0 >= 2) S = (int)s0;
   }
+  {
+    // diagnostic overrides (tools/stride_probe.py): HB_MM_FORCE_BT=64|128, HB_MM_FORCE_S=<slabs>
+    static const char* fbt = getenv("HB_MM_FORCE_BT");
+    static const char* fs = getenv("HB_MM_FORCE_S");
+    if (fbt) {
+      BT = atoi(fbt) == 128 ? 128 : 64;
+      a.tile = BT;
+    }
+    if (fs && ws) {
+      long s = atol(fs);
+      const long s3 = ws_elems / (batch * M * N);
+      if (s > s3) s = s3;
+      if (s > K / 16) s = K / 16;
+      S = s < 1 ? 1 : (int)s;
+    }
+  }
   a.S = S;
   a.to_ws = (S > 1 || (flags & HB_MM_SYM_OUT)) ? 1 : 0;
-  dim3 grid((unsigned)tiles, (unsigned)batch, (unsigned)S);
+  const long tiles_final = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
+  dim3 grid((unsigned)tiles_final, (unsigned)batch, (unsigned)S);
   constexpr long VEC = 16 / sizeof(T);
   const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % VEC == 0 && ldb % VEC == 0 &&
                        sA % VEC == 0 && sB % VEC == 0;
@@ -803,7 +820,7 @@ template <typename T, int PHASE, bool FAST>
 __global__ void __launch_bounds__(256) trinv_level_kernel(const T* __restrict__ L, T* __restrict__ W,
                                                           T* __restrict__ Tm, long Ml, long sl) {
   typedef TileGemm<T, 64, 64, 16, 2, 2> G;
-  __shared__ T lds[G::LDS_ELEMS];
+  __shared__ __attribute__((aligned(16))) T lds[G::LDS_ELEMS];
   const long b = blockIdx.z;
   L += b * Ml * Ml;
   W += b * Ml * Ml;

@@ -75,7 +75,7 @@ struct SgpZ {
 template <typename T, int D, bool FAST>
 __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
   typedef TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2> G;
-  __shared__ T lds[G::LDS_ELEMS + (D > 0 ? SGP_ZS_MAX : 1)];
+  __shared__ __attribute__((aligned(16))) T lds[G::LDS_ELEMS + (D > 0 ? SGP_ZS_MAX : 1)];
   T* zs = lds + G::LDS_ELEMS;
   const long e = blockIdx.z;
   const T* x = a.x + e * a.sx;
@@ -102,16 +102,19 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
 
   typedef typename TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2>::VT VT;
   constexpr int VEC = TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2>::VEC;
-  // vector path: this thread's B-operand group is always the same VEC columns
-  T xv[VEC][D > 0 ? D : 1];
+  constexpr int DD = D > 0 ? D : 1;
+  // vector path: the RBF block is synthesised "k-contiguous" -- a group is VEC consecutive inducing points
+  // for ONE data column, so it lands in LDS with one 16-byte write and is read back as 16-byte fragments.
+  // A thread's groups always sit on the same GB columns: column of group g = (g*256 + tid) / (BK/VEC).
+  constexpr int GBc = G::GB, GPR = 16 / VEC;  // groups per thread, groups per tile row
+  T xg[GBc][DD];
   if (FAST) {
-    const int n4 = col0 + (threadIdx.x % (SGP_BN / VEC)) * VEC;
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) {
-      const int cc = n4 + q < n ? n4 + q : n - 1;  // out-of-range columns compute garbage that is never stored
+    for (int gq = 0; gq < GBc; ++gq) {
+      const int cl = (gq * 256 + (int)threadIdx.x) / GPR;
+      const int cc = col0 + cl < n ? col0 + cl : n - 1;  // out-of-range columns compute garbage that is never stored
 #pragma unroll
-      for (int dd = 0; dd < (D > 0 ? D : 1); ++dd)
-        xv[q][dd] = x[cc * (D > 0 ? D : 1) + dd] * (T(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd]);
+      for (int dd = 0; dd < DD; ++dd) xg[gq][dd] = x[cc * DD + dd] * (T(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd]);
     }
   }
 
@@ -174,29 +177,43 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
         for (int q = 0; q < VEC; ++q) v[q] = ((r < M) & (k + q <= r)) ? raw[q] : T(0);
         return v;
       };
-      // the scaled inducing coordinate of row k is the B operand's "raw" value: read from LDS one
-      // iteration ahead, like a global load, so its latency is off the critical path
-      auto lb4 = [&](int k, int nn) -> SgpZ<T, (D > 0 ? D : 1)> {
-        SgpZ<T, (D > 0 ? D : 1)> r;
+      // the scaled inducing coordinates of rows k..k+VEC-1 are the B operand's "raw" value: read from LDS
+      // one iteration ahead, like a global load, so the latency is off the critical path
+      auto lb4 = [&](int k, int nn) -> SgpZ<T, VEC * DD> {
+        SgpZ<T, VEC * DD> r;
+        if (DD == 1) {
+          const VT v = *reinterpret_cast<const VT*>(&zs[k]);
 #pragma unroll
-        for (int dd = 0; dd < (D > 0 ? D : 1); ++dd) r.z[dd] = zs[k * D + dd];
+          for (int q = 0; q < VEC; ++q) r.z[q] = v[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < VEC * DD; ++q) r.z[q] = zs[k * DD + q];
+        }
         return r;
       };
-      auto fb4 = [&](SgpZ<T, (D > 0 ? D : 1)> raw, int k, int nn) -> VT {
+      auto fb4 = [&](SgpZ<T, VEC * DD> raw, int k, int nn) -> VT {
+        // which of this thread's columns: groups are laid out GPR per column, 256/GPR columns per group index
+        T xc[DD];
+#pragma unroll
+        for (int dd = 0; dd < DD; ++dd) {
+          xc[dd] = xg[0][dd];
+#pragma unroll
+          for (int gq = 1; gq < GBc; ++gq) xc[dd] = nn >= gq * (256 / GPR) ? xg[gq][dd] : xc[dd];
+        }
         VT v;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
           T r2 = T(0);
 #pragma unroll
-          for (int dd = 0; dd < (D > 0 ? D : 1); ++dd) {
-            const T t = raw.z[dd] - xv[q][dd];
+          for (int dd = 0; dd < DD; ++dd) {
+            const T t = raw.z[q * DD + dd] - xc[dd];
             r2 += t * t;
           }
           v[q] = hb_exp2_neg<T>(r2);
         }
         return v;
       };
-      g.template run_vec<HB_KC, HB_MC>(0, kend, la4, fa4, lb4, fb4, lds);
+      g.template run_vec<HB_KC, HB_KC>(0, kend, la4, fa4, lb4, fb4, lds);
     } else {
       g.template run<true, false>(0, kend, la, fa, lb, fb, lds);
     }
@@ -555,7 +572,7 @@ struct SgpRawB4 {
 template <typename T, bool FAST>
 __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
   typedef TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2> G;
-  __shared__ T lds[G::LDS_ELEMS];
+  __shared__ __attribute__((aligned(16))) T lds[G::LDS_ELEMS];
   const long e = blockIdx.z;
   const T* W = a.W + e * a.M * a.M;
   const T* u = a.u + e * a.P * a.M;

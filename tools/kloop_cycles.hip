@@ -40,25 +40,34 @@ template <int BM, int BN, int BK, int AMODE, int BMODE>
 void bench(const char* name, const float* A, const float* B, float* C, long long* cyc, int grid) {
   const int K = 512;  // operands [512 x 512]: 1 MB each, L2 resident after the first pass
   typedef TileGemm<float, BM, BN, BK, 2, 2> G;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((kern<BM, BN, BK, AMODE, BMODE>), dim3(grid), dim3(256), 0, 0, A, B, C, 512, 512, K, cyc);
+  (void)hipEventRecord(e0);
+  for (int rep = 0; rep < 10; ++rep) hipLaunchKernelGGL((kern<BM, BN, BK, AMODE, BMODE>), dim3(grid), dim3(256), 0, 0, A, B, C, 512, 512, K, cyc);
+  (void)hipEventRecord(e1);
   (void)hipDeviceSynchronize();
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  const double kernel_us = ms * 1e3 / 10;
   std::vector<long long> h(2 * grid);
   (void)hipMemcpy(h.data(), cyc, sizeof(long long) * 2 * grid, hipMemcpyDeviceToHost);
   double sc = 0, st = 0;
   for (int i = 0; i < grid; ++i) { sc += h[2 * i]; st += h[2 * i + 1]; }
   const int steps = K / BK;
   const double mfma = (double)G::NS * G::RM * G::RN * 64.0;
-  printf("%-34s grid %4d: %8.0f clk/k-step (MFMA-only ideal %5.0f -> %4.1f%%), wall %6.2f us total (100MHz ticks %g)\n", name, grid,
-         sc / grid / steps, mfma, 100.0 * mfma / (sc / grid / steps), st / grid / 100.0, st / grid);
+  const double chip_util = (double)grid * 4 * steps * mfma / (1024.0 * kernel_us * 2400.0);
+  printf("%-34s grid %4d: %8.0f clk/k-step per WG (ideal %5.0f -> %4.1f%%), kernel %6.2f us, chip MFMA utilisation %4.1f%%\n", name, grid,
+         sc / grid / steps, mfma, 100.0 * mfma / (sc / grid / steps), kernel_us, 100.0 * chip_util);
 }
 
 int main() {
   float *A, *B, *C;
   long long* cyc;
-  (void)hipMalloc(&A, 512 * 512 * 4); (void)hipMalloc(&B, 512 * 512 * 4); (void)hipMalloc(&C, 1 << 20); (void)hipMalloc(&cyc, 8 * 4096);
+  (void)hipMalloc(&A, 512 * 512 * 4); (void)hipMalloc(&B, 512 * 512 * 4); (void)hipMalloc(&C, 1 << 20); (void)hipMalloc(&cyc, 16 * 4096);
   (void)hipMemset(A, 0, 512 * 512 * 4); (void)hipMemset(B, 0, 512 * 512 * 4);
-  for (int grid : {1, 256}) {
-    bench<64, 128, 16, HB_KC, HB_MC>("64x128 BK16 KC/MC (sgp_A shape)", A, B, C, cyc, grid);
+  for (int grid : {256, 512, 1024}) {
+    bench<64, 128, 16, HB_KC, HB_KC>("64x128 BK16 KC/KC (sgp_A shape)", A, B, C, cyc, grid);
+    bench<64, 128, 16, HB_KC, HB_MC>("64x128 BK16 KC/MC", A, B, C, cyc, grid);
     bench<64, 128, 16, HB_MC, HB_MC>("64x128 BK16 MC/MC (kbar shape)", A, B, C, cyc, grid);
     bench<128, 128, 16, HB_KC, HB_KC>("128x128 BK16 KC/KC (Lbar shape)", A, B, C, cyc, grid);
     bench<128, 128, 32, HB_KC, HB_KC>("128x128 BK32 KC/KC", A, B, C, cyc, grid);
