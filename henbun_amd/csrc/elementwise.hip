@@ -205,6 +205,8 @@ extern "C" int hb_ewise_f64(int op, int nin, const void* const* in, const long* 
 #define HB_PROG_MAX_OUT 6
 #define HB_PROG_MAX_DIMS 4
 #define HB_PROG_MAX_REGS 40
+#define HB_PROG_SUM 256  // out_regs[k] flag: sum-reduce (forces a single workgroup; space <= HB_PROG_SUM_MAX_N)
+#define HB_PROG_SUM_MAX_N 65536
 
 struct ProgArgs {
   int ninstr, nin, nout, ndim;
@@ -214,7 +216,7 @@ struct ProgArgs {
   long ostr[HB_PROG_MAX_OUT][HB_PROG_MAX_DIMS];
   const void* in[HB_PROG_MAX_IN];
   void* out[HB_PROG_MAX_OUT];
-  int out_reg[HB_PROG_MAX_OUT];
+  int out_reg[HB_PROG_MAX_OUT];     // register written to out[k]; + HB_PROG_SUM: its SUM over the whole space -> out[k][0]
   short code[HB_PROG_MAX_INSTR][5];  // op, dst, a, b, c
   double params[HB_PROG_MAX_INSTR][2];
 };
@@ -222,6 +224,10 @@ struct ProgArgs {
 template <typename T>
 __global__ void __launch_bounds__(256) ew_prog_kernel(ProgArgs A) {
   __shared__ T regs[HB_PROG_MAX_REGS][256];
+  __shared__ T red_smem[16];
+  T racc[HB_PROG_MAX_OUT];
+#pragma unroll
+  for (int k = 0; k < HB_PROG_MAX_OUT; ++k) racc[k] = T(0);
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += stride) {
     int idx[HB_PROG_MAX_DIMS] = {0, 0, 0, 0};
@@ -257,7 +263,13 @@ __global__ void __launch_bounds__(256) ew_prog_kernel(ProgArgs A) {
         reg(dst + 2) = o2;
       }
     }
-    for (int k = 0; k < A.nout; ++k) {
+#pragma unroll
+    for (int k = 0; k < HB_PROG_MAX_OUT; ++k) {
+      if (k >= A.nout) break;
+      if (A.out_reg[k] & HB_PROG_SUM) {
+        racc[k] += reg(A.out_reg[k] & (HB_PROG_SUM - 1));
+        continue;
+      }
       long off = 0;
       bool write = true;
 #pragma unroll
@@ -271,6 +283,14 @@ __global__ void __launch_bounds__(256) ew_prog_kernel(ProgArgs A) {
     }
   }
 #undef reg
+  // sum-reduced outputs: the launcher runs such programs as ONE workgroup, so a block reduction finishes them
+#pragma unroll
+  for (int k = 0; k < HB_PROG_MAX_OUT; ++k) {
+    if (k < A.nout && (A.out_reg[k] & HB_PROG_SUM)) {
+      const T s = block_sum(racc[k], red_smem);
+      if (threadIdx.x == 0) ((T*)A.out[k])[0] = s;
+    }
+  }
 }
 
 template <typename T>
@@ -314,9 +334,15 @@ static int ew_prog_launch(int ninstr, const int* code, const double* params, int
     if (extra) HB_REQUIRE(params[q * 2] >= 0 && params[q * 2] < HB_PROG_MAX_REGS, "hb_ewise_prog: 4th operand register out of range");
     if (code[q * 5 + 1] + extra + 1 > maxreg) maxreg = code[q * 5 + 1] + extra + 1;
   }
-  for (int k = 0; k < nout; ++k)
-    HB_REQUIRE(out_regs[k] >= 0 && out_regs[k] < maxreg, "hb_ewise_prog: output register never written");
-  hipLaunchKernelGGL(ew_prog_kernel<T>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, A);
+  bool reduces = false;
+  for (int k = 0; k < nout; ++k) {
+    const int r = out_regs[k] & (HB_PROG_SUM - 1);
+    HB_REQUIRE(out_regs[k] >= 0 && out_regs[k] < 2 * HB_PROG_SUM && r < maxreg, "hb_ewise_prog: output register never written");
+    reduces = reduces || (out_regs[k] & HB_PROG_SUM);
+  }
+  HB_REQUIRE(!reduces || n <= HB_PROG_SUM_MAX_N, "hb_ewise_prog: sum-reduced outputs need a space of at most %d elements",
+             HB_PROG_SUM_MAX_N);
+  hipLaunchKernelGGL(ew_prog_kernel<T>, dim3(reduces ? 1 : hb_stream_grid(n, 256)), dim3(256), 0, stream, A);
   HB_LAUNCH_CHECK();
   return 0;
 }

@@ -72,6 +72,23 @@ struct SgpZ {
   T z[D];
 };
 
+// Row-block schedule of the triangular contractions.  gridDim.y == ceil(nRB/2): a workgroup takes the pair
+// (y, nRB-1-y) in turn, so every workgroup does the same work.  gridDim.y == nRB ("unpaired", chosen by the host
+// when the paired grid would leave one workgroup per CU): one row block per workgroup -- two workgroups are then
+// co-resident per CU and each fills the other's non-MFMA issue slots (tools/kloop_cycles.hip: 61 -> 72 % MFMA
+// utilisation) -- ordered so that workgroups y and y + nRB/2, which an in-order dispatch places together, are a
+// shallow and a deep block.
+__device__ __forceinline__ bool sgp_row_block(int half, int nRB, int& rb) {
+  const int y = (int)blockIdx.y;
+  if ((int)gridDim.y == nRB && nRB > 1) {
+    const int h = nRB / 2;
+    rb = y < h ? y : nRB - 1 - (y - h);
+    return half == 0;
+  }
+  rb = half == 0 ? y : nRB - 1 - y;
+  return !(half == 1 && rb <= y);  // odd count: the middle block is handled once
+}
+
 template <typename T, int D, bool FAST>
 __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
   typedef TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2> G;
@@ -130,8 +147,8 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
   const int npart = a.part ? (int)a.P : 0;
 
   for (int half = 0; half < 2; ++half) {
-    const int rb = half == 0 ? (int)blockIdx.y : nRB - 1 - (int)blockIdx.y;
-    if (half == 1 && rb <= (int)blockIdx.y) break;  // odd count: middle block handled once
+    int rb;
+    if (!sgp_row_block(half, nRB, rb)) break;
     const int row0 = rb * SGP_BM;
     int kend = row0 + SGP_BM;
     if (kend > M) kend = M;
@@ -417,9 +434,15 @@ __global__ void __launch_bounds__(256) sgp_rng_fill_kernel(uint64_t* state, long
 
 extern "C" long hb_sgp_ws_elems(long E, long n, long M, long d, long P) {
   (void)P;
-  const long gy = ((M + SGP_BM - 1) / SGP_BM + 1) / 2;
+  const long gy = (M + SGP_BM - 1) / SGP_BM;  // most row blocks a column's statistics can be split over
   const long mm = 32 * E * M * M, part = 5 * E * gy * n;  // backward split-K slabs / forward column partials
   return E * n + E * M * d + (mm > part ? mm : part);
+}
+
+// paired grid when it already gives the chip ~1.5 workgroups per CU, else one row block per workgroup
+static inline int sgp_grid_y(long E, long n, int nRB) {
+  const long paired = (long)hb_cdiv(n, SGP_BN) * ((nRB + 1) / 2) * E;
+  return (paired < 384 && nRB > 1) ? nRB : (nRB + 1) / 2;
 }
 
 template <typename T>
@@ -437,7 +460,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   const bool draw = mode == HB_SGP_DIAGONAL && !eps_in;
   if (draw) HB_REQUIRE(rng && rng_lanes > 0 && eps_out, "hb_sgp_fwd: need eps_in, or rng and eps_out");
   const int nRB = hb_cdiv(M, SGP_BM);
-  const int gy = (nRB + 1) / 2;
+  const int gy = sgp_grid_y(E, n, nRB);
   // fused path: the contraction kernel leaves per-column partial sums, one small kernel finishes f, v (and draws eps)
   if (M > 0 && P <= 4 && ws) {
     SgpArgs<T> a;
@@ -498,7 +521,7 @@ static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, l
   a.n = n; a.M = M; a.d = d; a.P = 0;
   a.part = nullptr;
   const int nRB = hb_cdiv(M, SGP_BM);
-  dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
+  dim3 grid(hb_cdiv(n, SGP_BN), sgp_grid_y(E, n, nRB), (unsigned)E);
   return sgp_A_launch<T>(a, grid, stream);
 }
 extern "C" int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
@@ -604,8 +627,8 @@ __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
   }
 
   for (int half = 0; half < 2; ++half) {
-    const int rb = half == 0 ? (int)blockIdx.y : nRB - 1 - (int)blockIdx.y;
-    if (half == 1 && rb <= (int)blockIdx.y) break;
+    int rb;
+    if (!sgp_row_block(half, nRB, rb)) break;
     const int row0 = rb * SGP_BM;
     G g;
     g.zero();
@@ -921,7 +944,7 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.W = W; a.u = u; a.A = A; a.fbar = fbar; a.eps = eps; a.v = v; a.Kbar = Kbar;
     a.n = n; a.M = M; a.P = P; a.mode = mode;
     const int nRB = hb_cdiv(M, SGP_BM);
-    dim3 grid(hb_cdiv(n, SGP_BN), (nRB + 1) / 2, (unsigned)E);
+    dim3 grid(hb_cdiv(n, SGP_BN), sgp_grid_y(E, n, nRB), (unsigned)E);
     constexpr long VECH = 16 / sizeof(T);
     const bool vec = P == 1 && M % 16 == 0 && n % VECH == 0 && ((uintptr_t)W % 16 == 0) && ((uintptr_t)A % 16 == 0);
     if (vec)

@@ -86,8 +86,11 @@ int hb_ewise_f64(int op, int nin, const void* const* in, const long* istrides, i
  * (read with `istrides`); instruction q = code[q] = {op, dst, a, b, c} (HB_EW_* op on registers a,b,c;
  * HB_EW_GAUSS_LOGPDF_GRAD takes the register number of its 4th operand in params[q][0] and writes
  * dst..dst+2) with params[q][2]; output k = register out_regs[k] stored with `ostrides` (a 0 stride on a dim of extent > 1
- * marks a broadcast dim: only index 0 writes).  All array arguments are (host) arrays.  Replaces the
+ * marks a broadcast dim: only index 0 writes); out_regs[k] + HB_EW_PROG_SUM instead writes the SUM of that
+ * register over the whole space to out[k][0] (tf.reduce_sum of a chain's result; the program then runs as one
+ * workgroup, space <= 65536 elements).  All array arguments are (host) arrays.  Replaces the
  * chains of tiny TF elementwise ops of the reference's graph at one launch per chain. */
+enum { HB_EW_PROG_SUM = 256 };
 int hb_ewise_prog_f32(int ninstr, const int* code, const double* params, int nin, const void* const* in,
                       const long* istrides, int nout, void* const* out, const int* out_regs,
                       const long* ostrides, int ndim, const long* shape, void* stream);

@@ -648,3 +648,26 @@ def test_gram_symmetric_bwd_and_jitter(H, kind):
     assert_close(lb, gl, TOL["f64"])
     got = H.gram_fwd(Xd, Xd, ld, kind=k, diag_add=0.25)
     assert_close(got, K.detach() + 0.25 * torch.eye(n, dtype=dt), TOL["f64"])
+
+
+@pytest.mark.parametrize("p", ["f32", "f64"])
+@pytest.mark.parametrize("n", [1, 255, 4097])
+def test_ewise_program_sum_outputs(H, p, n):
+    """out_regs + EW_PROG_SUM: the sum of a register over the whole space comes out of the same launch."""
+    dt = DT[p]
+    rng = np.random.RandomState(n)
+    a, b = rng.randn(3, n), rng.randn(1, n)
+    ins = [dev(a, dt), dev(b, dt)]
+    code = [[H.EW["MUL"], 2, 0, 1, 0], [H.EW["ADD"], 3, 2, 0, 0]]
+    params = [[0.0, 0.0], [0.0, 0.0]]
+    outs = [torch.empty(3, n, dtype=dt, device="cuda"), torch.empty(1, dtype=dt, device="cuda"),
+            torch.empty(1, dtype=dt, device="cuda")]
+    istr = [[n, 1], [0, 1]]
+    ostr = [[n, 1], [0, 0], [0, 0]]
+    prog = H.EwiseProgram(code, params, ins, istr, outs, [3, 2 + H.EW_PROG_SUM, 3 + H.EW_PROG_SUM], ostr, [3, n])
+    prog.launch()
+    prod = a * b
+    tol = TOL[p] if p == "f64" else dict(rtol=1e-4, atol=1e-3)
+    assert_close(outs[0], prod + a, TOL[p])
+    assert_close(outs[1], np.array([prod.sum()]), tol)
+    assert_close(outs[2], np.array([(prod + a).sum()]), tol)
