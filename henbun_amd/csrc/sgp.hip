@@ -18,6 +18,7 @@
 // E * M^2 * n (Kbar = W^T Abar), E * M^2 * n (Lbar = -tril(Kbar A^T)).
 // The roofline that bounds them is the f32 MFMA peak (v_mfma_f32_32x32x2_f32).
 #include "common.cuh"
+#include <type_traits>
 #include "gemm_tile.cuh"
 #include "rng_pairs.cuh"
 #include "../../include/henbun_hip.h"
@@ -290,6 +291,239 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// forward, column-strip form (fp32, M <= 512, M % 32 == 0, d <= SGP_DREG)
+//
+// One workgroup owns a strip of 32 data columns and ALL M rows.  The strip's RBF block
+// K(z, x[strip]) -- M x 32 -- is synthesised ONCE into LDS (one exp per element, where the tiled
+// kernel above re-synthesises it per row block: 4.5x the exps at M = 512), and then every wave
+// runs its own row tiles through the contraction with NO barriers and no LDS staging of W:
+//   * B fragments: two 16-byte LDS reads per 16-deep step, shared by all the wave's row tiles;
+//   * A fragments: W rows straight from global/L2 into registers (the contraction index is
+//     permuted so a lane reads 32 contiguous bytes of its row), prefetched one step ahead;
+//   * wave w takes the 32-row tiles {w, 7-w, 8+w, 15-w}: every wave contracts the same depth.
+// That is ~0.5 non-MFMA instructions per MFMA against ~3 in the tiled kernel, which matters
+// because on gfx950 the fp32 MFMA shares the wave's issue slot with everything else.
+// The epilogue leaves the same column statistics (one partial row: gy = 1).
+// ---------------------------------------------------------------------------
+// In-kernel phase stamps: compiled in only by tools/strip_stamps.hip (diagnostic build).
+#ifndef HB_SSTAMP
+#define HB_SSTAMP(i)
+#endif
+#define SGP_SN 32
+#define SGP_SM_MAX 512
+#define SGP_SLD (SGP_SM_MAX + 4)
+
+__device__ __forceinline__ int sgp_strip_tile(int w, int j) { return (j & 1) ? 8 * (j >> 1) + 7 - w : 8 * (j >> 1) + w; }
+
+template <int D>
+__global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef Mma<float> MM;
+  __shared__ __attribute__((aligned(16))) float Ks[SGP_SN][SGP_SLD];
+  __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
+  const long e = blockIdx.z;
+  const float* __restrict__ x = a.x + e * a.sx;
+  const float* __restrict__ z = a.z + e * a.M * D;
+  const float* __restrict__ ell = a.ell + e * a.dl;
+  const float* __restrict__ W = a.W + e * a.M * a.M;
+  float* __restrict__ A = a.A + e * a.M * a.n;
+  const int M = (int)a.M, n = (int)a.n;
+  const int col0 = blockIdx.x * SGP_SN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+
+  HB_SSTAMP(0);
+  // ---- K(z, x[strip]) -> LDS, [column][k]: thread (c = tid % 32, kq = tid / 32) takes the 16-byte groups kq, kq+8, ...
+  // z is staged (pre-scaled) in LDS first: read straight from global, every group would be a dependent
+  // load round trip (measured: the prologue alone cost ~10 us).
+  {
+    const int c = tid & 31, kq = tid >> 5;
+    const int cc = col0 + c < n ? col0 + c : n - 1;  // columns past n compute garbage that is never stored
+    float sc[D], xs[D];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
+      xs[dd] = x[cc * D + dd] * sc[dd];
+    }
+    for (int i = tid; i < M * D; i += 256) zs[i] = z[i] * sc[i % D];
+    __syncthreads();
+#pragma unroll 4
+    for (int k4 = kq * 4; k4 < M; k4 += 32) {
+      float zq[4 * D];
+#pragma unroll
+      for (int q = 0; q < 4 * D; q += 4) {
+        const V4 zz = *reinterpret_cast<const V4*>(&zs[k4 * D + q]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) zq[q + s] = zz[s];
+      }
+      V4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float r2 = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          const float tt = zq[q * D + dd] - xs[dd];
+          r2 += tt * tt;
+        }
+        v[q] = hb_exp2_neg<float>(r2);
+      }
+      *reinterpret_cast<V4*>(&Ks[c][k4]) = v;
+    }
+  }
+  __syncthreads();
+
+  HB_SSTAMP(1);
+  // (w, 7-w, 8+w, 15-w) is ascending; the tiles that exist (< nT) are a prefix of it.  They go to the LAST slots,
+  // so that "slots >= P" is always a set of real tiles in order of increasing depth.
+  const int nT = M / 32;
+  int nv = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) nv += sgp_strip_tile(w, j) < nT ? 1 : 0;
+  int tile[4];
+  bool tv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    tv[j] = j >= 4 - nv;
+    tile[j] = tv[j] ? sgp_strip_tile(w, j - (4 - nv)) : 0;  // empty slots point at a valid row block (prefetch stays in bounds)
+  }
+  typename MM::Acc acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // The wave's tiles are in order of increasing depth (tile j is active while Q < dep[j] = tile_j + 1 steps of 32),
+  // so the loop splits into four phases with tiles j >= P active: no per-tile branch inside a phase (the
+  // accumulators stay in AGPRs), and only tile P's last step crosses the diagonal and needs the k <= row mask.
+  // A step is 32 deep: lane (row, h) reads the 64 contiguous bytes k = 32Q + 16h .. +15 of its W row, so the
+  // two lanes of a row consume one whole 128-byte line per step (16-deep steps fetched every line twice: the
+  // 64 KB of lines a workgroup touches per step do not survive in L1 until the next one).
+  int dep[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dep[j] = tv[j] ? tile[j] + 1 : 0;
+  V4 an[4][4];
+  auto load_a = [&](int Q, auto pc) {
+    constexpr int P = decltype(pc)::value;
+#pragma unroll
+    for (int j = P; j < 4; ++j) {
+      int qq = Q < dep[j] ? Q : dep[j] - 1;  // finished tile: re-read its last step (never used)
+      qq = qq < 0 ? 0 : qq;                   // empty slot (depth 0): stay inside W
+      const float* p = W + (32 * tile[j] + li) * M + 32 * qq + 16 * h;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) an[j][v] = *reinterpret_cast<const V4*>(p + 4 * v);
+    }
+  };
+  auto step = [&](int Q, auto pc, auto mc) {
+    constexpr int P = decltype(pc)::value;
+    constexpr bool MASK = decltype(mc)::value;
+    V4 ac[4][4];
+#pragma unroll
+    for (int j = P; j < 4; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) ac[j][v] = an[j][v];
+    if (Q + 1 < dep[3]) load_a(Q + 1, pc);  // prefetch (a tile that finishes now re-reads its last step: harmless)
+    V4 bv[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bv[v] = *reinterpret_cast<const V4*>(&Ks[li][32 * Q + 16 * h + 4 * v]);
+    if (MASK) {
+      // W is lower triangular: entries k > row are not part of it (only tile P crosses the diagonal here)
+      const int r = 32 * tile[P] + li, kb = 32 * Q + 16 * h;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ac[P][v][s] = (kb + 4 * v + s <= r) ? ac[P][v][s] : 0.f;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = P; j < 4; ++j) acc[j] = MM::mma(ac[j][v][s], bv[v][s], acc[j]);
+  };
+  auto phase = [&](int q0, auto pc) {
+    constexpr int P = decltype(pc)::value;
+    const int q1 = dep[P];
+    int Q = q0;
+    for (; Q < q1 - 1; ++Q) step(Q, pc, std::false_type());
+    for (; Q < q1; ++Q) step(Q, pc, std::true_type());
+    return q1 > q0 ? q1 : q0;
+  };
+  if (dep[3] > 0) {
+    load_a(0, std::integral_constant<int, 0>());
+    int Q = 0;
+    Q = phase(Q, std::integral_constant<int, 0>());
+    HB_SSTAMP(2);
+    Q = phase(Q, std::integral_constant<int, 1>());
+    HB_SSTAMP(3);
+    Q = phase(Q, std::integral_constant<int, 2>());
+    HB_SSTAMP(4);
+    Q = phase(Q, std::integral_constant<int, 3>());
+  }
+  HB_SSTAMP(5);
+
+  // ---- epilogue: A rows, column statistics
+  const int npart = a.part ? (int)a.P : 0;
+  float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int gc = col0 + li;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!tv[j]) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * tile[j] + MM::acc_row(lane, r);
+      const float v = acc[j][r];
+      if (gc < n) A[(long)row * n + gc] = v;
+      if (a.part) {
+        cs[0] += v * v;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (p < npart) cs[1 + p] += a.u[e * a.P * a.M + (long)p * M + row] * v;
+      }
+    }
+  }
+  if (a.part) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) cs[q] += __shfl_xor(cs[q], 32);
+    __syncthreads();  // every wave is done reading the K block
+    float* red = &Ks[0][0];  // [4 waves][5][32]
+    if (lane < 32) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) red[(w * 5 + q) * 32 + lane] = cs[q];
+    }
+    __syncthreads();
+    if (tid < 32 && col0 + tid < n) {
+      float* pp = a.part + e * 5 * a.n + col0 + tid;  // gy = 1
+      for (int q = 0; q < 1 + npart; ++q)
+        pp[(long)q * n] = red[q * 32 + tid] + red[(5 + q) * 32 + tid] + red[(10 + q) * 32 + tid] + red[(15 + q) * 32 + tid];
+    }
+  }
+  HB_SSTAMP(6);
+}
+
+// diagnostic switch: HB_SGP_NO_STRIP=1 forces the tiled kernels (A/B timing)
+static inline bool hb_sgp_no_strip() {
+  static const bool v = getenv("HB_SGP_NO_STRIP") != nullptr;
+  return v;
+}
+static inline bool sgp_strip_ok(long M, long d, const void* W) {
+  return M >= 32 && M <= SGP_SM_MAX && M % 32 == 0 && d <= SGP_DREG && ((uintptr_t)W % 16 == 0);
+}
+
+static int sgp_A_strip_launch(const SgpArgs<float>& a, long E, hipStream_t stream) {
+  dim3 grid(hb_cdiv(a.n, SGP_SN), 1, (unsigned)E);
+  if (a.d == 1)
+    hipLaunchKernelGGL(sgp_A_strip_kernel<1>, grid, dim3(256), 0, stream, a);
+  else if (a.d == 2)
+    hipLaunchKernelGGL(sgp_A_strip_kernel<2>, grid, dim3(256), 0, stream, a);
+  else if (a.d == 3)
+    hipLaunchKernelGGL(sgp_A_strip_kernel<3>, grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(sgp_A_strip_kernel<4>, grid, dim3(256), 0, stream, a);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+static int sgp_A_strip_launch(const SgpArgs<double>&, long, hipStream_t) { return -1; }  // fp32 only
+
 // D dispatch: z staged in LDS when d <= SGP_DREG; vector operand path when, in
 // addition, M is a multiple of 16 and W is 16-byte aligned.
 template <typename T>
@@ -467,12 +701,19 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = u; a.A = A;
     a.n = n; a.M = M; a.d = d; a.P = P;
     a.part = ws + E * n + E * M * d;
-    dim3 grid(hb_cdiv(n, SGP_BN), gy, (unsigned)E);
-    int rc = sgp_A_launch<T>(a, grid, stream);
+    const bool strip = sizeof(T) == 4 && sgp_strip_ok(M, d, W) && !hb_sgp_no_strip();
+    const int gyp = strip ? 1 : gy;  // partial rows of the column statistics
+    int rc;
+    if (strip) {
+      rc = sgp_A_strip_launch(a, E, stream);
+    } else {
+      dim3 grid(hb_cdiv(n, SGP_BN), gy, (unsigned)E);
+      rc = sgp_A_launch<T>(a, grid, stream);
+    }
     if (rc) return rc;
     const long total = E * n;
     const int fgrid = draw ? hb_cdiv(rng_lanes, 256) : hb_stream_grid((total + 1) / 2, 256);
-    hipLaunchKernelGGL(sgp_finish_part_kernel<T>, dim3(fgrid), dim3(256), 0, stream, a.part, gy,
+    hipLaunchKernelGGL(sgp_finish_part_kernel<T>, dim3(fgrid), dim3(256), 0, stream, a.part, gyp,
                        mode == HB_SGP_DIAGONAL ? eps_in : (const T*)nullptr, draw ? rng : (uint64_t*)nullptr, rng_lanes,
                        mode == HB_SGP_DIAGONAL ? eps_out : (T*)nullptr, f, v, total, n, P, mode);
     HB_LAUNCH_CHECK();
@@ -520,6 +761,7 @@ static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, l
   a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = nullptr; a.A = A;
   a.n = n; a.M = M; a.d = d; a.P = 0;
   a.part = nullptr;
+  if (sizeof(T) == 4 && sgp_strip_ok(M, d, W) && !hb_sgp_no_strip()) return sgp_A_strip_launch(a, E, stream);
   const int nRB = hb_cdiv(M, SGP_BM);
   dim3 grid(hb_cdiv(n, SGP_BN), sgp_grid_y(E, n, nRB), (unsigned)E);
   return sgp_A_launch<T>(a, grid, stream);
