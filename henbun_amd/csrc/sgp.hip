@@ -322,6 +322,7 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
   typedef Mma<float> MM;
   __shared__ __attribute__((aligned(16))) float Ks[SGP_SN][SGP_SLD];
   __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
+  __shared__ float us[4][SGP_SM_MAX];  // u rows for the column statistics (staged once: the epilogue reads them per accumulator row)
   const long e = blockIdx.z;
   const float* __restrict__ x = a.x + e * a.sx;
   const float* __restrict__ z = a.z + e * a.M * D;
@@ -346,6 +347,9 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
       xs[dd] = x[cc * D + dd] * sc[dd];
     }
     for (int i = tid; i < M * D; i += 256) zs[i] = z[i] * sc[i % D];
+    if (a.part)
+      for (int p = 0; p < (int)a.P && p < 4; ++p)
+        for (int i = tid; i < M; i += 256) us[p][i] = a.u[e * a.P * a.M + (long)p * M + i];
     __syncthreads();
 #pragma unroll 4
     for (int k4 = kq * 4; k4 < M; k4 += 32) {
@@ -477,7 +481,7 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
         cs[0] += v * v;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          if (p < npart) cs[1 + p] += a.u[e * a.P * a.M + (long)p * M + row] * v;
+          if (p < npart) cs[1 + p] += us[p][row] * v;
       }
     }
   }
