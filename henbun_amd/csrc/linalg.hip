@@ -493,7 +493,10 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
             gc = gc < M ? gc : Mm1;
           }
           const T init = (ydiag && tr == tc) ? T(1) : T(0);
-          acc[si][sj][r] = fresh ? init : src[gr * M + gc];
+          // unconditional load + select (a fresh Y tile reads whatever its workspace holds and discards it): a
+          // conditional load compiles to a branch and an s_waitcnt vmcnt(0) per element -- serialised round trips
+          const T ld = src[gr * M + gc];
+          acc[si][sj][r] = fresh ? init : ld;
         }
   }
 
@@ -726,6 +729,297 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
   HB_STAMP(3);
 }
 
+// ===========================================================================
+// 64-column launches (fp32, M % 64 == 0): the same algorithm with two 32-column blocks per launch.
+// Half the launches means half the kernel boundaries, cold-start load round trips and panel stores on
+// the critical path (each ~1.5 + 2.3 + 0.9 us of the 8.8 us a 32-column launch costs); the price is a
+// rank-64 instead of a rank-32 update per wave tile (+1.3 us) -- the in-panel work (8-column steps) is
+// the same in total.  A wave tile is 32 rows x 64 columns (two 32x32 accumulators); a factor workgroup
+// stacks the 64x64 diagonal block (waves 0, 1) and 64 more rows (waves 2, 3) in LDS.
+// Row tiles are 32 rows (index rt), column blocks 64 wide (index j); the diagonal block of column j
+// (row tiles 2j, 2j+1) lives one block up, in the unused upper block (j-1, j), until it is factored.
+// ===========================================================================
+#define C64_NB 64
+#define C64_ROWS 128
+#define C64_LD 68
+
+static inline int chol64_factor_strips(int nrt, int k, int inv) {
+  const int n = (nrt - 2 * (k + 1)) + (inv ? 2 * (k + 1) : 0);
+  return n > 0 ? (n + 1) / 2 : 1;
+}
+static inline int chol64_grid(int nrt, int k, int inv) {
+  int g = chol64_factor_strips(nrt, k, inv);
+  if (k > 0)
+    for (int j = k + 1; j < nrt / 2; ++j) g += (nrt - 2 * j + (inv ? 2 * k : 0) + 3) / 4;
+  return g;
+}
+
+__global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict__ Ain, float* __restrict__ L,
+                                                        float* __restrict__ Y, float* __restrict__ W, int M, int k,
+                                                        int* __restrict__ info) {
+  typedef float T;
+  typedef Mma<float> MM;
+  typedef float VT __attribute__((ext_vector_type(4)));
+  constexpr int CK = 32;  // contraction entries per lane in the rank-64 update (128 bytes)
+  __shared__ __attribute__((aligned(16))) T Cs[C64_ROWS][C64_LD];
+  __shared__ __attribute__((aligned(16))) T Bs[C64_NB][C64_LD];  // panel rows of the column block (rank-64 update)
+
+  const long boff = (long)blockIdx.y * M * M;
+  Ain += boff;
+  L += boff;
+  const bool inv = Y != nullptr;
+  if (inv) {
+    Y += boff;
+    W += boff;
+  }
+  info += blockIdx.y;
+  const int nrt = M / 32, nblk = M / 64;
+  // workgroup -> (column block j, strip s)
+  int j = k, s = blockIdx.x;
+  {
+    const int nf = (nrt - 2 * (k + 1)) + (inv ? 2 * (k + 1) : 0);
+    int cnt = nf > 0 ? (nf + 1) / 2 : 1;
+    while (s >= cnt) {
+      s -= cnt;
+      ++j;
+      cnt = (nrt - 2 * j + (inv ? 2 * k : 0) + 3) / 4;
+    }
+  }
+  const bool factor = (j == k);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  // entry g of this workgroup's tile list -> (live, is a Y tile, row tile)
+  auto describe = [&](int g, bool& live_, bool& yt_, int& rt_) {
+    const int nA = factor ? nrt - 2 * (k + 1) : nrt - 2 * j;
+    const int nY = inv ? (factor ? 2 * (k + 1) : 2 * k) : 0;
+    const int e = factor ? 2 * s + g - 2 : 4 * s + g;
+    if (factor && g < 2) {
+      live_ = true, yt_ = false, rt_ = 2 * k + g;  // the diagonal block
+    } else if (e < nA) {
+      live_ = true, yt_ = false, rt_ = (factor ? 2 * (k + 1) : 2 * j) + e;
+    } else if (e < nA + nY) {
+      live_ = true, yt_ = true, rt_ = e - nA;
+    } else {
+      live_ = false, yt_ = false, rt_ = nrt - 1;  // idle wave: recompute a valid tile, store nothing
+    }
+  };
+  bool live, yt;
+  int rt;
+  describe(w, live, yt, rt);
+  const int row0 = rt * 32, col0 = j * C64_NB;
+  const bool adiag = !yt && (rt >> 1) == j;  // a row tile of column j's diagonal block
+  const bool ydiag = yt && (rt >> 1) == j;   // rows of the identity that start in this column: no update yet
+
+  HB_STAMP(0);
+  typename MM::Acc acc[2];
+  {
+    const T* src = yt ? Y : ((k <= 1) ? Ain : L);
+    const int hrow0 = (adiag && k >= 2) ? row0 - C64_NB : row0;  // home of a diagonal-block tile: one block up
+    const bool fresh = yt && (ydiag || k == (rt >> 1) + 1);
+    const int doff = 32 * (rt - 2 * j);  // ydiag: the 1s sit at column (row + doff)
+#pragma unroll
+    for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tr = MM::acc_row(lane, r), tc = sj * 32 + li;
+        const T init = (ydiag && tc == tr + doff) ? T(1) : T(0);
+        // unconditional load + select (a fresh Y tile reads whatever its workspace holds and discards it): a
+        // conditional load compiles to a branch and an s_waitcnt vmcnt(0) PER ELEMENT, i.e. 32 serialised round trips
+        const T ld = src[(hrow0 + tr) * M + col0 + tc];
+        acc[sj][r] = fresh ? init : ld;
+      }
+  }
+
+  if (k > 0) {
+    // rank-64 update by panel k-1.  The panel rows come in with coalesced 16-byte loads (16 lanes per 256-byte
+    // row) and are re-read from LDS as MFMA fragments: a lane loading its own fragment row directly makes every
+    // load instruction touch 64 different cache lines, and the address unit -- not the memory -- becomes the bound
+    // (tools/chol_stamps.hip: the load phase scaled with the number of load instructions, ~190 cycles each).
+    const int pc = (k - 1) * C64_NB;
+    {
+      // B rows (the 64 rows of column block j), shared by the four waves
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int r = p * 16 + (tid >> 4), c4 = (tid & 15) * 4;
+        *reinterpret_cast<VT*>(&Bs[r][c4]) = *reinterpret_cast<const VT*>(L + (col0 + r) * M + pc + c4);
+      }
+      // A rows of this wave's tile, staged in the wave's own rows of Cs
+      if (!ydiag) {
+        const T* ap = (yt ? Y : L) + row0 * M + pc;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int r = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+          *reinterpret_cast<VT*>(&Cs[w * 32 + r][c4]) = *reinterpret_cast<const VT*>(ap + r * M + c4);
+        }
+      }
+    }
+    __syncthreads();
+    if (!ydiag) {
+      // lane (li, h) contracts over entries [32h, 32h+32) of the panel rows
+#pragma unroll
+      for (int q = 0; q < CK / 4; ++q) {
+        const VT va = *reinterpret_cast<const VT*>(&Cs[w * 32 + li][32 * h + 4 * q]);
+        const VT vb0 = *reinterpret_cast<const VT*>(&Bs[li][32 * h + 4 * q]);
+        const VT vb1 = *reinterpret_cast<const VT*>(&Bs[32 + li][32 * h + 4 * q]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = MM::mma(-va[e], vb0[e], acc[0]);
+          acc[1] = MM::mma(-va[e], vb1[e], acc[1]);
+        }
+      }
+    }
+  }
+
+  HB_STAMP(1);
+  if (!factor) {
+    if (live) {
+      T* dst = yt ? Y : L;
+      const int wrow0 = adiag ? row0 - C64_NB : row0;
+#pragma unroll
+      for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(wrow0 + MM::acc_row(lane, r)) * M + col0 + sj * 32 + li] = acc[sj][r];
+    }
+    return;
+  }
+
+  // ---- factor column block k: stacked panel rows [32w, 32w+32) belong to wave w; rows 0..63 are the diagonal block
+  int fail = 0;
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+    // publish columns [8kb, 8kb+8) of the accumulators
+    {
+      const int sj = kb >> 2;
+      if ((li >> 3) == (kb & 3)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Cs[w * 32 + MM::acc_row(lane, r)][sj * 32 + li] = sj == 0 ? acc[0][r] : acc[1][r];
+      }
+    }
+    __syncthreads();
+    if (tid < C64_ROWS) {
+      // potrf8 on Cs[8kb.., 8kb..] (every lane, in registers, by columns in register pairs) + this thread's row solve
+      typedef T T2 __attribute__((ext_vector_type(2)));
+      T2 col[8][4];
+      T pinv[8];
+      {
+        T p[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int q = 0; q < 8; q += 4) {
+            const VT v = *reinterpret_cast<const VT*>(&Cs[8 * kb + i][8 * kb + q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[i][q + e] = v[e];
+          }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int hh = 0; hh < 4; ++hh) {
+            col[c][hh][0] = (2 * hh >= c) ? p[2 * hh][c] : p[c][2 * hh];
+            col[c][hh][1] = (2 * hh + 1 >= c) ? p[2 * hh + 1][c] : p[c][2 * hh + 1];
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const T d = col[c][c / 2][c % 2];
+        if (fail == 0 && !(d > T(0))) fail = 8 * kb + c + 1;
+        T lcc, pi;
+        pivot_sqrt(d, lcc, pi);
+        pinv[c] = pi;
+        const T2 pi2 = {pi, pi};
+#pragma unroll
+        for (int hh = c / 2; hh < 4; ++hh) col[c][hh] *= pi2;
+        col[c][c / 2][c % 2] = lcc;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 8; ++c2) {
+          const T sv = col[c][c2 / 2][c2 % 2];
+          const T2 ns = {-sv, -sv};
+#pragma unroll
+          for (int hh = c2 / 2; hh < 4; ++hh) col[c2][hh] = __builtin_elementwise_fma(col[c][hh], ns, col[c2][hh]);
+        }
+      }
+      T2 xv[4];
+#pragma unroll
+      for (int q = 0; q < 8; q += 4) {
+        const VT v = *reinterpret_cast<const VT*>(&Cs[tid][8 * kb + q]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[(q + e) / 2][(q + e) % 2] = v[e];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const T xc = xv[c / 2][c % 2] * pinv[c];
+        const T2 nx = {-xc, -xc};
+#pragma unroll
+        for (int hh = c / 2; hh < 4; ++hh) xv[hh] = __builtin_elementwise_fma(col[c][hh], nx, xv[hh]);
+        xv[c / 2][c % 2] = xc;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q += 4) {
+        VT v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = xv[(q + e) / 2][(q + e) % 2];
+        *reinterpret_cast<VT*>(&Cs[tid][8 * kb + q]) = v;
+      }
+    }
+    __syncthreads();
+    if (kb < 7) {
+      // rank-8 update of the columns to the right: acc -= X[:, 8kb:8kb+8] X_D[cols, 8kb:8kb+8]^T
+      const VT va = *reinterpret_cast<const VT*>(&Cs[w * 32 + li][8 * kb + 4 * h]);
+#pragma unroll
+      for (int sj = 0; sj < 2; ++sj) {
+        if (32 * (sj + 1) <= 8 * (kb + 1)) continue;  // every column of this half is finished (uniform)
+        const int dr = sj * 32 + li;  // row of the diagonal block = column of the panel
+        const VT vb = *reinterpret_cast<const VT*>(&Cs[dr][8 * kb + 4 * h]);
+        const bool right = dr >= 8 * (kb + 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const T bb = right ? vb[e] : T(0);
+          if (sj == 0)
+            acc[0] = MM::mma(-va[e], bb, acc[0]);
+          else
+            acc[1] = MM::mma(-va[e], bb, acc[1]);
+        }
+      }
+    }
+  }
+  HB_STAMP(2);
+  if (s == 0 && tid == 0) {
+    const int bad = fail != 0 ? k * C64_NB + fail : 0;
+    if (k == 0)
+      *info = bad;
+    else if (bad != 0 && *info == 0)
+      *info = bad;
+  }
+  // store the stacked panel, 32 rows (one wave's tile) at a time
+  constexpr int VPR = C64_NB / 4;  // 16-byte groups per row
+#pragma unroll 1
+  for (int g = 0; g < 4; ++g) {
+    bool glive, gy;
+    int grt;
+    describe(g, glive, gy, grt);
+    if (!glive || (g < 2 && s != 0)) continue;  // the diagonal block is written by strip 0 only
+    for (int idx = tid; idx < 32 * VPR; idx += 256) {
+      const int pr = idx / VPR, c = (idx % VPR) * 4;
+      VT v = *reinterpret_cast<const VT*>(&Cs[g * 32 + pr][c]);
+      if (g < 2) {
+        const int dpr = g * 32 + pr;  // row inside the diagonal block
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e > dpr) v[e] = T(0);  // strict upper part of the diagonal block
+      }
+      *reinterpret_cast<VT*>((gy ? Y : L) + (grt * 32 + pr) * M + k * C64_NB + c) = v;
+    }
+    if (gy) {
+      // the finished panel of Y = L^-T, transposed into W = L^-1
+      for (int idx = tid; idx < 32 * C64_NB; idx += 256) {
+        const int r = idx % 32, c = idx / 32;
+        W[(k * C64_NB + c) * M + grt * 32 + r] = Cs[g * 32 + r][c];
+      }
+    }
+  }
+  HB_STAMP(3);
+}
+
 template <typename T>
 static int cholesky_launch(const T* A, T* L, T* W, T* ws, long B, long M, int* info, hipStream_t stream) {
   HB_REQUIRE(B >= 0 && M >= 0, "hb_cholesky: negative extent");
@@ -743,6 +1037,19 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, long B, long M, int* i
   const int inv = W != nullptr;
   const int nblk = hb_cdiv(M, CR_B);
   const bool fast = ((uintptr_t)L % 16 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)ws % 16 == 0) && M % CR_B == 0;
+  static const bool no64 = getenv("HB_CHOL_NO64") != nullptr;  // diagnostic A/B switch
+  if (sizeof(T) == 4 && fast && M % C64_NB == 0 && !no64) {
+    const int nrt = (int)(M / 32);
+    for (int k = 0; k < nrt / 2; ++k) {
+      dim3 grid((unsigned)chol64_grid(nrt, k, inv), (unsigned)B);
+      hipLaunchKernelGGL(chol_rl64_kernel, grid, dim3(256), 0, stream, (const float*)A, (float*)L,
+                         inv ? (float*)ws : (float*)nullptr, (float*)W, (int)M, k, info);
+      HB_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, B, M);
+    HB_LAUNCH_CHECK();
+    return 0;
+  }
   for (int k = 0; k < nblk; ++k) {
     dim3 grid((unsigned)chol_rl_grid(nblk, k, inv), (unsigned)B);
     if (fast)
