@@ -641,6 +641,71 @@ extern "C" int hb_gather_rows_f64(const double* src, long nsrc, long row, const 
   return 0;
 }
 
+// Several arrays gathered by the same index vector in ONE launch (a model's MinibatchData arrays all take the same
+// rows; one launch per array is ~4 us of kernel boundary each).  Up to HB_GATHER_MAX arrays, each with its own
+// row width; all arrays have `nsrc` rows.
+#define HB_GATHER_MAX 8
+template <typename T>
+struct GatherMultiArgs {
+  const T* src[HB_GATHER_MAX];
+  T* dst[HB_GATHER_MAX];
+  long row[HB_GATHER_MAX];
+  long start[HB_GATHER_MAX + 1];  // prefix sums of n*row[a]: element range of array a in the flattened work list
+  int narr;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) gather_rows_multi_kernel(GatherMultiArgs<T> g, const long* __restrict__ idx,
+                                                                const long* __restrict__ perm, long n, long nsrc,
+                                                                int* __restrict__ err) {
+  const long total = g.start[g.narr];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int a = 0;
+#pragma unroll
+    for (int q = 1; q < HB_GATHER_MAX; ++q)
+      if (q < g.narr && i >= g.start[q]) a = q;
+    const long li = i - g.start[a];
+    const long r = li / g.row[a], c = li - r * g.row[a];
+    long j = idx[r];
+    if (perm) j = perm[j];
+    if (j < 0 || j >= nsrc) {
+      if (err) *err = 1;
+      g.dst[a][li] = T(0);
+    } else {
+      g.dst[a][li] = g.src[a][j * g.row[a] + c];
+    }
+  }
+}
+template <typename T>
+static int gather_rows_multi(int narr, const T* const* srcs, const long* rows, T* const* dsts, long nsrc,
+                             const long* idx, const long* perm, long n, int* err, hipStream_t stream) {
+  HB_REQUIRE(narr >= 1 && narr <= HB_GATHER_MAX, "hb_gather_rows_multi: %d arrays (max %d)", narr, HB_GATHER_MAX);
+  HB_REQUIRE(n >= 0 && nsrc >= 0 && srcs && rows && dsts && idx, "hb_gather_rows_multi: bad arguments");
+  GatherMultiArgs<T> g;
+  g.narr = narr;
+  g.start[0] = 0;
+  for (int a = 0; a < HB_GATHER_MAX; ++a) {
+    g.src[a] = a < narr ? srcs[a] : nullptr;
+    g.dst[a] = a < narr ? dsts[a] : nullptr;
+    g.row[a] = a < narr ? rows[a] : 1;
+    if (a < narr) HB_REQUIRE(rows[a] >= 1 && srcs[a] && dsts[a], "hb_gather_rows_multi: bad array %d", a);
+    g.start[a + 1] = g.start[a] + (a < narr ? n * rows[a] : 0);
+  }
+  if (g.start[narr] == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_multi_kernel<T>, dim3(hb_stream_grid(g.start[narr], 256)), dim3(256), 0, stream, g, idx,
+                     perm, n, nsrc, err);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_gather_rows_multi_f32(int narr, const float* const* srcs, const long* rows, float* const* dsts,
+                                        long nsrc, const long* idx, const long* perm, long n, int* err, void* stream) {
+  return gather_rows_multi<float>(narr, srcs, rows, dsts, nsrc, idx, perm, n, err, (hipStream_t)stream);
+}
+extern "C" int hb_gather_rows_multi_f64(int narr, const double* const* srcs, const long* rows, double* const* dsts,
+                                        long nsrc, const long* idx, const long* perm, long n, int* err, void* stream) {
+  return gather_rows_multi<double>(narr, srcs, rows, dsts, nsrc, idx, perm, n, err, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------
 // small matrix utilities on batched row-major [B, R, C]
 // ---------------------------------------------------------------------------

@@ -228,6 +228,28 @@ def gather_rows(src, idx, perm=None, out=None, err=None):
     return out
 
 
+class MultiGather:
+    """out_a[i,:] = src_a[perm[idx[i]],:] for several arrays sharing idx, one launch (argument arrays built once)."""
+
+    def __init__(self, srcs, outs, idx, perm, err):
+        assert 1 <= len(srcs) <= 8 and len(srcs) == len(outs)
+        nsrc = srcs[0].shape[0]
+        for s in srcs:
+            _chk(s)
+            assert s.shape[0] == nsrc and s.dtype == srcs[0].dtype
+        self.suf = _suf(srcs[0])
+        self.narr, self.nsrc, self.n = len(srcs), nsrc, idx.numel()
+        self.srcs = (c_void_p * self.narr)(*[s.data_ptr() for s in srcs])
+        self.dsts = (c_void_p * self.narr)(*[o.data_ptr() for o in outs])
+        self.rows = _larr([s.numel() // max(nsrc, 1) for s in srcs])
+        self.idx, self.perm, self.err = idx, perm, err
+        self._keep = (srcs, outs)
+
+    def launch(self, use_perm=True):
+        _lib.lib().call("hb_gather_rows_multi" + self.suf, self.narr, self.srcs, self.rows, self.dsts, self.nsrc,
+                        _p(self.idx), _p(self.perm if use_perm else None), self.n, _p(self.err), stream())
+
+
 def matutil(x, mode, lower=-1, upper=-1, alpha=0.0, out=None):
     _chk(x)
     R, C = x.shape[-2], x.shape[-1]

@@ -240,11 +240,28 @@ class Session:
                             plan.steps.append(draw)
                     idx, perm, err = feeder["idx"], feeder["perm"], feeder["err"]
                     H = sess.H
+                    # every minibatch array takes the same rows: ONE gather launch for all of them, emitted with the
+                    # first array (the list is complete by the time the plan runs)
+                    if "arrays" not in feeder:
+                        feeder["arrays"] = []
 
-                    def gather():
-                        H.gather_rows(full, idx, None if plan.indices_raw else perm, out=out, err=err)
+                        def gather():
+                            mg = feeder.get("mg")
+                            if mg is None:
+                                srcs = [a for a, _ in feeder["arrays"]]
+                                outs = [o for _, o in feeder["arrays"]]
+                                if len(srcs) <= 8 and len({tuple(a.shape[:1]) for a in srcs}) == 1:
+                                    mg = feeder["mg"] = H.MultiGather(srcs, outs, idx, perm, err)
+                                else:
+                                    mg = feeder["mg"] = False
+                            if mg:
+                                mg.launch(use_perm=not plan.indices_raw)
+                            else:
+                                for a, o in feeder["arrays"]:
+                                    H.gather_rows(a, idx, None if plan.indices_raw else perm, out=o, err=err)
 
-                    plan.steps.append(gather)
+                        plan.steps.append(gather)
+                    feeder["arrays"].append((full, out))
                     plan.gather_err = err
                     return out
                 raise RuntimeError("unknown leaf kind " + kind)

@@ -122,6 +122,12 @@ int hb_gather_rows_f32(const float* src, long nsrc, long row, const long* idx, c
                        long n, float* dst, int* err, void* stream);
 int hb_gather_rows_f64(const double* src, long nsrc, long row, const long* idx, const long* perm,
                        long n, double* dst, int* err, void* stream);
+/* The same gather for up to 8 arrays that share the index vector (all with nsrc rows; rows[a] = row width of
+ * array a), in one launch: a model's MinibatchData arrays (reference param.py:733-739 feeds them one by one). */
+int hb_gather_rows_multi_f32(int narr, const float* const* srcs, const long* rows, float* const* dsts,
+                             long nsrc, const long* idx, const long* perm, long n, int* err, void* stream);
+int hb_gather_rows_multi_f64(int narr, const double* const* srcs, const long* rows, double* const* dsts,
+                             long nsrc, const long* idx, const long* perm, long n, int* err, void* stream);
 
 /* batched [B,R,C] matrix utilities.  mode 0 = tf.matrix_band_part(lower,upper)
  * (reference variationals.py:145); 1 = + alpha*I (kernels.py:100 jitter);

@@ -671,3 +671,29 @@ def test_ewise_program_sum_outputs(H, p, n):
     assert_close(outs[0], prod + a, TOL[p])
     assert_close(outs[1], np.array([prod.sum()]), tol)
     assert_close(outs[2], np.array([(prod + a).sum()]), tol)
+
+
+@pytest.mark.parametrize("p", ["f32", "f64"])
+def test_gather_rows_multi(H, p):
+    """Several arrays gathered by one index vector in one launch == one gather per array."""
+    dt = DT[p]
+    rng = np.random.RandomState(7)
+    N, n = 50, 33
+    srcs = [rng.randn(N, 1), rng.randn(N, 5), rng.randn(N, 2, 3)]
+    idx = rng.randint(0, 40, n)
+    perm = rng.permutation(N)[:40]
+    dsrc = [dev(s, dt) for s in srcs]
+    outs = [torch.empty((n,) + s.shape[1:], dtype=dt, device="cuda") for s in srcs]
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    di, dp = torch.as_tensor(idx).cuda(), torch.as_tensor(perm).cuda()
+    mg = H.MultiGather(dsrc, outs, di, dp, err)
+    mg.launch()
+    for d, o in zip(dsrc, outs):
+        assert np.array_equal(host(o), host(d)[perm[idx]])
+    mg.launch(use_perm=False)
+    for d, o in zip(dsrc, outs):
+        assert np.array_equal(host(o), host(d)[idx])
+    assert err.item() == 0
+    bad = torch.as_tensor(np.array([0, N + 3] + [1] * (n - 2))).cuda()
+    H.MultiGather(dsrc, outs, bad, None, err).launch(use_perm=False)
+    assert err.item() == 1 and np.all(host(outs[1])[1] == 0)
