@@ -117,10 +117,15 @@ __global__ void __launch_bounds__(256) ew_kernel(EwArgs A) {
         for (int k = 0; k < 4; ++k) off[k] += c * A.istride[k][d];
       }
     }
-    T v[4] = {T(0), T(0), T(0), T(0)};
+    // unconditional loads (an absent operand re-reads operand 0) + select: conditional loads compile to a branch
+    // and a full vmcnt wait each, i.e. one serialised memory round trip per operand
+    T v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k < A.nin) v[k] = ((const T*)A.in[k])[off[k]];
+    for (int k = 0; k < 4; ++k) {
+      const int kk = k < A.nin ? k : 0;
+      const T ld = ((const T*)A.in[kk])[off[kk]];
+      v[k] = k < A.nin ? ld : T(0);
+    }
     T o0 = T(0), o1 = T(0), o2 = T(0);
     ew_apply<T>(A.op, v[0], v[1], v[2], v[3], A.p, o0, o1, o2);
     ((T*)A.out[0])[i] = o0;
@@ -244,11 +249,21 @@ __global__ void __launch_bounds__(256) ew_prog_kernel(ProgArgs A) {
     // indexed private arrays go to scratch memory, whose set-up alone doubled the launch cost
     T(*reg_)[256] = regs;
 #define reg(r_) reg_[r_][threadIdx.x]
-    for (int k = 0; k < A.nin; ++k) {
-      long off = 0;
+    {
+      // every input load is issued before the first one is consumed (a load -> LDS-store loop pays one dependent
+      // memory round trip per input: ~3 us of the ~8 us these launches used to take)
+      T rin[HB_PROG_MAX_IN];
 #pragma unroll
-      for (int d = 0; d < HB_PROG_MAX_DIMS; ++d) off += (long)idx[d] * A.istr[k][d];
-      reg(k) = ((const T*)A.in[k])[off];
+      for (int k = 0; k < HB_PROG_MAX_IN; ++k) {
+        const int kk = k < A.nin ? k : 0;
+        long off = 0;
+#pragma unroll
+        for (int d = 0; d < HB_PROG_MAX_DIMS; ++d) off += (long)idx[d] * A.istr[kk][d];
+        rin[k] = ((const T*)A.in[kk])[off];
+      }
+#pragma unroll
+      for (int k = 0; k < HB_PROG_MAX_IN; ++k)
+        if (k < A.nin) reg(k) = rin[k];
     }
     for (int q = 0; q < A.ninstr; ++q) {
       const int op = A.code[q][0], dst = A.code[q][1];

@@ -95,6 +95,7 @@ gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const
     T gacc[HB_GRAM_MAXD], lacc[HB_GRAM_MAXD];
 #pragma unroll
     for (int k = 0; k < HB_GRAM_MAXD; ++k) gacc[k] = lacc[k] = T(0);
+#pragma unroll 4
     for (long o = threadIdx.x; o < nother; o += blockDim.x) {
       const long i = side != 1 ? row : o;
       const long j = side != 1 ? o : row;
@@ -153,8 +154,10 @@ __global__ void __launch_bounds__(256) gram_ell_finish_kernel(const T* __restric
   ellbar += (long)blockIdx.y * dl;
   T acc = T(0);
   if (dl == 1) {
+#pragma unroll 4
     for (long t = threadIdx.x; t < rows * d; t += blockDim.x) acc += partial[t];
   } else {
+#pragma unroll 4
     for (long r = threadIdx.x; r < rows; r += blockDim.x) acc += partial[r * d + c];
   }
   acc = block_sum(acc, smem);

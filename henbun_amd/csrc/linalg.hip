@@ -146,12 +146,23 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
       continue;
     }
     if ((a.flags & HB_MM_LOWER_OUT) && (c / a.tile) * a.tile > (r / a.tile) * a.tile + a.tile - 1) continue;
-    T acc = T(0);
-    for (int s = 0; s < a.S; ++s) acc += a.ws[(long)s * total + t];
+    // slab sums, four independent loads in flight per step (a plain `acc += ws[s]` loop with a run-time trip count
+    // is one dependent round trip per slab); the order of the additions is fixed, so the result is deterministic
+    auto slab_sum = [&](long at) -> T {
+      T acc0 = T(0), acc1 = T(0), acc2 = T(0), acc3 = T(0);
+      int s = 0;
+      for (; s + 4 <= a.S; s += 4) {
+        const T v0 = a.ws[(long)s * total + at], v1 = a.ws[(long)(s + 1) * total + at];
+        const T v2 = a.ws[(long)(s + 2) * total + at], v3 = a.ws[(long)(s + 3) * total + at];
+        acc0 += v0, acc1 += v1, acc2 += v2, acc3 += v3;
+      }
+      for (; s < a.S; ++s) acc0 += a.ws[(long)s * total + at];
+      return (acc0 + acc1) + (acc2 + acc3);
+    };
+    T acc = slab_sum(t);
     if (a.flags & HB_MM_SYM_OUT) {
       const long tt = b * a.M * a.N + c * a.N + r;  // the mirrored element
-      T acc2 = T(0);
-      for (int s = 0; s < a.S; ++s) acc2 += a.ws[(long)s * total + tt];
+      const T acc2 = slab_sum(tt);
       cp[0] = T(0.5) * (acc + acc2);
       continue;
     }

@@ -346,10 +346,35 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
       sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
       xs[dd] = x[cc * D + dd] * sc[dd];
     }
-    for (int i = tid; i < M * D; i += 256) zs[i] = z[i] * sc[i % D];
-    if (a.part)
-      for (int p = 0; p < (int)a.P && p < 4; ++p)
-        for (int i = tid; i < M; i += 256) us[p][i] = a.u[e * a.P * a.M + (long)p * M + i];
+    // all staging loads are issued before any is consumed (a load -> LDS store loop would pay one dependent
+    // round trip per iteration: five of them, ~5 us, in the first version of this prologue)
+    constexpr int ZIT = (SGP_SM_MAX * D) / 256, UIT = SGP_SM_MAX / 256;
+    float zt[ZIT], ut[4][UIT];
+    const int npu = a.part ? ((int)a.P < 4 ? (int)a.P : 4) : 0;
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + 256 * it;
+      zt[it] = z[i < M * D ? i : 0];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int it = 0; it < UIT; ++it) {
+        const int i = tid + 256 * it;
+        ut[p][it] = p < npu ? a.u[e * a.P * a.M + (long)p * M + (i < M ? i : 0)] : 0.f;
+      }
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + 256 * it;
+      if (i < M * D) zs[i] = zt[it] * sc[i % D];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int it = 0; it < UIT; ++it) {
+        const int i = tid + 256 * it;
+        if (p < npu && i < M) us[p][i] = ut[p][it];
+      }
     __syncthreads();
 #pragma unroll 4
     for (int k4 = kq * 4; k4 < M; k4 += 32) {
@@ -1107,8 +1132,10 @@ __global__ void __launch_bounds__(256) sgp_ell_finish_kernel(const T* __restrict
   part += e * M * d;
   T acc = T(0);
   if (dl == 1) {
+#pragma unroll 4
     for (long t = threadIdx.x; t < M * d; t += blockDim.x) acc += part[t];
   } else {
+#pragma unroll 4
     for (long m = threadIdx.x; m < M; m += blockDim.x) acc += part[m * d + c];
   }
   acc = block_sum(acc, smem);
