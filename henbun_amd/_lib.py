@@ -34,13 +34,16 @@ _SIGS = {
     "hb_rng_init": [P, L, U64, U64, P],
     "hb_rng_randint": [P, L, P, L, L, L, P],
     "hb_sgp_ws_elems": [L, L, L, L, L],
+    "hb_ewise_prog_image_bytes": [],
+    "hb_ewise_prog_build": [I, P, P, I, P, P, I, P, P, P, I, P, P, P, P],
 }
-_RESTYPES = {"hb_last_error_string": c_char_p, "hb_sgp_ws_elems": c_long}
+_RESTYPES = {"hb_last_error_string": c_char_p, "hb_sgp_ws_elems": c_long, "hb_ewise_prog_image_bytes": c_long}
 
 # entry points that exist as _f32 and _f64
 _TYPED = {
     "hb_ewise": [I, I, P, P, I, P, I, P, P, P],
     "hb_ewise_prog": [I, P, P, I, P, P, I, P, P, P, I, P, P],
+    "hb_ewise_prog_run": [P, L, I, P],
     "hb_reduce": [I, P, P, L, L, L, P, L, P],
     "hb_copy_nd": [P, P, P, P, I, P, P],
     "hb_fill": [P, L, D, P],

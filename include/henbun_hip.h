@@ -97,6 +97,18 @@ int hb_ewise_prog_f32(int ninstr, const int* code, const double* params, int nin
 int hb_ewise_prog_f64(int ninstr, const int* code, const double* params, int nin, const void* const* in,
                       const long* istrides, int nout, void* const* out, const int* out_regs,
                       const long* ostrides, int ndim, const long* shape, void* stream);
+/* Device-resident form for programs that are replayed (a captured plan): hb_ewise_prog_build validates the
+ * same arguments and writes the launch descriptor (hb_ewise_prog_image_bytes() bytes, independent of the element
+ * type) to HOST memory; the caller copies it to the device once (4-byte aligned) and every launch is
+ * hb_ewise_prog_run_* with that pointer and the `n` / `reduces` build returned.  The kernel pulls the descriptor
+ * into LDS with one parallel load; the by-value form above walks it with dependent scalar loads (~4 us slower). */
+long hb_ewise_prog_image_bytes(void);
+int hb_ewise_prog_build(int ninstr, const int* code, const double* params, int nin, const void* const* in,
+                        const long* istrides, int nout, void* const* out, const int* out_regs,
+                        const long* ostrides, int ndim, const long* shape, void* image_host, long* n_out,
+                        int* reduces_out);
+int hb_ewise_prog_run_f32(const void* image_dev, long n, int reduces, void* stream);
+int hb_ewise_prog_run_f64(const void* image_dev, long n, int reduces, void* stream);
 
 enum { HB_RED_SUM = 0, HB_RED_MAX = 1 };
 /* out[K1,K2] = reduce over R of contiguous in[K1,R,K2]  (tf.reduce_sum / reduce_max) */
