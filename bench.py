@@ -201,13 +201,14 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
             pmc = json.load(fh)["kernels"]
-        want = "sgp_A_kernel<%s, 1, true>" % ("float" if args.dtype == "float32" else "double")
+        # fp32 runs the column-strip form of the kernel, fp64 the tiled form
+        want = ["sgp_A_strip_kernel<1>"] if args.dtype == "float32" else ["sgp_A_kernel<double, 1, true>"]
         for name, rec in pmc.items():
-            if want in name:
+            if any(w in name for w in want):
                 traffic, traffic_src = rec["traffic_bytes"], "profiles/r01_pmc_traffic.json"
     except (OSError, KeyError, ValueError):
         pass
-    roofline = {"kernel": "sgp_A_kernel<%s,1> (A = L^-1 K(z,x), %dx%d by %d)" % ("float" if args.dtype == "float32" else "double", Mi, Mi, n),
+    roofline = {"kernel": "%s (A = L^-1 K(z,x), %dx%d by %d)" % ("sgp_A_strip_kernel<1>" if args.dtype == "float32" else "sgp_A_kernel<double,1,true>", Mi, Mi, n),
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_us": kern_us,
                 "flops_per_launch": flops,
