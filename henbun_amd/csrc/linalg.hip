@@ -219,8 +219,10 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   const long tiles = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
   const long active = active_tiles(BT);
   if (BT == 64 && ws && active * batch < 320 && K >= 128) {
-    // shallow or small: latency matters -- ~2.5 workgroups per CU, each slice >= 64 deep
-    long s0 = 640 / (active * batch);
+    // few tiles: split the contraction, each slice >= 64 deep.  Deep problems (K >= 2048) want ~2.5 workgroups per
+    // CU; shallow ones are dominated by the slab traffic (S slabs written, then read by the finish kernel), so they
+    // stop at ~1.25 workgroups per CU
+    long s0 = (K >= 2048 ? 640 : 320) / (active * batch);
     const long s1 = K / 64;
     const long s3 = ws_elems / (batch * M * N);
     if (s0 > s1) s0 = s1;

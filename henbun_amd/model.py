@@ -298,6 +298,65 @@ class Optimizer:
         plan.check()
         self.last_plan = plan
 
+    # ------------------------------------------------------------------ exact resume
+    def save_state(self, path):
+        """Everything a bit-exact resume of `optimize` needs, in one .npz: the raw parameters, the Adam slots and
+        step count, the three device RNG streams of this rank and the Indexer's train/test split.  (The reference's
+        `save` keeps the parameters only, param.py:562-603; with data parallelism every rank saves its own file --
+        the parameters and the `global` stream are identical across ranks, `local` / `index` are not.)"""
+        self._ensure_compiled()
+        self.model.initialize()
+        sess = self.model._session
+        sess.torch.cuda.synchronize()
+        slots = self._optimizer.slots(sess)
+        out = {
+            "theta": sess.theta.cpu().numpy(),
+            "adam_m": slots["m"].cpu().numpy(), "adam_v": slots["v"].cpu().numpy(), "adam_t": slots["t"].cpu().numpy(),
+            "layout": np.array(sorted((v.long_name, o, s) for v in self.model.get_variables()
+                                      for o, s in [sess._offsets.get(id(v), (-1, -1))] if o >= 0), dtype=object),
+        }
+        for k, r in sess.rngs.items():
+            out["rng_" + k] = r.state.cpu().numpy()
+        idx = self.model._index
+        if idx.data_size is not None:
+            out["index_train"], out["index_test"] = np.asarray(idx._train_index), np.asarray(idx._test_index)
+        p = path if path.endswith(".npz") else path + ".npz"
+        np.savez(p, **out)
+        return p
+
+    def restore_state(self, path):
+        """Inverse of save_state.  All device buffers are overwritten IN PLACE, so plans captured before the call
+        keep replaying on the restored state."""
+        self._ensure_compiled()
+        self.model.initialize()
+        sess = self.model._session
+        torch = sess.torch
+        p = path if path.endswith(".npz") else path + ".npz"
+        with np.load(p, allow_pickle=True) as f:
+            layout = sorted((v.long_name, o, s) for v in self.model.get_variables()
+                            for o, s in [sess._offsets.get(id(v), (-1, -1))] if o >= 0)
+            saved = [tuple(r) for r in f["layout"].tolist()]
+            if [(a, int(b), int(c)) for a, b, c in saved] != layout:
+                raise ValueError("checkpoint %s was written for a different parameter layout" % p)
+            slots = self._optimizer.slots(sess)
+            torch.cuda.synchronize()
+            sess.theta.copy_(torch.as_tensor(f["theta"]).to(sess.theta.dtype))
+            slots["m"].copy_(torch.as_tensor(f["adam_m"]).to(slots["m"].dtype))
+            slots["v"].copy_(torch.as_tensor(f["adam_v"]).to(slots["v"].dtype))
+            slots["t"].copy_(torch.as_tensor(f["adam_t"]))
+            for k, r in sess.rngs.items():
+                r.state.copy_(torch.as_tensor(f["rng_" + k]))
+            if "index_train" in f.files:
+                idx = self.model._index
+                idx._train_index, idx._test_index = f["index_train"], f["index_test"]
+                idx.data_size = len(idx._train_index) + len(idx._test_index)
+                idx.train_size, idx.test_size = len(idx._train_index), len(idx._test_index)
+                for key, arr in (("train", idx._train_index), ("test", idx._test_index)):
+                    dev = idx._dev.get(key)
+                    if dev is not None:
+                        dev.copy_(torch.as_tensor(np.ascontiguousarray(arr, dtype=np.int64)))
+            torch.cuda.synchronize()
+
     def gradients(self, minibatch_size=None, indices=None):
         """{long_name: d objective / d raw parameter} at the current parameters
         (not in the reference; used by the parity tests).  Runs forward+backward

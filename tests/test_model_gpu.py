@@ -280,3 +280,31 @@ def test_rng_noise_statistics_and_minibatch_indices():
     plan = opt.last_plan
     idx = plan.index_buffer.cpu().numpy()
     assert idx.min() >= 0 and idx.max() < 1800
+
+
+def test_exact_resume_save_state(tmp_path):
+    """save_state / restore_state: parameters + Adam slots + RNG streams + index split give a
+    bit-identical continuation, in graph-replay mode, without rebuilding any plan."""
+    from models import SVGP, svgp_data
+
+    np.random.seed(11)
+    X, Y, Z = svgp_data(3000, 32, 0, domain=16.0)
+    m = SVGP(X=X, Y=Y, Z=Z, dtype="float32")
+    opt = m.ELBO()
+    opt.compile(optimizer=tf.train.AdamOptimizer(1e-2))
+    opt.optimize(maxiter=7, minibatch_size=256)
+    opt.run(minibatch_size=256)  # build the evaluation plan now: building a plan draws from the RNG streams once
+    path = opt.save_state(str(tmp_path / "ck"))
+    opt.optimize(maxiter=9, minibatch_size=256)
+    theta_a = m._session.theta.clone()
+    e_a = opt.run(minibatch_size=256)
+    opt.restore_state(path)
+    opt.optimize(maxiter=9, minibatch_size=256)
+    assert torch.equal(m._session.theta, theta_a)
+    assert opt.run(minibatch_size=256) == e_a
+    # a different layout is refused
+    m2 = SVGP(X=X, Y=Y, Z=Z[:16], dtype="float32")
+    o2 = m2.ELBO()
+    o2.compile()
+    with pytest.raises(ValueError):
+        o2.restore_state(path)
