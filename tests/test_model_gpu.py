@@ -65,7 +65,8 @@ NAMES = [("model.gp.z", "z"), ("model.gp.kern.lengthscales", "ell_raw"), ("model
 @pytest.mark.parametrize("q_shape,N,M,n", [("diagonal", 1000, 64, 1000),    # BASELINE cfg 1 sizes
                                            ("diagonal", 3000, 200, 700),
                                            ("fullrank", 2000, 96, 512),
-                                           ("diagonal", 5000, 512, 2048)])   # cfg-2 inducing count
+                                           ("diagonal", 5000, 512, 2048),    # cfg-2 inducing count
+                                           ("diagonal", 20000, 512, 8192)])  # cfg-2 inducing count AND minibatch
 def test_svgp_fp64_elbo_and_gradient_parity(q_shape, N, M, n):
     cfg = hb.settings.get_settings()
     cfg.numerics.jitter_level = 1e-5
@@ -308,3 +309,49 @@ def test_exact_resume_save_state(tmp_path):
     o2.compile()
     with pytest.raises(ValueError):
         o2.restore_state(path)
+
+
+def test_cfg2_full_size_properties_fp32():
+    """BASELINE cfg 2 at full per-step size (M = 512, n = 8192, fp32 -- the benchmark dtype), through properties that
+    do not need a reference run: bit-determinism of the whole forward+backward, closeness to the fp64 oracle, and the
+    defining identities of the fused factor/inverse/contraction kernels (L L^T = K + jitter I, W L = I, L A = K(z,x),
+    v = 1 - colsum(A^2))."""
+    cfg = hb.settings.get_settings()
+    cfg.numerics.jitter_level = 1e-4
+    with hb.settings.temp_settings(cfg):
+        m, data = make_svgp(20000, 512, 8192, "diagonal", "float32")
+        opt = m.ELBO()
+        opt.compile()
+        v1, g1 = opt.gradients(minibatch_size=8192, indices=data[5])
+        v2, g2 = opt.gradients(minibatch_size=8192, indices=data[5])
+        assert v1 == v2 and all(np.array_equal(g1[k], g2[k]) for k in g1), "same inputs must give the same bits"
+        fn, params = oracle_svgp(m, data, 1e-4, "diagonal")
+        ref_val, ref = O.grads_of(fn, params)
+    assert abs(v1 - ref_val.item()) <= 2e-3 * abs(ref_val.item()), (v1, ref_val.item())
+    for mine, theirs in NAMES:
+        assert rel_err(g1[mine], ref[theirs].numpy()) <= 5e-2, mine
+    # kernel identities at the same size
+    H = m._session.H
+    rng = np.random.RandomState(0)
+    M, n = 512, 8192
+    z = torch.as_tensor(np.linspace(0, 256, M)[:, None], dtype=torch.float32).cuda()
+    x = torch.as_tensor(rng.uniform(0, 256, (n, 1)), dtype=torch.float32).cuda()
+    ell = torch.ones(1, dtype=torch.float32, device="cuda")
+    K = H.gram_fwd(z, z, ell, diag_add=1e-3)
+    L, W, info = H.cholesky_inverse(K)
+    assert info.item() == 0
+    Ld, Wd, Kd = L.double().cpu().numpy(), W.double().cpu().numpy(), K.double().cpu().numpy()
+    assert np.abs(Ld @ Ld.T - Kd).max() < 5e-5
+    assert np.abs(Wd @ Ld - np.eye(M)).max() < 5e-3
+    A = H.sgp_A(x, z, ell, W)
+    Kzx = H.gram_fwd(z, x, ell).double().cpu().numpy()
+    Ad = A.double().cpu().numpy()
+    assert np.abs(Ld @ Ad - Kzx).max() < 2e-3
+    u = torch.as_tensor(rng.randn(1, M), dtype=torch.float32).cuda()
+    eps = torch.as_tensor(rng.randn(n), dtype=torch.float32).cuda()
+    f, A2, v, _ = H.sgp_fwd(x, z, ell, W, u, eps_in=eps)
+    assert torch.equal(A2, A)
+    vd = 1.0 - (Ad ** 2).sum(0)
+    assert np.abs(v.double().cpu().numpy() - vd).max() < 1e-4
+    fd = u.double().cpu().numpy() @ Ad + np.sqrt(np.abs(vd)) * eps.double().cpu().numpy()
+    assert np.abs(f.double().cpu().numpy() - fd).max() < 2e-3
