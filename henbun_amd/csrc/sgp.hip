@@ -477,30 +477,18 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
     for (; Q < q1; ++Q) step(Q, pc, std::true_type());
     return q1 > q0 ? q1 : q0;
   };
-  if (dep[3] > 0) {
-    load_a(0, std::integral_constant<int, 0>());
-    int Q = 0;
-    Q = phase(Q, std::integral_constant<int, 0>());
-    HB_SSTAMP(2);
-    Q = phase(Q, std::integral_constant<int, 1>());
-    HB_SSTAMP(3);
-    Q = phase(Q, std::integral_constant<int, 2>());
-    HB_SSTAMP(4);
-    Q = phase(Q, std::integral_constant<int, 3>());
-  }
-  HB_SSTAMP(5);
-
-  // ---- epilogue: A rows, column statistics
+  // A tile is stored (and folded into the column statistics) the moment its phase ends: the stores of three of the
+  // four tiles then drain under the MFMAs of the later phases instead of forming a serial epilogue.
   const int npart = a.part ? (int)a.P : 0;
   float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   const int gc = col0 + li;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (!tv[j]) continue;
+  auto retire = [&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    if (!tv[P]) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = 32 * tile[j] + MM::acc_row(lane, r);
-      const float v = acc[j][r];
+      const int row = 32 * tile[P] + MM::acc_row(lane, r);
+      const float v = acc[P][r];
       if (gc < n) A[(long)row * n + gc] = v;
       if (a.part) {
         cs[0] += v * v;
@@ -509,7 +497,25 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
           if (p < npart) cs[1 + p] += us[p][row] * v;
       }
     }
+  };
+  if (dep[3] > 0) {
+    load_a(0, std::integral_constant<int, 0>());
+    int Q = 0;
+    Q = phase(Q, std::integral_constant<int, 0>());
+    retire(std::integral_constant<int, 0>());
+    HB_SSTAMP(2);
+    Q = phase(Q, std::integral_constant<int, 1>());
+    retire(std::integral_constant<int, 1>());
+    HB_SSTAMP(3);
+    Q = phase(Q, std::integral_constant<int, 2>());
+    retire(std::integral_constant<int, 2>());
+    HB_SSTAMP(4);
+    Q = phase(Q, std::integral_constant<int, 3>());
+    retire(std::integral_constant<int, 3>());
   }
+  HB_SSTAMP(5);
+
+  // ---- epilogue: column statistics across lanes and waves
   if (a.part) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) cs[q] += __shfl_xor(cs[q], 32);
