@@ -50,10 +50,14 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
   const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
   const int lda = (int)a.lda, ldb = (int)a.ldb;
   const int tiles_n = (N + BT - 1) / BT;
-  const int row0 = (blockIdx.x / tiles_n) * BT;
-  const int col0 = (blockIdx.x % tiles_n) * BT;
+  // blockIdx.x = tile * S + slab, slab fastest: workgroups are dealt to the 8 XCDs round-robin, so with S a
+  // multiple of 8 every XCD works on its own contraction slabs (all tiles of them) and an operand slab is fetched
+  // into ONE L2 instead of all eight (the Lbar contraction moved 106 MB for 33 MB of operands before this)
+  const int tile = blockIdx.x / a.S;
+  const int s = blockIdx.x - tile * a.S;
+  const int row0 = (tile / tiles_n) * BT;
+  const int col0 = (tile % tiles_n) * BT;
   const long b = blockIdx.y;
-  const int s = blockIdx.z;
   if ((a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && col0 > row0 + BT - 1) {
     if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && !a.to_ws) {
       // a tile wholly above the diagonal: all zero (with split-K the finish kernel writes them)
@@ -219,10 +223,10 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   const long tiles = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
   const long active = active_tiles(BT);
   if (BT == 64 && ws && active * batch < 320 && K >= 128) {
-    // few tiles: split the contraction, each slice >= 64 deep.  Deep problems (K >= 2048) want ~2.5 workgroups per
+    // few tiles: split the contraction, each slice >= 64 deep.  Deep problems (K >= 2048) want ~3.5 workgroups per
     // CU; shallow ones are dominated by the slab traffic (S slabs written, then read by the finish kernel), so they
     // stop at ~1.25 workgroups per CU
-    long s0 = (K >= 2048 ? 640 : 320) / (active * batch);
+    long s0 = (K >= 2048 ? 896 : 320) / (active * batch);
     const long s1 = K / 64;
     const long s3 = ws_elems / (batch * M * N);
     if (s0 > s1) s0 = s1;
@@ -246,10 +250,12 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
       S = s < 1 ? 1 : (int)s;
     }
   }
+  if (S > 8) S -= S % 8;  // slab <-> XCD affinity (see matmul_kernel)
   a.S = S;
   a.to_ws = (S > 1 || (flags & HB_MM_SYM_OUT)) ? 1 : 0;
   const long tiles_final = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
-  dim3 grid((unsigned)tiles_final, (unsigned)batch, (unsigned)S);
+  HB_REQUIRE(tiles_final * S < 2147483647L, "hb_matmul: grid too large");
+  dim3 grid((unsigned)(tiles_final * S), (unsigned)batch, 1);
   constexpr long VEC = 16 / sizeof(T);
   const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % VEC == 0 && ldb % VEC == 0 &&
                        sA % VEC == 0 && sB % VEC == 0;
