@@ -44,6 +44,7 @@ _TYPED = {
     "hb_ewise": [I, I, P, P, I, P, I, P, P, P],
     "hb_ewise_prog": [I, P, P, I, P, P, I, P, P, P, I, P, P],
     "hb_ewise_prog_run": [P, L, I, P],
+    "hb_gauss_ll": [P, P, P, P, L, P, P, P, P, P, L, P],
     "hb_reduce": [I, P, P, L, L, L, P, L, P],
     "hb_copy_nd": [P, P, P, P, I, P, P],
     "hb_fill": [P, L, D, P],

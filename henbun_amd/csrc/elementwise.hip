@@ -788,6 +788,93 @@ extern "C" int hb_gather_rows_multi_f64(int narr, const double* const* srcs, con
 }
 
 // ---------------------------------------------------------------------------
+// Fused Gaussian log-likelihood head:  ll = sum_j log N(x_j | mu_j, var),  mu_j = f_j * scale   (scale, var scalars)
+// together with everything its backward pass needs, in the same pass over the data:
+//   dmu_j  = d ll / d mu_j = (x_j - mu_j) / var            [n]
+//   dscale = d ll / d scale = sum_j dmu_j f_j               [1]
+//   dvar   = d ll / d var  = sum_j (-1/(2 var) + (x_j - mu_j)^2 / (2 var^2))   [1]
+// (reference densities.py:25-27 + tf.reduce_sum + TF autodiff: a chain of eight launches when lowered op by op --
+// two elementwise programs, three reductions, the 3-output gradient op and their glue).  Two launches here: per-block
+// partial sums, then one block folds the three sums (deterministic order).
+// ---------------------------------------------------------------------------
+#define HB_GLL_BLOCK_ELEMS 1024
+template <typename T>
+__global__ void __launch_bounds__(256) gauss_ll_kernel(const T* __restrict__ x, const T* __restrict__ f,
+                                                       const T* __restrict__ scale, const T* __restrict__ var,
+                                                       long n, T* __restrict__ dmu, T* __restrict__ partial) {
+  __shared__ T smem[16];
+  const T s = scale ? scale[0] : T(1), v = var[0];
+  const T iv = T(1) / v, lc = T(-0.91893853320467274178) - T(0.5) * hb_log(v);
+  T all = T(0), asc = T(0), avr = T(0);
+  const long base = (long)blockIdx.x * HB_GLL_BLOCK_ELEMS;
+#pragma unroll
+  for (int q = 0; q < HB_GLL_BLOCK_ELEMS / 256; ++q) {
+    const long j = base + q * 256 + threadIdx.x;
+    const long jc = j < n ? j : n - 1;
+    const T xv = x[jc], fv = f[jc];
+    const T dlt = xv - fv * s;
+    const T g = dlt * iv;
+    if (j < n) {
+      dmu[j] = g;
+      all += lc - T(0.5) * dlt * g;
+      asc += g * fv;
+      avr += T(-0.5) * iv + T(0.5) * g * g;
+    }
+  }
+  all = block_sum(all, smem);
+  asc = block_sum(asc, smem);
+  avr = block_sum(avr, smem);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = all;
+    partial[gridDim.x + blockIdx.x] = asc;
+    partial[2 * gridDim.x + blockIdx.x] = avr;
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) gauss_ll_finish_kernel(const T* __restrict__ partial, int nb, T* __restrict__ ll,
+                                                              T* __restrict__ dscale, T* __restrict__ dvar) {
+  __shared__ T smem[16];
+  T a0 = T(0), a1 = T(0), a2 = T(0);
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    a0 += partial[i];
+    a1 += partial[nb + i];
+    a2 += partial[2 * nb + i];
+  }
+  a0 = block_sum(a0, smem);
+  a1 = block_sum(a1, smem);
+  a2 = block_sum(a2, smem);
+  if (threadIdx.x == 0) {
+    ll[0] = a0;
+    dscale[0] = a1;
+    dvar[0] = a2;
+  }
+}
+template <typename T>
+static int gauss_ll(const T* x, const T* f, const T* scale, const T* var, long n, T* ll, T* dmu, T* dscale, T* dvar,
+                    T* ws, long ws_elems, hipStream_t stream) {
+  HB_REQUIRE(n >= 0 && x && f && var && ll && dmu && dscale && dvar && ws, "hb_gauss_ll: bad arguments");
+  const int nb = n > 0 ? hb_cdiv(n, HB_GLL_BLOCK_ELEMS) : 0;
+  HB_REQUIRE(ws_elems >= 3L * (nb > 0 ? nb : 1), "hb_gauss_ll: workspace of 3*ceil(n/%d) elements required",
+             HB_GLL_BLOCK_ELEMS);
+  if (nb > 0) {
+    hipLaunchKernelGGL(gauss_ll_kernel<T>, dim3(nb), dim3(256), 0, stream, x, f, scale, var, n, dmu, ws);
+    HB_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(gauss_ll_finish_kernel<T>, dim3(1), dim3(256), 0, stream, ws, nb, ll, dscale, dvar);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_gauss_ll_f32(const float* x, const float* f, const float* scale, const float* var, long n, float* ll,
+                               float* dmu, float* dscale, float* dvar, float* ws, long ws_elems, void* stream) {
+  return gauss_ll<float>(x, f, scale, var, n, ll, dmu, dscale, dvar, ws, ws_elems, (hipStream_t)stream);
+}
+extern "C" int hb_gauss_ll_f64(const double* x, const double* f, const double* scale, const double* var, long n,
+                               double* ll, double* dmu, double* dscale, double* dvar, double* ws, long ws_elems,
+                               void* stream) {
+  return gauss_ll<double>(x, f, scale, var, n, ll, dmu, dscale, dvar, ws, ws_elems, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
 // small matrix utilities on batched row-major [B, R, C]
 // ---------------------------------------------------------------------------
 // mode 0: band part   out = in where (lower<0 || i-j<=lower) && (upper<0 || j-i<=upper) else 0

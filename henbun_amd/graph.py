@@ -391,6 +391,10 @@ def _reduce(kind, x, axes=None, keepdims=False) -> Tensor:
     axes = _norm_axes(axes, nd)
     if not axes:
         return x
+    if kind == "sum" and len(axes) == nd and x.size > 1:
+        ll = _try_gauss_ll(x)
+        if ll is not None:  # tf.reduce_sum(densities.gaussian(y, f * s, var)): one fused op (value + gradient pieces)
+            return reshape(ll, [1] * nd if keepdims else [])
     # chain contiguous runs of reduced axes (each run is one [K1,R,K2] launch)
     runs, cur = [], [axes[0]]
     for a in axes[1:]:
@@ -411,6 +415,59 @@ def _reduce(kind, x, axes=None, keepdims=False) -> Tensor:
     if not keepdims:
         t = reshape(t, [s for i, s in enumerate(x.shape) if i not in axes])
     return t
+
+
+# ------------------------------------------------------------------------------
+# fused Gaussian log-likelihood head
+def _try_gauss_ll(x):
+    """x = GAUSS_LOGPDF(y, mu, var) about to be summed over everything, var a single element and y, mu of full size
+    (mu optionally f * scale with a single-element scale): return ll[1] of the fused op, else None."""
+    n = x.node
+    if n.op != "ew" or n.attrs["f"] != "GAUSS_LOGPDF":
+        return None
+    y, mu, var = n.inputs
+    if var.size != 1 or y.size != x.size or mu.size != x.size or _squeeze_shape(y.shape) != _squeeze_shape(mu.shape):
+        return None
+    f, scale = mu, None
+    mn = mu.node
+    if mn.op == "ew" and mn.attrs["f"] == "MUL":
+        a, b = mn.inputs
+        if b.size == 1 and a.size == mu.size:
+            f, scale = a, b
+        elif a.size == 1 and b.size == mu.size:
+            f, scale = b, a
+    ins = (y, f, var) + ((scale,) if scale is not None else ())
+    return make("gauss_ll", ins, {}, [(1,), tuple(f.shape), (1,), (1,)]).outputs[0]
+
+
+def _gauss_ll_emit(plan, node):
+    H = plan.H
+    y, f, var = (plan.buf(t) for t in node.inputs[:3])
+    scale = plan.buf(node.inputs[3]) if len(node.inputs) > 3 else None
+    outs = tuple(plan.out(t) for t in node.outputs)
+    plan.steps.append(lambda: H.gauss_ll(y, f, scale, var, out=outs))
+
+
+def _gauss_ll_vjp(node, gs):
+    g = gs[0]
+    if any(x is not None for x in gs[1:]):
+        raise NotImplementedError("gradients through the saved derivative outputs of gauss_ll")
+    if g is None:
+        return [None] * len(node.inputs)
+    y, f, var = node.inputs[:3]
+    scale = node.inputs[3] if len(node.inputs) > 3 else None
+    ll, dmu, dsc, dvr = node.outputs
+    g1 = reshape(g, [1])
+    gmu = mul(g1, dmu)  # d/d mu, shape of f
+    res = [reshape(unary("NEG", gmu), y.shape),
+           reshape(mul(reshape(scale, [1]), gmu) if scale is not None else gmu, f.shape),
+           reshape(mul(g1, dvr), var.shape)]
+    if scale is not None:
+        res.append(reshape(mul(g1, dsc), scale.shape))
+    return res
+
+
+defop("gauss_ll", _gauss_ll_emit, _gauss_ll_vjp)
 
 
 def reduce_sum(x, axis=None, keepdims=False, keep_dims=None) -> Tensor:

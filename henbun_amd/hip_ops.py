@@ -199,6 +199,24 @@ class EwiseProgram:
         _lib.lib().call("hb_ewise_prog_run" + self.suf, _p(self.image), self.n, self.reduces, stream())
 
 
+def gauss_ll(x, f, scale, var, out=None):
+    """(ll[1], dmu[like x], dscale[1], dvar[1]) of sum_j log N(x_j | f_j*scale, var)  (hb_gauss_ll; scale may be None)."""
+    _chk(x), _chk(f), _chk(var)
+    assert x.numel() == f.numel() and var.numel() == 1 and (scale is None or scale.numel() == 1)
+    n = x.numel()
+    if out is None:
+        ll = _empty(1, dtype=x.dtype, device=x.device)
+        dmu = _empty_like(x)
+        ds = _empty(1, dtype=x.dtype, device=x.device)
+        dv = _empty(1, dtype=x.dtype, device=x.device)
+    else:
+        ll, dmu, ds, dv = out
+    ws = workspace(x.dtype, x.device, 3 * max((n + 1023) // 1024, 1))
+    _lib.lib().call("hb_gauss_ll" + _suf(x), _p(x), _p(f), _p(scale), _p(var), n, _p(ll), _p(dmu), _p(ds), _p(dv), _p(ws),
+                    ws.numel(), stream())
+    return ll, dmu, ds, dv
+
+
 def reduce_mid(x, K1, R, K2, op=RED_SUM, out=None):
     """out[K1,K2] = reduce_R x[K1,R,K2] (x contiguous, any shape with K1*R*K2 elements)."""
     _chk(x)

@@ -81,6 +81,18 @@ int hb_ewise_f32(int op, int nin, const void* const* in, const long* istrides, i
 int hb_ewise_f64(int op, int nin, const void* const* in, const long* istrides, int nout,
                  void* const* out, int ndim, const long* shape, const double* params, void* stream);
 
+/* Fused Gaussian log-likelihood head (reference densities.py:25-27 under tf.reduce_sum, plus its TF gradients):
+ *   ll = sum_j log N(x_j | f_j*scale, var)            -> ll[1]
+ *   dmu_j = (x_j - f_j*scale)/var                      -> dmu[n]   (d ll / d mu_j)
+ *   dscale = sum_j dmu_j f_j, dvar = sum_j (-1/(2var) + (x_j-mu_j)^2/(2var^2))   -> dscale[1], dvar[1]
+ * x, f: n contiguous elements; scale (nullable = 1) and var: one element each, device.
+ * ws >= 3*ceil(n/1024) elements.  Two launches; sums in a fixed order. */
+int hb_gauss_ll_f32(const float* x, const float* f, const float* scale, const float* var, long n, float* ll,
+                    float* dmu, float* dscale, float* dvar, float* ws, long ws_elems, void* stream);
+int hb_gauss_ll_f64(const double* x, const double* f, const double* scale, const double* var, long n,
+                    double* ll, double* dmu, double* dscale, double* dvar, double* ws, long ws_elems,
+                    void* stream);
+
 /* A whole cluster of elementwise ops in one launch: a register program interpreted per element
  * of the broadcast iteration space `shape[ndim]` (ndim <= 4).  Registers 0..nin-1 hold the inputs
  * (read with `istrides`); instruction q = code[q] = {op, dst, a, b, c} (HB_EW_* op on registers a,b,c;

@@ -84,6 +84,16 @@ def evaluate(outputs, leaf_values, noise=None):
             outs = [r]
         elif op == "reshape":
             outs = [ins[0].reshape(at["shape"])]
+        elif op == "gauss_ll":
+            y, f_, var = ins[:3]
+            s = ins[3].reshape(()) if len(ins) > 3 else torch.ones((), dtype=DT)
+            v = var.reshape(())
+            mu = f_.reshape(-1) * s
+            dlt = y.reshape(-1) - mu
+            dmu = dlt / v
+            ll = (-0.5 * math.log(2 * math.pi) - 0.5 * torch.log(v) - 0.5 * dlt * dlt / v).sum()
+            outs = [ll.reshape(1), dmu.reshape(f_.shape), (dmu * f_.reshape(-1)).sum().reshape(1),
+                    (-0.5 / v + 0.5 * dlt * dlt / (v * v)).sum().reshape(1)]
         elif op == "bcast":
             outs = [torch.broadcast_to(ins[0], tuple(at["shape"])).clone()]
         elif op == "strided":

@@ -697,3 +697,26 @@ def test_gather_rows_multi(H, p):
     bad = torch.as_tensor(np.array([0, N + 3] + [1] * (n - 2))).cuda()
     H.MultiGather(dsrc, outs, bad, None, err).launch(use_perm=False)
     assert err.item() == 1 and np.all(host(outs[1])[1] == 0)
+
+
+@pytest.mark.parametrize("p", ["f32", "f64"])
+@pytest.mark.parametrize("n,scaled", [(1, True), (1000, True), (8192, False), (5001, True)])
+def test_gauss_ll_fused(H, p, n, scaled):
+    """hb_gauss_ll: sum of log N(x | f*scale, var) and the pieces of its gradient == the oracle's density + autograd."""
+    dt = DT[p]
+    rng = np.random.RandomState(n)
+    x, f = rng.randn(1, n), rng.randn(1, n)
+    s, v = np.array([1.7]), np.array([0.6])
+    tf_ = torch.as_tensor(f).requires_grad_(True)
+    ts, tv = torch.as_tensor(s).requires_grad_(True), torch.as_tensor(v).requires_grad_(True)
+    mu = tf_ * ts if scaled else tf_
+    ll = O.gaussian(torch.as_tensor(x), mu, tv).sum()
+    gmu, = torch.autograd.grad(ll, [mu], retain_graph=True)
+    gs, gv = torch.autograd.grad(ll, [ts, tv], allow_unused=True)
+    got = H.gauss_ll(dev(x, dt), dev(f, dt), dev(s, dt) if scaled else None, dev(v, dt))
+    tol = TOL[p] if p == "f64" else dict(rtol=2e-4, atol=2e-3)
+    assert_close(got[0], ll.detach().reshape(1), tol)
+    assert_close(got[1], gmu, TOL[p] if p == "f64" else dict(rtol=1e-4, atol=1e-5))
+    if scaled:
+        assert_close(got[2], gs.reshape(1), tol)
+    assert_close(got[3], gv.reshape(1), tol)
