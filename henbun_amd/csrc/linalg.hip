@@ -23,6 +23,7 @@ struct MmArgs {
   long sBias;
   int act, flags, S, tile;
   int to_ws;  // results go to the workspace slabs and the finish kernel writes C (split-K, or SYM_OUT)
+  int bfast;  // batch index fastest in blockIdx.x (batch % 8 == 0), see matmul_kernel
   T* ws;
 };
 
@@ -53,11 +54,24 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
   // blockIdx.x = tile * S + slab, slab fastest: workgroups are dealt to the 8 XCDs round-robin, so with S a
   // multiple of 8 every XCD works on its own contraction slabs (all tiles of them) and an operand slab is fetched
   // into ONE L2 instead of all eight (the Lbar contraction moved 106 MB for 33 MB of operands before this)
-  const int tile = blockIdx.x / a.S;
-  const int s = blockIdx.x - tile * a.S;
+  // With a batch that is a multiple of 8 (experts) the batch index is fastest instead: an XCD then works on "its"
+  // matrices only, and consecutive workgroups of one matrix walk the tiles of one slab (tile fastest), which share
+  // operand rows through that XCD's L2.
+  int tile, s;
+  long b;
+  if (a.bfast) {
+    b = blockIdx.x % a.batch;
+    const int rest = (int)(blockIdx.x / a.batch);
+    const int ntile = tiles_n * ((M + BT - 1) / BT);
+    s = rest / ntile;
+    tile = rest - s * ntile;
+  } else {
+    tile = blockIdx.x / a.S;
+    s = blockIdx.x - tile * a.S;
+    b = blockIdx.y;
+  }
   const int row0 = (tile / tiles_n) * BT;
   const int col0 = (tile % tiles_n) * BT;
-  const long b = blockIdx.y;
   if ((a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && col0 > row0 + BT - 1) {
     if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && !a.to_ws) {
       // a tile wholly above the diagonal: all zero (with split-K the finish kernel writes them)
@@ -254,8 +268,9 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   a.S = S;
   a.to_ws = (S > 1 || (flags & HB_MM_SYM_OUT)) ? 1 : 0;
   const long tiles_final = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
-  HB_REQUIRE(tiles_final * S < 2147483647L, "hb_matmul: grid too large");
-  dim3 grid((unsigned)(tiles_final * S), (unsigned)batch, 1);
+  HB_REQUIRE(tiles_final * S * batch < 2147483647L, "hb_matmul: grid too large");
+  a.bfast = (batch > 1 && batch % 8 == 0) ? 1 : 0;
+  dim3 grid = a.bfast ? dim3((unsigned)(tiles_final * S * batch), 1, 1) : dim3((unsigned)(tiles_final * S), (unsigned)batch, 1);
   constexpr long VEC = 16 / sizeof(T);
   const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % VEC == 0 && ldb % VEC == 0 &&
                        sA % VEC == 0 && sB % VEC == 0;

@@ -46,7 +46,26 @@ struct SgpArgs {
   T* A;         // [E, M, n]
   long n, M, d, P;
   T* part;      // [E, gridDim.y, 5, n] column partial sums (sum A^2, sum_m u_pm A_mj for p < 4) or nullptr
+  long efast;   // > 0: the grid is (columns * E, rows, 1) with the expert index fastest (see sgp_block)
 };
+
+// Expert <-> XCD affinity.  Workgroups are dealt to the 8 XCDs round-robin by linear id, i.e. by blockIdx.x.  With
+// the expert in blockIdx.z every XCD sees every expert and their E triangular factors (1 MB each at M = 512) compete
+// for one 4 MB L2; when E is a multiple of 8 the expert is made the fastest grid coordinate instead, so an XCD only
+// ever works on "its" experts.
+__device__ __forceinline__ void sgp_block(long efast, long& e, int& bx) {
+  if (efast > 0) {
+    e = blockIdx.x % efast;
+    bx = (int)(blockIdx.x / efast);
+  } else {
+    e = blockIdx.z;
+    bx = (int)blockIdx.x;
+  }
+}
+static inline dim3 sgp_grid(long gx, long gy, long E, long& efast) {
+  efast = (E > 1 && E % 8 == 0) ? E : 0;
+  return efast ? dim3((unsigned)(gx * E), (unsigned)gy, 1) : dim3((unsigned)gx, (unsigned)gy, (unsigned)E);
+}
 
 // ---------------------------------------------------------------------------
 // forward: A = W K(z,x)
@@ -95,14 +114,16 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
   typedef TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2> G;
   __shared__ __attribute__((aligned(16))) T lds[G::LDS_ELEMS + (D > 0 ? SGP_ZS_MAX : 1)];
   T* zs = lds + G::LDS_ELEMS;
-  const long e = blockIdx.z;
+  long e;
+  int bx;
+  sgp_block(a.efast, e, bx);
   const T* x = a.x + e * a.sx;
   const T* z = a.z + e * a.M * a.d;
   const T* ell = a.ell + e * a.dl;
   const T* W = a.W + e * a.M * a.M;
   T* A = a.A + e * a.M * a.n;
   const int M = (int)a.M, n = (int)a.n, d = (int)a.d;
-  const int col0 = blockIdx.x * SGP_BN;
+  const int col0 = bx * SGP_BN;
   const int nRB = (M + SGP_BM - 1) / SGP_BM;
   const int Mm1 = M - 1;
 
@@ -323,14 +344,16 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
   __shared__ __attribute__((aligned(16))) float Ks[SGP_SN][SGP_SLD];
   __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
   __shared__ float us[4][SGP_SM_MAX];  // u rows for the column statistics (staged once: the epilogue reads them per accumulator row)
-  const long e = blockIdx.z;
+  long e;
+  int bx;
+  sgp_block(a.efast, e, bx);
   const float* __restrict__ x = a.x + e * a.sx;
   const float* __restrict__ z = a.z + e * a.M * D;
   const float* __restrict__ ell = a.ell + e * a.dl;
   const float* __restrict__ W = a.W + e * a.M * a.M;
   float* __restrict__ A = a.A + e * a.M * a.n;
   const int M = (int)a.M, n = (int)a.n;
-  const int col0 = blockIdx.x * SGP_SN;
+  const int col0 = bx * SGP_SN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
 
   HB_SSTAMP(0);
@@ -540,12 +563,16 @@ static inline bool hb_sgp_no_strip() {
   static const bool v = getenv("HB_SGP_NO_STRIP") != nullptr;
   return v;
 }
-static inline bool sgp_strip_ok(long M, long d, const void* W) {
-  return M >= 32 && M <= SGP_SM_MAX && M % 32 == 0 && d <= SGP_DREG && ((uintptr_t)W % 16 == 0);
+// The strip form wins when the tiled kernel would leave ~one workgroup per CU (cfg 2: 35.7 -> 32.9 us); with
+// many experts / a long minibatch the tiled kernel runs several workgroups per CU and is the faster one
+// (cfg 5, E = 8, n = 65536: 1.83 ms tiled vs 2.10 ms strip).
+static inline bool sgp_strip_ok(long E, long n, long M, long d, const void* W) {
+  const long tiled_wgs = E * hb_cdiv(n, SGP_BN) * ((hb_cdiv(M, SGP_BM) + 1) / 2);
+  return M >= 32 && M <= SGP_SM_MAX && M % 32 == 0 && d <= SGP_DREG && ((uintptr_t)W % 16 == 0) && tiled_wgs < 1024;
 }
 
-static int sgp_A_strip_launch(const SgpArgs<float>& a, long E, hipStream_t stream) {
-  dim3 grid(hb_cdiv(a.n, SGP_SN), 1, (unsigned)E);
+static int sgp_A_strip_launch(SgpArgs<float> a, long E, hipStream_t stream) {
+  dim3 grid = sgp_grid(hb_cdiv(a.n, SGP_SN), 1, E, a.efast);
   if (a.d == 1)
     hipLaunchKernelGGL(sgp_A_strip_kernel<1>, grid, dim3(256), 0, stream, a);
   else if (a.d == 2)
@@ -557,7 +584,7 @@ static int sgp_A_strip_launch(const SgpArgs<float>& a, long E, hipStream_t strea
   HB_LAUNCH_CHECK();
   return 0;
 }
-static int sgp_A_strip_launch(const SgpArgs<double>&, long, hipStream_t) { return -1; }  // fp32 only
+static int sgp_A_strip_launch(SgpArgs<double>, long, hipStream_t) { return -1; }  // fp32 only
 
 // D dispatch: z staged in LDS when d <= SGP_DREG; vector operand path when, in
 // addition, M is a multiple of 16 and W is 16-byte aligned.
@@ -736,13 +763,13 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = u; a.A = A;
     a.n = n; a.M = M; a.d = d; a.P = P;
     a.part = ws + E * n + E * M * d;
-    const bool strip = sizeof(T) == 4 && sgp_strip_ok(M, d, W) && !hb_sgp_no_strip();
+    const bool strip = sizeof(T) == 4 && sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip();
     const int gyp = strip ? 1 : gy;  // partial rows of the column statistics
     int rc;
     if (strip) {
       rc = sgp_A_strip_launch(a, E, stream);
     } else {
-      dim3 grid(hb_cdiv(n, SGP_BN), gy, (unsigned)E);
+      dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), gy, E, a.efast);
       rc = sgp_A_launch<T>(a, grid, stream);
     }
     if (rc) return rc;
@@ -770,7 +797,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = u; a.A = A;
     a.n = n; a.M = M; a.d = d; a.P = P;
     a.part = nullptr;
-    dim3 grid(hb_cdiv(n, SGP_BN), gy, (unsigned)E);
+    dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), gy, E, a.efast);
     int rc = sgp_A_launch<T>(a, grid, stream);
     if (rc) return rc;
   }
@@ -796,9 +823,9 @@ static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, l
   a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = nullptr; a.A = A;
   a.n = n; a.M = M; a.d = d; a.P = 0;
   a.part = nullptr;
-  if (sizeof(T) == 4 && sgp_strip_ok(M, d, W) && !hb_sgp_no_strip()) return sgp_A_strip_launch(a, E, stream);
+  if (sizeof(T) == 4 && sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip()) return sgp_A_strip_launch(a, E, stream);
   const int nRB = hb_cdiv(M, SGP_BM);
-  dim3 grid(hb_cdiv(n, SGP_BN), sgp_grid_y(E, n, nRB), (unsigned)E);
+  dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), sgp_grid_y(E, n, nRB), E, a.efast);
   return sgp_A_launch<T>(a, grid, stream);
 }
 extern "C" int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
@@ -855,6 +882,7 @@ struct SgpBwdArgs {
   T* Kbar;        // [E, M, n]
   long n, M, P;
   int mode;
+  long efast;     // expert-fastest grid (see sgp_block)
 };
 
 template <typename T>
@@ -873,7 +901,9 @@ template <typename T, bool FAST>
 __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
   typedef TileGemm<T, SGP_BM, SGP_BN, 16, 2, 2> G;
   __shared__ __attribute__((aligned(16))) T lds[G::LDS_ELEMS];
-  const long e = blockIdx.z;
+  long e;
+  int bx;
+  sgp_block(a.efast, e, bx);
   const T* W = a.W + e * a.M * a.M;
   const T* u = a.u + e * a.P * a.M;
   const T* A = a.A + e * a.M * a.n;
@@ -882,7 +912,7 @@ __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
   const T* vres = a.v + e * a.n;
   T* Kbar = a.Kbar + e * a.M * a.n;
   const int M = (int)a.M, n = (int)a.n;
-  const int col0 = blockIdx.x * SGP_BN;
+  const int col0 = bx * SGP_BN;
   const int nRB = (M + SGP_BM - 1) / SGP_BM;
   const int jcol = col0 + (threadIdx.x % SGP_BN);
   const bool jok = jcol < n;
@@ -1223,7 +1253,7 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.W = W; a.u = u; a.A = A; a.fbar = fbar; a.eps = eps; a.v = v; a.Kbar = Kbar;
     a.n = n; a.M = M; a.P = P; a.mode = mode;
     const int nRB = hb_cdiv(M, SGP_BM);
-    dim3 grid(hb_cdiv(n, SGP_BN), sgp_grid_y(E, n, nRB), (unsigned)E);
+    dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), sgp_grid_y(E, n, nRB), E, a.efast);
     constexpr long VECH = 16 / sizeof(T);
     const bool vec = P == 1 && M % 16 == 0 && n % VECH == 0 && ((uintptr_t)W % 16 == 0) && ((uintptr_t)A % 16 == 0);
     if (vec)
