@@ -236,11 +236,14 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   a.tile = BT;
   const long tiles = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
   const long active = active_tiles(BT);
-  if (BT == 64 && ws && active * batch < 320 && K >= 128) {
+  if (BT == 64 && ws && (active * batch < 320 || K >= 32768) && K >= 128) {
     // few tiles: split the contraction, each slice >= 64 deep.  Deep problems (K >= 2048) want ~3.5 workgroups per
     // CU; shallow ones are dominated by the slab traffic (S slabs written, then read by the finish kernel), so they
     // stop at ~1.25 workgroups per CU
     long s0 = (K >= 2048 ? 896 : 320) / (active * batch);
+    // very deep contractions: slabs of ~2048 even when there are plenty of tiles (8 experts x K = 65536: 2.47 ms
+    // with 2 slabs, 1.74 ms with 32 -- tools/lbar_probe.py)
+    if (K >= 32768 && K / 2048 > s0) s0 = K / 2048;
     const long s1 = K / 64;
     const long s3 = ws_elems / (batch * M * N);
     if (s0 > s1) s0 = s1;
