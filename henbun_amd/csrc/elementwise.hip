@@ -501,7 +501,16 @@ __global__ void __launch_bounds__(256) reduce_cols_kernel(const T* __restrict__ 
   T acc = red_identity<T, OP>();
   if (col < K2) {
     const T* base = in + k1 * R * K2 + col;
-    for (long r = beg + ry; r < end; r += 4) acc = red_combine<T, OP>(acc, base[r * K2]);
+    // eight rows in flight per step (a one-load-per-iteration loop is bound by the load round trip, not bandwidth)
+    long r = beg + ry;
+    for (; r + 28 < end; r += 32) {
+      T v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = base[(r + 4 * q) * K2];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc = red_combine<T, OP>(acc, v[q]);
+    }
+    for (; r < end; r += 4) acc = red_combine<T, OP>(acc, base[r * K2]);
   }
   smem[ry][cx] = acc;
   __syncthreads();
