@@ -178,8 +178,18 @@ __global__ void __launch_bounds__(256) fullrank_fwd_wave_kernel(const T* __restr
     const long r = o / size, k = o - r * size;
     const T* Srow = S + (r * size + k) * size;
     const T* ur = u + r * size;
+    // four row segments in flight per step (same summation order as the plain loop: deterministic)
     T dot = T(0);
-    for (long j = lane; j <= k; j += 64) dot += Srow[j] * ur[j];
+    long j = lane;
+    for (; j + 192 <= k; j += 256) {
+      const T s0 = Srow[j], s1 = Srow[j + 64], s2 = Srow[j + 128], s3 = Srow[j + 192];
+      const T u0 = ur[j], u1 = ur[j + 64], u2 = ur[j + 128], u3 = ur[j + 192];
+      dot += s0 * u0;
+      dot += s1 * u1;
+      dot += s2 * u2;
+      dot += s3 * u3;
+    }
+    for (; j <= k; j += 64) dot += Srow[j] * ur[j];
     dot = wave_sum(dot);
     if (lane == 0) {
       const T xv = mu[o] + dot;
