@@ -329,6 +329,28 @@ struct TileGemm {
     }
   }
 
+  // tile-local column of this thread's accumulator fragment j (its columns do not depend on i or r)
+  __device__ __forceinline__ int frag_col(int j) const {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    return (w % WN) * WTN + j * MM::TN + MM::acc_col(lane);
+  }
+  // f(j, row, col, value): as for_each, with the column-fragment index (per-column data can be preloaded per j)
+  template <class F>
+  __device__ __forceinline__ void for_each_j(F f) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w / WN, wn = w % WN;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int j = 0; j < RN; ++j)
+#pragma unroll
+        for (int r = 0; r < MM::NACC; ++r) {
+          const int row = wm * WTM + i * MM::TM + MM::acc_row(lane, r);
+          const int col = wn * WTN + j * MM::TN + MM::acc_col(lane);
+          f(j, row, col, acc[i][j][r]);
+        }
+  }
+
   // f(row, col, value) over this thread's accumulator elements (tile-local)
   template <class F>
   __device__ __forceinline__ void for_each(F f) {

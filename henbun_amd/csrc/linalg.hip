@@ -135,11 +135,19 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
   } else {
     T* Cb = a.C + b * a.sC;
     const T* biasb = a.bias ? a.bias + b * a.sBias : nullptr;
-    g.for_each([&](int row, int col, T v) {
+    // the bias of this thread's columns, loaded once: a `biasb[c]` inside the store loop is re-loaded after every
+    // store (it may alias C as far as the compiler knows): one dependent round trip per output element
+    T breg[G::RN];
+#pragma unroll
+    for (int j = 0; j < G::RN; ++j) {
+      const int c = col0 + g.frag_col(j);
+      breg[j] = biasb ? biasb[c < N ? c : N - 1] : T(0);
+    }
+    g.for_each_j([&](int j, int row, int col, T v) {
       const long r = row0 + row, c = col0 + col;
       if (r < a.M && c < a.N) {
         T o = a.alpha * v;
-        if (biasb) o += biasb[c];
+        o += breg[j];
         o = apply_act<T>(a.act, o);
         if (a.beta != T(0)) o += a.beta * Cb[r * a.ldc + c];
         if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && c > r) o = T(0);
