@@ -219,6 +219,14 @@ __device__ __forceinline__ T hb_sigmoid(T x) {
     return e / (T(1) + e);
   }
 }
+// fp32: branch-free on v_exp_f32 / v_rcp_f32 (1 ulp each) -- the IEEE exp + divide sequences are ~40 instructions
+// per element and dominated the epilogue of the bias+sigmoid GEMMs
+template <>
+__device__ __forceinline__ float hb_sigmoid<float>(float x) {
+  const float e = __expf(-fabsf(x));           // in (0, 1]: no overflow
+  const float r = __builtin_amdgcn_rcpf(1.0f + e);
+  return x >= 0.0f ? r : e * r;
+}
 
 // ---------------------------------------------------------------------------
 // xoroshiro128+ per-lane generator.  The state array holds two uint64 per
