@@ -233,7 +233,8 @@ def main():
         "flops_per_step_algorithmic": 3.0 * Mi * Mi * n + 3.0 * Mi ** 3 + 4.0 * Mi * n,
         "elbo_after": elbo_after,
         "roofline": roofline,
-        "step_breakdown_us": breakdown,
+        "step_breakdown_us_eager_replay": breakdown,  # informational: small ops are CPU-launch bound in this replay
+
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
