@@ -268,15 +268,13 @@ struct TileGemm {
     for (int g = 0; g < NG; ++g) fetch_one(g, kbeg + BK);
     __syncthreads();
 
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      const T* __restrict__ As = lds + cur * BUF_ELEMS;
+    // MFMA sub-step s contracts, for the lane's k-group h = lane / T{M,N}, over k = h*NS + s (the
+    // contraction order is free as long as both operands agree): a lane's NS values are consecutive in k
+    static_assert(NS % VEC == 0 && MM::TK * NS == BK && NS % 2 == 0, "fragment vectors");
+    typedef T FragA[NS][RM];
+    typedef T FragB[NS][RN];
+    auto read_frags = [&](const T* __restrict__ As, FragA& a, FragB& b) {
       const T* __restrict__ Bs = As + A_ELEMS;
-      T* __restrict__ nxt = lds + (cur ^ 1) * BUF_ELEMS;
-      // MFMA sub-step s contracts, for the lane's k-group h = lane / T{M,N}, over k = h*NS + s (the
-      // contraction order is free as long as both operands agree): a lane's NS values are consecutive in k
-      static_assert(NS % VEC == 0 && MM::TK * NS == BK, "fragment vectors");
-      T a[NS][RM], b[NS][RN];
       if (AMODE == HB_KC) {
 #pragma unroll
         for (int i = 0; i < RM; ++i)
@@ -307,26 +305,55 @@ struct TileGemm {
 #pragma unroll
           for (int j = 0; j < RN; ++j) b[s][j] = Bs[(bk * NS + s) * LDB + bn + j * MM::TN];
       }
-      // keep ALL fragment reads issued here: the compiler otherwise sinks each ds_read in front of
-      // its MFMA and pays the LDS latency once per MFMA group instead of once per k-step
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    // One k-step, software-pipelined across the single barrier it contains:
+    //   first half of the MFMAs  | finish + stash tile k+1 into `nxt`, refill the raw registers with tile k+2
+    //   lgkmcnt(0) + s_barrier   (stash visible; `cur` was last read half a step ago)
+    //   second half of the MFMAs | ds_read the fragments of tile k+1 from `nxt` into the other register set
+    // so the LDS read latency sits under MFMA issue instead of at the top of every step.
+    auto step = [&](const FragA& a, const FragB& b, FragA& an, FragB& bn_, int k0, T* __restrict__ nxt) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
+      for (int s = 0; s < NS / 2; ++s) {
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
           for (int j = 0; j < RN; ++j) acc[i][j] = MM::mma(a[s][i], b[s][j], acc[i][j]);
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-          if (g * NS / NG == s) {
+          if (g * (NS / 2) / NG == s) {
             stash_one(g, k0 + BK, nxt);
             fetch_one(g, k0 + 2 * BK);
           }
       }
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: global loads stay in flight across the barrier
       __builtin_amdgcn_s_barrier();
-      cur ^= 1;
+      read_frags(nxt, an, bn_);
+      // keep the fragment reads issued here, ahead of the second half's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = NS / 2; s < NS; ++s)
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j) acc[i][j] = MM::mma(a[s][i], b[s][j], acc[i][j]);
+    };
+
+    FragA a0, a1;
+    FragB b0, b1;
+    T* __restrict__ buf0 = lds;
+    T* __restrict__ buf1 = lds + BUF_ELEMS;
+    read_frags(buf0, a0, b0);
+    for (int k0 = kbeg;;) {
+      step(a0, b0, a1, b1, k0, buf1);
+      k0 += BK;
+      if (k0 >= kend) break;
+      step(a1, b1, a0, b0, k0, buf0);
+      k0 += BK;
+      if (k0 >= kend) break;
     }
+    // the last step's look-ahead reads are never used, but the LDS buffers are: callers reuse them right away
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
   }
 
   // tile-local column of this thread's accumulator fragment j (its columns do not depend on i or r)
