@@ -219,8 +219,10 @@ struct TileGemm {
     const int bn = wn * WTN + (lane % MM::TN), bk = lane / MM::TN;
     typedef decltype(la(0, 0)) RawA;
     typedef decltype(lb(0, 0)) RawB;
-    RawA ra[GA];
-    RawB rb[GB];
+    // two raw register sets: the tile stashed in step k was fetched two steps earlier, so operands that
+    // stream from HBM (contraction lengths of 1e4..1e5) have two k-steps to arrive, not one
+    RawA ra[2][GA];
+    RawB rb[2][GB];
 
     // group g of this thread -> first (m, kk) / (kk, n) inside the tile
     auto a_m = [&](int g) { const int i = g * NT + tid; return AMODE == HB_KC ? i / (BK / VEC) : (i % (BM / VEC)) * VEC; };
@@ -228,7 +230,7 @@ struct TileGemm {
     auto b_n = [&](int g) { const int i = g * NT + tid; return BMODE == HB_KC ? i / (BK / VEC) : (i % (BN / VEC)) * VEC; };
     auto b_kk = [&](int g) { const int i = g * NT + tid; return BMODE == HB_KC ? (i % (BK / VEC)) * VEC : i / (BN / VEC); };
 
-    auto fetch_one = [&](int g, int k0) {
+    auto fetch_one = [&](int g, int k0, RawA* ra, RawB* rb) {
       // past the end the tile is never consumed: re-read the last tile instead of running off the operand
       const int kc = k0 < kend ? k0 : kend - BK;
       if (g < GA) {
@@ -238,7 +240,7 @@ struct TileGemm {
         rb[gb >= 0 ? gb : 0] = lb(kc + b_kk(gb), b_n(gb));
       }
     };
-    auto stash_one = [&](int g, int k0, T* buf) {
+    auto stash_one = [&](int g, int k0, T* buf, const RawA* ra, const RawB* rb) {
       const int kc = k0 < kend ? k0 : kend - BK;
       if (g < GA) {
         const int m = a_m(g), kk = a_kk(g);
@@ -261,11 +263,13 @@ struct TileGemm {
     };
 
 #pragma unroll
-    for (int g = 0; g < NG; ++g) fetch_one(g, kbeg);
+    for (int g = 0; g < NG; ++g) fetch_one(g, kbeg, ra[0], rb[0]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) stash_one(g, kbeg, lds);
+    for (int g = 0; g < NG; ++g) fetch_one(g, kbeg + BK, ra[1], rb[1]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) fetch_one(g, kbeg + BK);
+    for (int g = 0; g < NG; ++g) stash_one(g, kbeg, lds, ra[0], rb[0]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) fetch_one(g, kbeg + 2 * BK, ra[0], rb[0]);
     __syncthreads();
 
     // MFMA sub-step s contracts, for the lane's k-group h = lane / T{M,N}, over k = h*NS + s (the
@@ -311,7 +315,10 @@ struct TileGemm {
     //   lgkmcnt(0) + s_barrier   (stash visible; `cur` was last read half a step ago)
     //   second half of the MFMAs | ds_read the fragments of tile k+1 from `nxt` into the other register set
     // so the LDS read latency sits under MFMA issue instead of at the top of every step.
-    auto step = [&](const FragA& a, const FragB& b, FragA& an, FragB& bn_, int k0, T* __restrict__ nxt) {
+    // the stash is packed into the first QS sub-steps so that its LDS writes have landed by the time the
+    // mid-step wait is reached (a wave cannot issue MFMAs past an s_waitcnt)
+    constexpr int QS = NS / 4 > 0 ? NS / 4 : 1;
+    auto step = [&](const FragA& a, const FragB& b, FragA& an, FragB& bn_, int k0, T* __restrict__ nxt, RawA* ra, RawB* rb) {
 #pragma unroll
       for (int s = 0; s < NS / 2; ++s) {
 #pragma unroll
@@ -320,10 +327,11 @@ struct TileGemm {
           for (int j = 0; j < RN; ++j) acc[i][j] = MM::mma(a[s][i], b[s][j], acc[i][j]);
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-          if (g * (NS / 2) / NG == s) {
-            stash_one(g, k0 + BK, nxt);
-            fetch_one(g, k0 + 2 * BK);
+          if (s < QS && g * QS / NG == s) {
+            stash_one(g, k0 + BK, nxt, ra, rb);
+            fetch_one(g, k0 + 3 * BK, ra, rb);
           }
+        __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise hoists the stash (and the wait) to the top
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: global loads stay in flight across the barrier
       __builtin_amdgcn_s_barrier();
@@ -343,14 +351,13 @@ struct TileGemm {
     T* __restrict__ buf0 = lds;
     T* __restrict__ buf1 = lds + BUF_ELEMS;
     read_frags(buf0, a0, b0);
-    for (int k0 = kbeg;;) {
-      step(a0, b0, a1, b1, k0, buf1);
-      k0 += BK;
-      if (k0 >= kend) break;
-      step(a1, b1, a0, b0, k0, buf0);
-      k0 += BK;
-      if (k0 >= kend) break;
+    // two steps per trip, in ONE basic block (fragment reads must not be sunk into a successor block)
+    int k0 = kbeg;
+    for (; k0 + 2 * BK <= kend; k0 += 2 * BK) {
+      step(a0, b0, a1, b1, k0, buf1, ra[1], rb[1]);
+      step(a1, b1, a0, b0, k0 + BK, buf0, ra[0], rb[0]);
     }
+    if (k0 < kend) step(a0, b0, a1, b1, k0, buf1, ra[1], rb[1]);
     // the last step's look-ahead reads are never used, but the LDS buffers are: callers reuse them right away
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
