@@ -385,6 +385,25 @@ struct TileGemm {
         }
   }
 
+  // f(row, col, value&): in-place variant of for_each
+  template <class F>
+  __device__ __forceinline__ void for_each_ref(F f) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w / WN, wn = w % WN;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int j = 0; j < RN; ++j)
+#pragma unroll
+        for (int r = 0; r < MM::NACC; ++r) {
+          const int row = wm * WTM + i * MM::TM + MM::acc_row(lane, r);
+          const int col = wn * WTN + j * MM::TN + MM::acc_col(lane);
+          T val = acc[i][j][r];  // (an accumulator is a vector register: its elements cannot be bound by reference)
+          f(row, col, val);
+          acc[i][j][r] = val;
+        }
+  }
+
   // f(row, col, value) over this thread's accumulator elements (tile-local)
   template <class F>
   __device__ __forceinline__ void for_each(F f) {

@@ -37,6 +37,17 @@ __device__ __forceinline__ T apply_act(int act, T v) {
   }
 }
 
+// derivative of the activation expressed through its OUTPUT y (HB_MM_ACTGRAD)
+template <typename T>
+__device__ __forceinline__ T act_grad(int act, T y) {
+  switch (act) {
+    case HB_ACT_SIGMOID: return y * (T(1) - y);
+    case HB_ACT_RELU: return y > T(0) ? T(1) : T(0);
+    case HB_ACT_TANH: return T(1) - y * y;
+    default: return T(1);
+  }
+}
+
 // k-step depth.  (32 was tried for the k-contiguous/k-contiguous 128x128 case -- whole 128-byte lines per row
 // and step -- and measured slower: 62.8 vs 56.3 us on the Lbar contraction, profiles/r01_kloop_cycles.txt.)
 template <typename T, bool TA, bool TB, int BT>
@@ -134,6 +145,21 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
     });
   } else {
     T* Cb = a.C + b * a.sC;
+    if (a.flags & HB_MM_ACTGRAD) {
+      // two passes: every Y load is issued before the first store (a load inside the store loop waits for the
+      // store before it -- C may alias Y as far as the compiler knows)
+      const T* __restrict__ Yb = a.bias + b * a.sBias;
+      g.for_each_ref([&](int row, int col, T& v) {
+        const long r = row0 + row, c = col0 + col;
+        const T y = Yb[(r < a.M ? r : a.M - 1) * a.N + (c < a.N ? c : a.N - 1)];
+        v *= a.alpha * act_grad<T>(a.act, y);
+      });
+      g.for_each([&](int row, int col, T v) {
+        const long r = row0 + row, c = col0 + col;
+        if (r < a.M && c < a.N) Cb[r * a.ldc + c] = v;
+      });
+      return;
+    }
     const T* biasb = a.bias ? a.bias + b * a.sBias : nullptr;
     // the bias of this thread's columns, loaded once: a `biasb[c]` inside the store loop is re-loaded after every
     // store (it may alias C as far as the compiler knows): one dependent round trip per output element
@@ -193,6 +219,10 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
       continue;
     }
     if ((a.flags & HB_MM_PHI_OUT) && c == r) acc *= T(0.5);
+    if (a.flags & HB_MM_ACTGRAD) {
+      cp[0] = acc * act_grad<T>(a.act, a.bias[b * a.sBias + r * a.N + c]);
+      continue;
+    }
     if (a.bias) acc += a.bias[b * a.sBias + c];
     acc = apply_act<T>(a.act, acc);
     if (a.beta != T(0)) acc += a.beta * cp[0];
@@ -229,13 +259,17 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   HB_REQUIRE(!(flags & HB_MM_SYM_OUT) || (M == N && ws && ws_elems >= batch * M * N && !bias && act == HB_ACT_NONE &&
                                           beta == 0.0 && !(flags & ~HB_MM_SYM_OUT)),
              "hb_matmul: SYM_OUT needs a square result, a workspace, and no other epilogue");
+  HB_REQUIRE(!(flags & HB_MM_ACTGRAD) || (bias && beta == 0.0 && flags == HB_MM_ACTGRAD),
+             "hb_matmul: ACTGRAD needs Y in `bias`, beta = 0 and no other flag");
   const bool lower = (flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) != 0;
   auto active_tiles = [&](int bt) -> long {
     const long tr = hb_cdiv(M, bt), tc = hb_cdiv(N, bt);
     return (lower && M == N) ? tr * (tr + 1) / 2 : tr * tc;
   };
   int BT = 64, S = 1;
-  if (M >= 256 && N >= 256) {
+  // (short contractions are store-bound: more, smaller workgroups hide the output traffic better -- the MLP
+  //  layers of cfg 4, K = 32 / 64: 0.319 ms/step with 128-tiles, 0.272 with 64-tiles)
+  if (M >= 256 && N >= 256 && K >= 256) {
     const long a128 = active_tiles(128) * batch;
     if (a128 >= 200) {
       BT = 128;  // enough big tiles to cover the chip

@@ -198,8 +198,20 @@ def bshape(*shapes):
     return tuple(np.broadcast_shapes(*shapes))
 
 
+def _cval(t):
+    """the value of a single-element constant tensor, else None"""
+    if isinstance(t, Tensor) and t.node.op == "leaf:const" and t.size == 1:
+        return float(np.asarray(t.node.attrs["value"]).reshape(-1)[0])
+    return None
+
+
 def unary(opname, x, params=()) -> Tensor:
     x = as_tensor(x)
+    c = _cval(x)
+    if c is not None and opname in ("NEG", "AFFINE"):
+        # single-element constants fold at trace time: the gradient seed and its sign flips never reach the device
+        v = -c if opname == "NEG" else float(params[0]) * c + float(params[1])
+        return constant(np.full(x.shape, v))
     return make("ew", (x,), {"f": opname, "p": tuple(float(p) for p in params)}, [x.shape]).outputs[0]
 
 
@@ -235,6 +247,15 @@ def mul(a, b):
         return affine(a, float(b), 0.0)
     if is_scalar_const(a):
         return affine(b, float(a), 0.0)
+    a, b = as_tensor(a), as_tensor(b)
+    ca, cb = _cval(a), _cval(b)
+    shp = bshape(a.shape, b.shape)
+    if ca is not None and cb is not None:
+        return constant(np.full(shp, ca * cb))
+    if ca is not None and shp == tuple(b.shape):
+        return affine(b, ca, 0.0)
+    if cb is not None and shp == tuple(a.shape):
+        return affine(a, cb, 0.0)
     return binary("MUL", a, b)
 
 
@@ -527,6 +548,8 @@ def reshape(x, shape) -> Tensor:
         raise ValueError("cannot reshape %s to %s" % (x.shape, shape))
     if shape == x.shape:
         return x
+    if x.node.op == "leaf:const":
+        return constant(np.asarray(x.node.attrs["value"]).reshape(shape))
     return make("reshape", (x,), {"shape": shape}, [shape]).outputs[0]
 
 
@@ -820,7 +843,7 @@ def _matmul_emit(plan, node):
     # a triangular / Phi / symmetrising matutil that is the only consumer becomes the GEMM's epilogue
     cons = plan._consumers.get(y, [])
     epi = 0
-    if (len(cons) == 1 and cons[0].op == "matutil" and bias is None and at["act"] == "none" and y.shape[-1] == y.shape[-2]
+    if (not at.get("actgrad") and len(cons) == 1 and cons[0].op == "matutil" and bias is None and at["act"] == "none" and y.shape[-1] == y.shape[-2]
             and y not in plan.outputs and y not in plan._bind):
         ma = cons[0].attrs
         if ma["mode"] == 2:
@@ -834,6 +857,10 @@ def _matmul_emit(plan, node):
         plan._fused_matutil.add(cons[0].id)
     else:
         out = plan.out(y)
+    if at.get("actgrad"):
+        # third input = the activation output Y: C = (op(A) op(B)) * act'(Y)
+        plan.steps.append(lambda: H.matmul(a, b, transA=at["ta"], transB=at["tb"], act=at["actgrad"], actgrad=bias, out=out))
+        return
     plan.steps.append(lambda: H.matmul(a, b, transA=at["ta"], transB=at["tb"], bias=bias, act=at["act"], out=out,
                                        epilogue=epi))
 
@@ -851,7 +878,16 @@ def _matmul_vjp(node, gs):
     a, b = node.inputs[0], node.inputs[1]
     ta, tb, act = node.attrs["ta"], node.attrs["tb"], node.attrs["act"]
     y = node.outputs[0]
-    if act == "sigmoid":
+    if node.attrs.get("actgrad"):
+        raise NotImplementedError("second derivatives through a fused activation-gradient GEMM are not supported")
+    gn = g.node
+    if (act != "none" and gn.op == "matmul" and len(gn.inputs) == 2 and gn.attrs["act"] == "none"
+            and not gn.attrs.get("actgrad") and tuple(g.shape) == tuple(y.shape)):
+        # the incoming gradient is itself a GEMM (the next layer's dx): the activation derivative becomes that
+        # GEMM's epilogue instead of a separate pass over the [n, H] activations (reference nn.py:79-84 backward)
+        g = make("matmul", (gn.inputs[0], gn.inputs[1], y), {"ta": gn.attrs["ta"], "tb": gn.attrs["tb"], "act": "none",
+                                                             "actgrad": act}, [tuple(g.shape)]).outputs[0]
+    elif act == "sigmoid":
         g = binary("SIGMOID_GRAD", y, g)
     elif act == "tanh":
         g = binary("TANH_GRAD", y, g)
@@ -1313,7 +1349,37 @@ def topo_order(outputs: Sequence[Tensor]) -> List[Node]:
     return order
 
 
+def _scatter_partition(ts):
+    """The gradients of last-axis slices that tile their source exactly (an encoder output split into mean and
+    log-std halves, reference variationals.py:70-80): their sum is the concatenation, not N zero-filled buffers added up."""
+    if len(ts) < 2 or any(t.node.op != "scatter_strided" for t in ts):
+        return None
+    xshape = tuple(ts[0].node.attrs["xshape"])
+    if len(xshape) < 1:
+        return None
+    cst = tuple(_contig_strides(xshape))
+    parts = []
+    for t in ts:
+        a = t.node.attrs
+        if (tuple(a["xshape"]) != xshape or len(a["shape"]) != len(xshape) or tuple(a["shape"][:-1]) != xshape[:-1]
+                or tuple(a["strides"]) != cst or not 0 <= a["offset"] < xshape[-1]):
+            return None
+        parts.append((a["offset"], a["shape"][-1], t.node.inputs[0]))
+    parts.sort(key=lambda p: p[0])
+    pos = 0
+    for off, w, _ in parts:
+        if off != pos:
+            return None
+        pos += w
+    if pos != xshape[-1]:
+        return None
+    return concat([p[2] for p in parts], len(xshape) - 1)
+
+
 def add_n(ts: List[Tensor]) -> Tensor:
+    packed = _scatter_partition(ts)
+    if packed is not None:
+        return packed
     acc = ts[0]
     for t in ts[1:]:
         acc = binary("ADD", acc, t)
@@ -1333,7 +1399,7 @@ def gradients(loss: Tensor, wrt: Sequence[Tensor]) -> List[Optional[Tensor]]:
     for n in order:
         if any(o in wrt_set for o in n.outputs) or any(t.node.id in dep for t in n.inputs):
             dep.add(n.id)
-    grads: Dict[Tensor, List[Tensor]] = {loss: [unary("AFFINE", loss, (0.0, 1.0))]}  # ones_like(loss), on device
+    grads: Dict[Tensor, List[Tensor]] = {loss: [constant(np.ones(loss.shape))]}
     for n in reversed(order):
         if n.id not in dep or n.op.startswith("leaf:"):
             continue

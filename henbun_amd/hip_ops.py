@@ -33,6 +33,7 @@ MM_LOWER_OUT = 1
 MM_TRIL_OUT = 2
 MM_PHI_OUT = 4
 MM_SYM_OUT = 8
+MM_ACTGRAD = 16
 ACT = dict(none=0, sigmoid=1, relu=2, tanh=3)
 SGP_NEGLECTED, SGP_DIAGONAL = 0, 1
 MATUTIL_BAND, MATUTIL_ADD_EYE, MATUTIL_PHI, MATUTIL_SYM = 0, 1, 2, 3
@@ -293,7 +294,7 @@ def matutil(x, mode, lower=-1, upper=-1, alpha=0.0, out=None):
 class Rng:
     """xoroshiro128+ per-lane state on the device (hb_rng_*)."""
 
-    def __init__(self, seed, stream_id=0, nlanes=16384, device="cuda"):
+    def __init__(self, seed, stream_id=0, nlanes=65536, device="cuda"):
         self.nlanes = int(nlanes)
         self.state = _empty(2 * self.nlanes, dtype=torch.int64, device=device)
         self.seed, self.stream_id = int(seed), int(stream_id)
@@ -450,9 +451,10 @@ def gram_bwd(X, X2, ell, Kbar, kind=KERN_RBF, need=(True, True, True)):
 
 # ---- dense linear algebra ------------------------------------------------------
 def matmul(A, B, transA=False, transB=False, alpha=1.0, bias=None, act="none", lower_out=False, out=None,
-           beta=0.0, tril_out=False, epilogue=0):
+           beta=0.0, tril_out=False, epilogue=0, actgrad=None):
     """C = act(alpha*op(A)@op(B) + bias) (+ beta*C).  A:[...,m,k], B:[...,k,n]; a 2-D operand broadcasts
-    over the other's leading (batch) dims.  bias: [n] or [batch..., n]/[batch...,1,n]."""
+    over the other's leading (batch) dims.  bias: [n] or [batch..., n]/[batch...,1,n].
+    actgrad=Y: C = alpha*op(A)@op(B) * act'(Y), Y = the output of activation `act` ([..., m, n], contiguous)."""
     _chk(A), _chk(B)
     am, ak = (A.shape[-1], A.shape[-2]) if transA else (A.shape[-2], A.shape[-1])
     bk, bn = (B.shape[-1], B.shape[-2]) if transB else (B.shape[-2], B.shape[-1])
@@ -469,7 +471,17 @@ def matmul(A, B, transA=False, transB=False, alpha=1.0, bias=None, act="none", l
     if out is None:
         out = _empty(lead + (am, bn), dtype=A.dtype, device=A.device)
     sBias = 0
-    if bias is not None:
+    if actgrad is not None:
+        _chk(actgrad)
+        if bias is not None or beta != 0.0 or lower_out or tril_out or epilogue:
+            raise ValueError("matmul: actgrad excludes bias, beta and the triangular epilogues")
+        if tuple(actgrad.shape[-2:]) != (am, bn) or actgrad.numel() not in (am * bn, batch * am * bn):
+            raise ValueError("matmul: actgrad operand %s does not match the result [%d,%d]" % (tuple(actgrad.shape), am, bn))
+        if not actgrad.is_contiguous() or actgrad.dtype != A.dtype:
+            raise ValueError("matmul: actgrad operand must be contiguous and of the operands' dtype")
+        bias, epilogue = actgrad, MM_ACTGRAD
+        sBias = am * bn if (actgrad.numel() == batch * am * bn and batch > 1) else 0
+    elif bias is not None:
         _chk(bias)
         if bias.numel() == bn:
             sBias = 0

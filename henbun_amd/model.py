@@ -204,8 +204,11 @@ class Optimizer:
             for t in self.model.get_tf_variables(self._collection):
                 if t is not None and t.node.op == "leaf:param" and t not in leaves:
                     leaves.append(t)
-            loss = G.unary("NEG", obj)
-            grads = G.gradients(loss, leaves)
+            # the flat buffer receives d objective / d theta; the optimiser minimises -objective (reference
+            # model.py:206-220) by reading it with a negative gscale: negation is exact, so the update is
+            # bit-identical to differentiating -objective, without a sign flip over every gradient
+            grads = [g if g is None or not g.node.op.startswith("leaf:") else G.unary("COPY", g)
+                     for g in G.gradients(obj, leaves)]
             torch = sess.torch
             gflat = torch.zeros(sess.theta.numel(), dtype=sess.torch_dtype, device=sess.device)
             binds, segs = [], []
@@ -231,7 +234,7 @@ class Optimizer:
             slots = opt.slots(sess)
             H = sess.H
             theta = sess.theta
-            gscale = parallel.gradient_scale(sess.world_size, self.dp_reduce)
+            gscale = -parallel.gradient_scale(sess.world_size, self.dp_reduce)
 
             def adam():
                 # one fused launch per contiguous segment; the shared step counter ticks once

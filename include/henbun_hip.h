@@ -240,8 +240,12 @@ enum {
   HB_MM_LOWER_OUT = 1, /* only tiles touching the lower triangle of C are computed; the rest of C is left alone */
   HB_MM_TRIL_OUT = 2,  /* C = tril(result): as LOWER_OUT, and the strict upper triangle is written as zero */
   HB_MM_PHI_OUT = 4,   /* C = Phi(result): strict lower kept, diagonal halved, strict upper zero (Cholesky VJP) */
-  HB_MM_SYM_OUT = 8    /* C = (R + R^T)/2 of the square result R (needs the workspace: ws_elems >= batch*M*N;
+  HB_MM_SYM_OUT = 8,   /* C = (R + R^T)/2 of the square result R (needs the workspace: ws_elems >= batch*M*N;
                           bias/act/beta are not applied) */
+  HB_MM_ACTGRAD = 16   /* C = alpha * result * act'(Y): `bias` then points to Y = the activation OUTPUT of the layer
+                          being differentiated, [batch, M, N] contiguous (sBias = M*N or 0), and `act` names the
+                          activation: y(1-y), [y > 0], 1-y^2.  The MLP backward's "dx GEMM, then activation-gradient
+                          pass" in one launch; beta must be 0 and no other flag may be set */
 };
 enum { HB_ACT_NONE = 0, HB_ACT_SIGMOID = 1, HB_ACT_RELU = 2, HB_ACT_TANH = 3 };
 /* C[b] = act(alpha * op(A[b]) op(B[b]) + bias[b]) + beta * C[b], op = transpose if trans?.

@@ -110,10 +110,15 @@ def evaluate(outputs, leaf_values, noise=None):
             a = a.transpose(-1, -2) if at["ta"] else a
             b = b.transpose(-1, -2) if at["tb"] else b
             y = a @ b
-            if len(ins) > 2:
+            if at.get("actgrad"):
+                yy = ins[2]
+                d = {"sigmoid": yy * (1 - yy), "relu": (yy > 0).to(DT), "tanh": 1 - yy * yy}[at["actgrad"]]
+                outs = [y * d]
+            elif len(ins) > 2:
                 y = y + ins[2].reshape(ins[2].shape[:-2] + (1, ins[2].shape[-1])) if ins[2].dim() >= 2 else y + ins[2]
-            y = {"none": lambda v: v, "sigmoid": torch.sigmoid, "relu": torch.relu, "tanh": torch.tanh}[at["act"]](y)
-            outs = [y]
+            if not at.get("actgrad"):
+                y = {"none": lambda v: v, "sigmoid": torch.sigmoid, "relu": torch.relu, "tanh": torch.tanh}[at["act"]](y)
+                outs = [y]
         elif op == "matutil":
             x = ins[0]
             m = at["mode"]

@@ -170,6 +170,38 @@ def test_vjp_shape_ops():
     _check_vjp(lambda x: G.diag_part(x), [(2, 4, 4)])
 
 
+def test_vjp_slices_that_tile_their_source_pack_into_a_concat():
+    # mean / log-std halves of an encoder output (reference variationals.py:70-80): the summed slice gradients
+    # are emitted as ONE concat, not zero-filled scatters added together -- and stay correct
+    def halves(x):
+        return G.unary("EXP", x[:, 3:]) * 2.0 + G.unary("TANH", x[:, :3])
+
+    _check_vjp(halves, [(5, 6)])
+    x = G.leaf("data", (5, 6), var=None)
+    g = G.gradients(G.reduce_sum(halves(x)), [x])[0]
+    assert g.node.op == "concat" and not any(n.op == "scatter_strided" for n in G.topo_order([g]))
+    # three parts, given out of order; and a partial cover, which must NOT be packed
+    _check_vjp(lambda x: G.reduce_sum(x[:, 4:] * 3.0, 1) + G.reduce_sum(x[:, :1], 1) * G.reduce_sum(G.unary("EXP", x[:, 1:4]), 1), [(4, 6)])
+    y = G.leaf("data", (4, 6), var=None)
+    g = G.gradients(G.reduce_sum(y[:, :2] * 2.0) + G.reduce_sum(y[:, 3:] * 3.0), [y])[0]
+    assert g.node.op != "concat"
+    _check_vjp(lambda x: G.reduce_sum(x[:, :2] * 2.0, 1) + G.reduce_sum(x[:, 3:] * 3.0, 1), [(4, 6)])
+
+
+def test_mlp_backward_fuses_the_activation_gradient_into_the_dx_gemm():
+    x, w1, b1, w2 = [G.leaf("data", s, var=None) for s in ((7, 4), (4, 5), (1, 5), (5, 3))]
+
+    def net(x, w1, b1, w2):
+        return G.matmul(G.matmul(x, w1, bias=b1, act="sigmoid"), w2)
+
+    for act in ("sigmoid", "tanh", "relu"):
+        _check_vjp(lambda x, w1, b1, w2, act=act: G.matmul(G.matmul(x, w1, bias=b1, act=act), w2), [(7, 4), (4, 5), (1, 5), (5, 3)])
+    gs = G.gradients(G.reduce_sum(G.unary("SQUARE", net(x, w1, b1, w2))), [w1])
+    ops = [n for n in G.topo_order(gs)]
+    assert any(n.op == "matmul" and n.attrs.get("actgrad") == "sigmoid" for n in ops)
+    assert not any(n.op == "ew" and n.attrs["f"] == "SIGMOID_GRAD" for n in ops)
+
+
 def test_vjp_reductions_and_broadcast():
     _check_vjp(lambda x: G.reduce_sum(x, [0, 2]), [(3, 4, 5)])
     _check_vjp(lambda x: G.reduce_sum(x, 1, keepdims=True), [(3, 4, 5)])

@@ -299,6 +299,30 @@ def test_matmul_basic(H, p, tA, tB, shape):
     assert_close(H.matmul(dev(a, dt), dev(b, dt), transA=tA, transB=tB), exp, tol)
 
 
+@pytest.mark.parametrize("p", ["f32", "f64"])
+def test_matmul_activation_gradient_epilogue(H, p):
+    """dx GEMM with the activation derivative as its epilogue (direct, ragged, batched and split-K finish) ==
+    the two-pass form: the backward of the reference's MatBias + activation layer (nn.py:31-32,79-84)."""
+    dt = DT[p]
+    rng = np.random.RandomState(3)
+    tol = TOL[p] if p == "f64" else dict(rtol=2e-4, atol=2e-3)
+    dact = {"sigmoid": lambda y: y * (1 - y), "tanh": lambda y: 1 - y * y, "relu": lambda y: (y > 0).astype(y.dtype)}
+    for act in ("sigmoid", "tanh", "relu"):
+        for (m, n, k) in ((300, 70, 33), (256, 256, 32), (7, 5, 3)):
+            g, w = rng.randn(m, k), rng.randn(n, k)
+            y = rng.rand(m, n) if act != "relu" else np.maximum(rng.randn(m, n), 0)
+            got = H.matmul(dev(g, dt), dev(w, dt), transB=True, act=act, actgrad=dev(y, dt))
+            assert_close(got, (g @ w.T) * dact[act](y), tol)
+    # batched, and the split-K finish path (few tiles, long contraction)
+    g, w, y = rng.randn(3, 40, 9), rng.randn(3, 9, 20), rng.rand(3, 40, 20)
+    assert_close(H.matmul(dev(g, dt), dev(w, dt), act="sigmoid", actgrad=dev(y, dt), alpha=0.5), 0.5 * (g @ w) * y * (1 - y), tol)
+    g, w, y = rng.randn(30, 6000), rng.randn(6000, 50), rng.rand(30, 50)
+    assert_close(H.matmul(dev(g, dt), dev(w, dt), act="tanh", actgrad=dev(y, dt)), (g @ w) * (1 - y * y),
+                 TOL[p] if p == "f64" else dict(rtol=1e-3, atol=2e-2))
+    with pytest.raises(ValueError):
+        H.matmul(dev(g, dt), dev(w, dt), act="tanh", actgrad=dev(y, dt), bias=dev(rng.randn(50), dt))
+
+
 def test_matmul_asymmetric_identity(H):
     # A = I with an ASYMMETRIC B catches a swapped accumulator row/col map
     for dt in (torch.float32, torch.float64):
