@@ -207,7 +207,7 @@ extern "C" int hb_ewise_f64(int op, int nin, const void* const* in, const long* 
 // into a handful matters more than per-element speed.
 // ---------------------------------------------------------------------------
 #define HB_PROG_MAX_INSTR 48
-#define HB_PROG_MAX_IN 8
+#define HB_PROG_MAX_IN 12
 #define HB_PROG_MAX_OUT 6
 #define HB_PROG_MAX_DIMS 4
 #define HB_PROG_MAX_REGS 40

@@ -1444,7 +1444,7 @@ def gradients(loss: Tensor, wrt: Sequence[Tensor]) -> List[Optional[Tensor]]:
 # ------------------------------------------------------------------------------
 EW_CLUSTER_MAX_ELEMS = 1 << 16   # larger tensors keep one specialised launch per op
 EW_CLUSTER_MAX_INSTR = 44
-EW_CLUSTER_MAX_IN = 8
+EW_CLUSTER_MAX_IN = 12
 EW_CLUSTER_MAX_OUT = 6
 EW_CLUSTER_MAX_REGS = 38
 
