@@ -858,6 +858,49 @@ __global__ void __launch_bounds__(256) gauss_ll_finish_kernel(const T* __restric
     dvar[0] = a2;
   }
 }
+// n <= HB_GLL_SINGLE_N: one 1024-thread workgroup does the whole head, sums included (a second launch costs more
+// than streaming 16 elements per thread from one CU); every load of a thread is in flight before the first use
+#define HB_GLL_SINGLE_N 16384
+template <typename T>
+__global__ void __launch_bounds__(1024) gauss_ll_single_kernel(const T* __restrict__ x, const T* __restrict__ f,
+                                                               const T* __restrict__ scale, const T* __restrict__ var,
+                                                               long n, T* __restrict__ dmu, T* __restrict__ ll,
+                                                               T* __restrict__ dscale, T* __restrict__ dvar) {
+  __shared__ T smem[16];
+  constexpr int PER = HB_GLL_SINGLE_N / 1024;
+  const T s = scale ? scale[0] : T(1), v = var[0];
+  const T iv = T(1) / v, lc = T(-0.91893853320467274178) - T(0.5) * hb_log(v);
+  T xv[PER], fv[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const long j = q * 1024 + threadIdx.x;
+    const long jc = j < n ? j : n - 1;
+    xv[q] = x[jc];
+    fv[q] = f[jc];
+  }
+  T all = T(0), asc = T(0), avr = T(0);
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const long j = q * 1024 + threadIdx.x;
+    const T dlt = xv[q] - fv[q] * s;
+    const T g = dlt * iv;
+    if (j < n) {
+      dmu[j] = g;
+      all += lc - T(0.5) * dlt * g;
+      asc += g * fv[q];
+      avr += T(-0.5) * iv + T(0.5) * g * g;
+    }
+  }
+  all = block_sum(all, smem);
+  asc = block_sum(asc, smem);
+  avr = block_sum(avr, smem);
+  if (threadIdx.x == 0) {
+    ll[0] = all;
+    dscale[0] = asc;
+    dvar[0] = avr;
+  }
+}
+
 template <typename T>
 static int gauss_ll(const T* x, const T* f, const T* scale, const T* var, long n, T* ll, T* dmu, T* dscale, T* dvar,
                     T* ws, long ws_elems, hipStream_t stream) {
@@ -865,6 +908,12 @@ static int gauss_ll(const T* x, const T* f, const T* scale, const T* var, long n
   const int nb = n > 0 ? hb_cdiv(n, HB_GLL_BLOCK_ELEMS) : 0;
   HB_REQUIRE(ws_elems >= 3L * (nb > 0 ? nb : 1), "hb_gauss_ll: workspace of 3*ceil(n/%d) elements required",
              HB_GLL_BLOCK_ELEMS);
+  if (n > 0 && n <= HB_GLL_SINGLE_N) {
+    hipLaunchKernelGGL(gauss_ll_single_kernel<T>, dim3(1), dim3(1024), 0, stream, x, f, scale, var, n, dmu, ll, dscale,
+                       dvar);
+    HB_LAUNCH_CHECK();
+    return 0;
+  }
   if (nb > 0) {
     hipLaunchKernelGGL(gauss_ll_kernel<T>, dim3(nb), dim3(256), 0, stream, x, f, scale, var, n, dmu, ws);
     HB_LAUNCH_CHECK();

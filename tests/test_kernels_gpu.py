@@ -724,7 +724,7 @@ def test_gather_rows_multi(H, p):
 
 
 @pytest.mark.parametrize("p", ["f32", "f64"])
-@pytest.mark.parametrize("n,scaled", [(1, True), (1000, True), (8192, False), (5001, True)])
+@pytest.mark.parametrize("n,scaled", [(1, True), (1000, True), (8192, False), (5001, True), (16384, True), (16385, False), (100003, True)])
 def test_gauss_ll_fused(H, p, n, scaled):
     """hb_gauss_ll: sum of log N(x | f*scale, var) and the pieces of its gradient == the oracle's density + autograd."""
     dt = DT[p]
