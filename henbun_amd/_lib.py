@@ -50,6 +50,7 @@ _TYPED = {
     "hb_fill": [P, L, D, P],
     "hb_gather_rows": [P, L, L, P, P, L, P, P, P],
     "hb_gather_rows_multi": [I, P, P, P, L, P, P, L, P, P],
+    "hb_gather_rows_multi_draw": [I, P, P, P, L, P, L, L, L, P, P, L, P, P],
     "hb_matutil": [P, P, L, L, L, I, L, L, D, P],
     "hb_rng_normal": [P, L, P, L, P],
     "hb_diag_sample_kl_fwd": [P, P, P, P, L, P, P, P, L, P, P],

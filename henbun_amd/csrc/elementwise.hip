@@ -5,6 +5,7 @@
 // per step; they are launch-bound at the sizes on the path and
 // are written for correctness + coalescing, not for a roofline.
 #include "common.cuh"
+#include "rng_pairs.cuh"
 #include <string.h>
 #include "../../include/henbun_hip.h"
 
@@ -794,6 +795,93 @@ extern "C" int hb_gather_rows_multi_f32(int narr, const float* const* srcs, cons
 extern "C" int hb_gather_rows_multi_f64(int narr, const double* const* srcs, const long* rows, double* const* dsts,
                                         long nsrc, const long* idx, const long* perm, long n, int* err, void* stream) {
   return gather_rows_multi<double>(narr, srcs, rows, dsts, nsrc, idx, perm, n, err, (hipStream_t)stream);
+}
+
+// The minibatch draw and the gather in one launch (n <= nlanes): G threads per row; the group's first thread owns
+// RNG lane r -- it draws idx[r] exactly as rng_randint_kernel does (one value per lane, state advanced once), stores
+// it for inspection, and hands it to the group, which then copies row perm[idx[r]] of every array.
+template <typename T, int G>
+__global__ void __launch_bounds__(256) gather_rows_multi_draw_kernel(GatherMultiArgs<T> g, uint64_t* __restrict__ state,
+                                                                     long nlanes, long lo, uint64_t range,
+                                                                     long* __restrict__ idx_out,
+                                                                     const long* __restrict__ perm, long n, long nsrc,
+                                                                     int* __restrict__ err) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r = t / G;
+  const int sub = (int)(t % G);
+  long j = 0;
+  if (sub == 0 && r < n) {
+    HbRng rg = rng_load(state, nlanes, r);
+    j = lo + (long)__umul64hi(rg.next(), range);
+    rng_store(state, nlanes, r, rg);
+    idx_out[r] = j;
+  }
+  if (G > 1) {
+    // the leader is lane (lane - sub) of the same wave (G divides 64)
+    const int leader = (threadIdx.x & 63) - sub;
+    const int jl = __shfl((int)(j & 0xffffffffL), leader), jh = __shfl((int)(j >> 32), leader);
+    j = ((long)jh << 32) | (unsigned int)jl;
+  }
+  if (r >= n) return;
+  if (perm) j = perm[j];
+  const bool bad = j < 0 || j >= nsrc;
+  if (bad && sub == 0 && err) *err = 1;
+#pragma unroll
+  for (int a = 0; a < HB_GATHER_MAX; ++a) {
+    if (a >= g.narr) break;
+    const long w = g.row[a];
+    for (long c = sub; c < w; c += G) g.dst[a][r * w + c] = bad ? T(0) : g.src[a][j * w + c];
+  }
+}
+template <typename T>
+static int gather_rows_multi_draw(int narr, const T* const* srcs, const long* rows, T* const* dsts, long nsrc,
+                                  uint64_t* state, long nlanes, long lo, long hi, long* idx_out, const long* perm,
+                                  long n, int* err, hipStream_t stream) {
+  HB_REQUIRE(narr >= 1 && narr <= HB_GATHER_MAX, "hb_gather_rows_multi_draw: %d arrays (max %d)", narr, HB_GATHER_MAX);
+  HB_REQUIRE(n >= 0 && nsrc >= 0 && srcs && rows && dsts && state && idx_out, "hb_gather_rows_multi_draw: bad arguments");
+  HB_REQUIRE(n <= nlanes, "hb_gather_rows_multi_draw: n=%ld exceeds the %ld RNG lanes (draw with hb_rng_randint instead)", n,
+             nlanes);
+  HB_REQUIRE(hi > lo, "hb_gather_rows_multi_draw: empty range [%ld,%ld)", lo, hi);
+  GatherMultiArgs<T> g;
+  g.narr = narr;
+  g.start[0] = 0;
+  long wmax = 1;
+  for (int a = 0; a < HB_GATHER_MAX; ++a) {
+    g.src[a] = a < narr ? srcs[a] : nullptr;
+    g.dst[a] = a < narr ? dsts[a] : nullptr;
+    g.row[a] = a < narr ? rows[a] : 1;
+    if (a < narr) HB_REQUIRE(rows[a] >= 1 && srcs[a] && dsts[a], "hb_gather_rows_multi_draw: bad array %d", a);
+    if (a < narr && rows[a] > wmax) wmax = rows[a];
+    g.start[a + 1] = g.start[a] + (a < narr ? n * rows[a] : 0);
+  }
+  if (n == 0) return 0;
+  const uint64_t range = (uint64_t)(hi - lo);
+#define HB_GDRAW(G_)                                                                                                   \
+  hipLaunchKernelGGL((gather_rows_multi_draw_kernel<T, G_>), dim3((unsigned)hb_cdiv(n * G_, 256)), dim3(256), 0, stream, g, \
+                     state, nlanes, lo, range, idx_out, perm, n, nsrc, err)
+  if (wmax <= 2)
+    HB_GDRAW(1);
+  else if (wmax <= 8)
+    HB_GDRAW(4);
+  else if (wmax <= 32)
+    HB_GDRAW(16);
+  else
+    HB_GDRAW(64);
+#undef HB_GDRAW
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_gather_rows_multi_draw_f32(int narr, const float* const* srcs, const long* rows, float* const* dsts,
+                                             long nsrc, uint64_t* state, long nlanes, long lo, long hi, long* idx_out,
+                                             const long* perm, long n, int* err, void* stream) {
+  return gather_rows_multi_draw<float>(narr, srcs, rows, dsts, nsrc, state, nlanes, lo, hi, idx_out, perm, n, err,
+                                       (hipStream_t)stream);
+}
+extern "C" int hb_gather_rows_multi_draw_f64(int narr, const double* const* srcs, const long* rows, double* const* dsts,
+                                             long nsrc, uint64_t* state, long nlanes, long lo, long hi, long* idx_out,
+                                             const long* perm, long n, int* err, void* stream) {
+  return gather_rows_multi_draw<double>(narr, srcs, rows, dsts, nsrc, state, nlanes, lo, hi, idx_out, perm, n, err,
+                                        (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -279,6 +279,12 @@ class MultiGather:
         _lib.lib().call("hb_gather_rows_multi" + self.suf, self.narr, self.srcs, self.rows, self.dsts, self.nsrc,
                         _p(self.idx), _p(self.perm if use_perm else None), self.n, _p(self.err), stream())
 
+    def launch_draw(self, rng, lo, hi, use_perm=True):
+        """draw idx ~ U{lo..hi-1} from `rng` (as rng.randint would) and gather, in one launch; needs n <= rng.nlanes"""
+        _lib.lib().call("hb_gather_rows_multi_draw" + self.suf, self.narr, self.srcs, self.rows, self.dsts, self.nsrc,
+                        _p(rng.state), rng.nlanes, int(lo), int(hi), _p(self.idx), _p(self.perm if use_perm else None),
+                        self.n, _p(self.err), stream())
+
 
 def matutil(x, mode, lower=-1, upper=-1, alpha=0.0, out=None):
     _chk(x)

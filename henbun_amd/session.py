@@ -234,9 +234,15 @@ class Session:
                         plan.index_buffer = idx
                         plan.index_range = hi
                         if str(settings.runtime.index_source) == "device":
+                            feeder["draw"] = (rng, hi)
+
                             def draw():
-                                if not plan.indices_injected:
+                                # once the multi-array gather exists it draws the indices itself (same values, same
+                                # RNG state: one launch instead of two)
+                                feeder["drawn"] = False
+                                if not plan.indices_injected and not (feeder.get("mg") and n <= rng.nlanes):
                                     rng.randint(n, 0, hi, out=idx)
+                                    feeder["drawn"] = True
                             plan.steps.append(draw)
                     idx, perm, err = feeder["idx"], feeder["perm"], feeder["err"]
                     H = sess.H
@@ -254,7 +260,11 @@ class Session:
                                     mg = feeder["mg"] = H.MultiGather(srcs, outs, idx, perm, err)
                                 else:
                                     mg = feeder["mg"] = False
-                            if mg:
+                            fused = (mg and feeder.get("draw") and not feeder.get("drawn") and not plan.indices_injected
+                                     and n <= feeder["draw"][0].nlanes)
+                            if fused:
+                                mg.launch_draw(feeder["draw"][0], 0, feeder["draw"][1], use_perm=not plan.indices_raw)
+                            elif mg:
                                 mg.launch(use_perm=not plan.indices_raw)
                             else:
                                 for a, o in feeder["arrays"]:

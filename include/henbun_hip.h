@@ -153,6 +153,17 @@ int hb_gather_rows_multi_f32(int narr, const float* const* srcs, const long* row
 int hb_gather_rows_multi_f64(int narr, const double* const* srcs, const long* rows, double* const* dsts,
                              long nsrc, const long* idx, const long* perm, long n, int* err, void* stream);
 
+/* The minibatch draw and that gather in ONE launch: idx[i] ~ U{lo..hi-1} is drawn from RNG lane i exactly as
+ * hb_rng_randint(state, nlanes, idx_out, n, lo, hi) would (same values, same state afterwards; n <= nlanes), written
+ * to idx_out, and row perm[idx[i]] of every array is gathered.  Replaces Indexer.train_index + the feed of every
+ * MinibatchData (reference param.py:715-739) per step. */
+int hb_gather_rows_multi_draw_f32(int narr, const float* const* srcs, const long* rows, float* const* dsts,
+                                  long nsrc, uint64_t* state, long nlanes, long lo, long hi, long* idx_out,
+                                  const long* perm, long n, int* err, void* stream);
+int hb_gather_rows_multi_draw_f64(int narr, const double* const* srcs, const long* rows, double* const* dsts,
+                                  long nsrc, uint64_t* state, long nlanes, long lo, long hi, long* idx_out,
+                                  const long* perm, long n, int* err, void* stream);
+
 /* batched [B,R,C] matrix utilities.  mode 0 = tf.matrix_band_part(lower,upper)
  * (reference variationals.py:145); 1 = + alpha*I (kernels.py:100 jitter);
  * 2 = Phi (lower triangle, halved diagonal) of the Cholesky gradient;

@@ -724,6 +724,45 @@ def test_gather_rows_multi(H, p):
 
 
 @pytest.mark.parametrize("p", ["f32", "f64"])
+@pytest.mark.parametrize("widths", [(1, 1), (1, 5, 6), (64,), (20, 3)])
+def test_gather_rows_multi_with_in_kernel_draw(H, p, widths):
+    """Index draw + gather in one launch == hb_rng_randint followed by the gather: same indices, same rows, same
+    RNG state afterwards (so a plan may switch between the two forms freely)."""
+    dt = DT[p]
+    rng = np.random.RandomState(11)
+    N, n, hi = 300, 257, 250
+    srcs = [rng.randn(N, w) for w in widths]
+    perm = rng.permutation(N)[:hi]
+    dsrc = [dev(s, dt) for s in srcs]
+    dp = torch.as_tensor(perm).cuda()
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    # reference: two launches
+    r1 = H.Rng(seed=5, stream_id=2, nlanes=512)
+    idx1 = torch.zeros(n, dtype=torch.int64, device="cuda")
+    outs1 = [torch.empty((n, w), dtype=dt, device="cuda") for w in widths]
+    r1.randint(n, 0, hi, out=idx1)
+    H.MultiGather(dsrc, outs1, idx1, dp, err).launch()
+    # fused
+    r2 = H.Rng(seed=5, stream_id=2, nlanes=512)
+    idx2 = torch.zeros(n, dtype=torch.int64, device="cuda")
+    outs2 = [torch.empty((n, w), dtype=dt, device="cuda") for w in widths]
+    mg = H.MultiGather(dsrc, outs2, idx2, dp, err)
+    mg.launch_draw(r2, 0, hi)
+    assert torch.equal(idx1, idx2) and torch.equal(r1.state, r2.state)
+    for a, b, d in zip(outs1, outs2, dsrc):
+        assert torch.equal(a, b)
+        assert np.array_equal(host(b), host(d)[perm[host(idx2).astype(np.int64)]])
+    assert err.item() == 0 and 0 <= int(idx2.min()) and int(idx2.max()) < hi
+    # a second draw continues the stream; without the permutation the raw indices are used
+    r1.randint(n, 0, hi, out=idx1)
+    mg.launch_draw(r2, 0, hi, use_perm=False)
+    assert torch.equal(idx1, idx2) and torch.equal(r1.state, r2.state)
+    assert np.array_equal(host(outs2[0]), host(dsrc[0])[host(idx2).astype(np.int64)])
+    with pytest.raises(Exception, match="RNG lanes"):
+        H.MultiGather(dsrc, outs2, idx2, dp, err).launch_draw(H.Rng(seed=1, nlanes=128), 0, hi)
+
+
+@pytest.mark.parametrize("p", ["f32", "f64"])
 @pytest.mark.parametrize("n,scaled", [(1, True), (1000, True), (8192, False), (5001, True), (16384, True), (16385, False), (100003, True)])
 def test_gauss_ll_fused(H, p, n, scaled):
     """hb_gauss_ll: sum of log N(x | f*scale, var) and the pieces of its gradient == the oracle's density + autograd."""
