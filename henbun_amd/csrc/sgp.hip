@@ -331,6 +331,10 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
 #ifndef HB_SSTAMP
 #define HB_SSTAMP(i)
 #endif
+// Ablation switches of the same diagnostic build (0 in the product): 1 = no MFMAs, 2 = no W loads inside the loop
+#ifndef HB_STRIP_ABLATE
+#define HB_STRIP_ABLATE 0
+#endif
 #define SGP_SN 32
 #define SGP_SM_MAX 512
 #define SGP_SLD (SGP_SM_MAX + 4)
@@ -473,7 +477,7 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
     for (int j = P; j < 4; ++j)
 #pragma unroll
       for (int v = 0; v < 4; ++v) ac[j][v] = an[j][v];
-    if (Q + 1 < dep[3]) load_a(Q + 1, pc);  // prefetch (a tile that finishes now re-reads its last step: harmless)
+    if (!(HB_STRIP_ABLATE & 2) && Q + 1 < dep[3]) load_a(Q + 1, pc);  // prefetch (a tile that finishes now re-reads its last step: harmless)
     V4 bv[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) bv[v] = *reinterpret_cast<const V4*>(&Ks[li][32 * Q + 16 * h + 4 * v]);
@@ -490,7 +494,12 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int j = P; j < 4; ++j) acc[j] = MM::mma(ac[j][v][s], bv[v][s], acc[j]);
+        for (int j = P; j < 4; ++j) {
+          if (HB_STRIP_ABLATE & 1)
+            asm volatile("" ::"v"(ac[j][v][s]), "v"(bv[v][s]));
+          else
+            acc[j] = MM::mma(ac[j][v][s], bv[v][s], acc[j]);
+        }
   };
   auto phase = [&](int q0, auto pc) {
     constexpr int P = decltype(pc)::value;
