@@ -121,11 +121,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    # rehearsal switches (not used by the driver): HENBUN_DIST_BACKEND=gloo + HENBUN_ONE_DEVICE=1 run the N > 1 code
+    # path with every rank on cuda:0 of a one-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("HENBUN_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("HENBUN_ONE_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 

@@ -504,6 +504,7 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
   constexpr int VEC = 16 / (int)sizeof(T);
   typedef T VT __attribute__((ext_vector_type(VEC)));
   __shared__ __attribute__((aligned(16))) T Cs[CR_ROWS][CR_LD];
+  __shared__ __attribute__((aligned(16))) T Dg[8][8];  // snapshot of the step's 8x8 diagonal sub-block (see chol_rl64_kernel)
 
   const long boff = (long)blockIdx.y * M * M;
   Ain += boff;
@@ -656,6 +657,7 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
             T v = acc[si][sj][r];
             if (!FAST && w == 0 && (tr >= nb || tc >= nb)) v = (tr == tc) ? T(1) : T(0);  // identity padding
             Cs[w * CR_B + tr][tc] = v;
+            if (((w * CR_B + tr) >> 3) == kb) Dg[(w * CR_B + tr) & 7][tc & 7] = v;
           }
         }
       }
@@ -675,7 +677,7 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int q = 0; q < 8; q += VEC) {
-            const VT v = *reinterpret_cast<const VT*>(&Cs[8 * kb + i][8 * kb + q]);
+            const VT v = *reinterpret_cast<const VT*>(&Dg[i][q]);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) p[i][q + e] = v[e];
           }
@@ -842,6 +844,10 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
   constexpr int CK = 32;  // contraction entries per lane in the rank-64 update (128 bytes)
   __shared__ __attribute__((aligned(16))) T Cs[C64_ROWS][C64_LD];
   __shared__ __attribute__((aligned(16))) T Bs[C64_NB][C64_LD];  // panel rows of the column block (rank-64 update)
+  // Snapshot of the 8x8 diagonal sub-block of the current in-panel step.  potrf8 must not read it from Cs: the
+  // threads that own rows 8kb..8kb+7 write their SOLVED rows back to exactly those Cs entries with no barrier in
+  // between, so a wave that runs late (a shared GPU, a context switch) would factor a half-overwritten block.
+  __shared__ __attribute__((aligned(16))) T Dg[8][8];
 
   const long boff = (long)blockIdx.y * M * M;
   Ain += boff;
@@ -972,6 +978,15 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
       if ((li >> 3) == (kb & 3)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) Cs[w * 32 + MM::acc_row(lane, r)][sj * 32 + li] = sj == 0 ? acc[0][r] : acc[1][r];
+        // rows 8kb..8kb+7 live in wave kb/4, accumulator rows 8(kb%4) + 4h + (0..3) of its tile
+        if (w == sj) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * (kb & 3) + rr;
+            static_assert(Mma<float>::NACC == 16, "32x32 accumulator layout");
+            Dg[4 * h + rr][li & 7] = sj == 0 ? acc[0][r] : acc[1][r];
+          }
+        }
       }
     }
     __syncthreads();
@@ -986,7 +1001,7 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int q = 0; q < 8; q += 4) {
-            const VT v = *reinterpret_cast<const VT*>(&Cs[8 * kb + i][8 * kb + q]);
+            const VT v = *reinterpret_cast<const VT*>(&Dg[i][q]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) p[i][q + e] = v[e];
           }

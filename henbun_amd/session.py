@@ -77,7 +77,11 @@ class Session:
         if self._device_arg is not None:
             self.device = torch.device(self._device_arg)
         else:
-            self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", torch.cuda.current_device())))
+            # one process per GPU: LOCAL_RANK names the card (HENBUN_ONE_DEVICE=1: rehearsal of the multi-rank path
+            # with every rank on the current device of a one-GPU box)
+            one = os.environ.get("HENBUN_ONE_DEVICE")
+            self.device = torch.device("cuda", torch.cuda.current_device() if one else
+                                       int(os.environ.get("LOCAL_RANK", torch.cuda.current_device())))
         torch.cuda.set_device(self.device)
         self.torch_dtype = torch.float64 if self.np_dtype == np.float64 else torch.float32
         if torch.distributed.is_available() and torch.distributed.is_initialized():

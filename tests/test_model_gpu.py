@@ -355,3 +355,21 @@ def test_cfg2_full_size_properties_fp32():
     assert np.abs(v.double().cpu().numpy() - vd).max() < 1e-4
     fd = u.double().cpu().numpy() @ Ad + np.sqrt(np.abs(vd)) * eps.double().cpu().numpy()
     assert np.abs(f.double().cpu().numpy() - fd).max() < 2e-3
+
+
+def test_replay_is_bitwise_deterministic_when_the_gpu_is_shared():
+    """Two processes replay the cfg-2 step graph on the same GPU at the same time; with the RNG rewound every replay
+    must reproduce the flat gradient bit for bit.  Contention makes the waves of a workgroup drift apart, which
+    exposes LDS hazards that never show on an idle GPU (regression: the Cholesky in-panel step read its 8x8 diagonal
+    sub-block from rows other threads were already overwriting: ~3 % of replays went NaN)."""
+    import subprocess
+    import sys as _sys
+
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "replay_determinism.py")
+    procs = [subprocess.Popen([_sys.executable, tool, "4", "proc%d" % i], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for i in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out[-2000:]
+        tail = [ln for ln in out.splitlines() if "replays" in ln]
+        assert tail and tail[-1].strip().endswith(" 0 differ"), out[-2000:]
