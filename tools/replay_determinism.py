@@ -1,5 +1,5 @@
 """Replay the cfg-2 forward+backward hipGraph with the RNG streams rewound before every replay and compare the
-flat gradient bitwise: `python tools/replay_determinism.py <seconds> <tag>`.  Run two or three copies at once on one
+flat gradient bitwise: `python tools/replay_determinism.py <seconds> <tag> [cfg2|cfg2_f64|cfg3|cfg3_f64|cfg4|cfg5|ragged_f64]`.  Run two or three copies at once on one
 GPU to put the kernels under contention (waves of a workgroup then drift apart by thousands of cycles): that is how
 the missing-barrier hazard in the Cholesky in-panel step was found (3 % of replays went NaN; 0 after the fix).
 On a mismatch the first non-finite plan buffers are listed in topological order."""
@@ -8,12 +8,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import henbun_amd as hb
-from models import SVGP, svgp_data
+from models import SVGP, Amortised, ExpertsGPR, svgp_data
 tf = hb.tf
 np.random.seed(1234)
-M, n = 512, 8192
-X, Y, Z = svgp_data(200000, M, seed=0, domain=0.5 * M)
-m = SVGP(X=X, Y=Y, Z=Z, dtype="float32", seed=0)
+cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg2"   # cfg2 | cfg2_f64 | cfg3 | cfg3_f64 | cfg4 | cfg5 | ragged_f64
+rng0 = np.random.RandomState(0)
+if cfg in ("cfg2", "cfg2_f64"):
+    M, n = 512, 8192
+    X, Y, Z = svgp_data(200000, M, seed=0, domain=0.5 * M)
+    m = SVGP(X=X, Y=Y, Z=Z, q_shape="diagonal", dtype="float64" if cfg.endswith("f64") else "float32", seed=0)
+elif cfg in ("cfg3", "cfg3_f64"):
+    M, n = (1024, 16384) if cfg == "cfg3" else (512, 4096)
+    X, Y, Z = svgp_data(100000, M, seed=0, domain=0.5 * M)
+    m = SVGP(X=X, Y=Y, Z=Z, q_shape="fullrank", dtype="float64" if cfg.endswith("f64") else "float32", seed=0)
+    m.u.q_sqrt = 0.1 * np.eye(M) + 0.01 * np.tril(rng0.randn(M, M))
+elif cfg == "ragged_f64":
+    M, n = 200, 3001   # ragged sizes: 32-column Cholesky with identity padding, scalar GEMM paths
+    X, Y, Z = svgp_data(20000, M, seed=0, domain=0.5 * M)
+    m = SVGP(X=X, Y=Y, Z=Z, q_shape="fullrank", dtype="float64", seed=0)
+    m.u.q_sqrt = 0.1 * np.eye(M) + 0.01 * np.tril(rng0.randn(M, M))
+elif cfg == "cfg4":
+    N, Din, H_, L_, n = 200000, 64, 256, 16, 32768
+    Z0 = rng0.randn(N, L_).astype(np.float32)
+    Yd = np.tanh(Z0 @ (rng0.randn(L_, Din).astype(np.float32) / np.sqrt(L_))) + 0.1 * rng0.randn(N, Din).astype(np.float32)
+    m = Amortised(Y=Yd, L=L_, H=H_, dtype="float32")
+elif cfg == "cfg5":
+    E, M, n = 4, 512, 16384
+    X, Y, Z = svgp_data(200000, M, 0, domain=512.0)
+    ells = list(np.linspace(0.6, 1.2, E)) + list(np.linspace(0.8, 1.4, E))
+    m = ExpertsGPR(X=X, Y=Y, Z=Z, ells=ells, dtype="float32")
+else:
+    raise SystemExit("unknown config " + cfg)
 opt = m.ELBO()
 m.initialize()
 sess = m._session
@@ -58,4 +83,4 @@ while time.time() - t0 < float(sys.argv[1]):
                 if shown >= 3:
                     break
     it += 1
-print("%s: %d replays, %d differ" % (sys.argv[2], it, bad), flush=True)
+print("%s %s: %d replays, %d differ" % (sys.argv[2], cfg, it, bad), flush=True)
