@@ -46,7 +46,10 @@ struct TileGemm {
   // A k-contiguous operand (HB_KC, vector path) is staged row-major [m][LDK] instead of k-major [kk][LDA]:
   // its 16-byte global groups go to LDS with ONE ds_write_b128 and a lane's fragments of a whole k-step
   // are NS consecutive elements = NS/VEC ds_read_b128 (the k-major form needs NS ds_read_b32).
-  static constexpr int LDK = BK + 4;
+#ifndef HB_LDK_PAD
+#define HB_LDK_PAD 4  // (8 and 12 measured no better: tools/kloop_cycles.hip with -DHB_LDK_PAD=...)
+#endif
+  static constexpr int LDK = BK + HB_LDK_PAD;
   static constexpr int A_ELEMS = (BM * LDK > BK * LDA) ? BM * LDK : BK * LDA;
   static constexpr int B_ELEMS = (BN * LDK > BK * LDB) ? BN * LDK : BK * LDB;
   static constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;  // one LDS buffer
