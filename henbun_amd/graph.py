@@ -1850,13 +1850,16 @@ class Plan:
 
     def check(self):
         """Synchronise and raise if any Cholesky in the plan failed."""
-        self.torch.cuda.synchronize()
+        if self.stream is not None:
+            self.stream.synchronize()
+        else:
+            self.torch.cuda.synchronize()
         for info, label in self._infos:
-            bad = info.nonzero()
-            if bad.numel():
-                k = int(info[bad[0, 0]].item())
+            host = info.cpu().numpy().reshape(-1)  # one small copy: `nonzero()` costs a launch and a second sync
+            bad = np.flatnonzero(host)
+            if bad.size:
                 raise CholeskyError("%s: leading minor %d is not positive definite (matrix %d)"
-                                    % (label, k, int(bad[0, 0].item())))
+                                    % (label, int(host[bad[0]]), int(bad[0])))
 
     def value(self, t: Tensor):
         return self.buf(t).detach().cpu().numpy()

@@ -317,6 +317,16 @@ class _SessionPlan(G.Plan):
         if changed:
             self._graph = None
 
+    def check(self):
+        """Cholesky status (G.Plan.check) and, when the row indices came from the caller, their range: a row index
+        outside the data set makes the gather write zeros and raise its flag (device-drawn indices cannot be)."""
+        G.Plan.check(self)
+        err = getattr(self, "gather_err", None)
+        if err is not None and (self.indices_injected or self.host_indices):
+            if int(err.cpu().item()) != 0:
+                err.zero_()
+                raise IndexError("minibatch indices outside the data set (rows were zero-filled)")
+
     def run(self):
         if self.host_indices and self.index_buffer is not None and not self.indices_injected:
             index = self.session.model._index

@@ -373,3 +373,20 @@ def test_replay_is_bitwise_deterministic_when_the_gpu_is_shared():
         assert p.returncode == 0, out[-2000:]
         tail = [ln for ln in out.splitlines() if "replays" in ln]
         assert tail and tail[-1].strip().endswith(" 0 differ"), out[-2000:]
+
+
+def test_injected_indices_out_of_range_raise():
+    """A caller-supplied minibatch index outside the data set is an error, not silently zero-filled rows
+    (the reference would fail inside tf.gather / numpy indexing, param.py:733-739)."""
+    np.random.seed(0)
+    X, Y, Z = svgp_data(300, 16, seed=0)
+    m = SVGP(X=X, Y=Y, Z=Z, dtype="float64", seed=0)
+    opt = m.ELBO()
+    opt.compile(optimizer=tf.train.AdamOptimizer(1e-3))
+    good = np.arange(64)
+    assert np.isfinite(opt.run(minibatch_size=64, indices=good))
+    bad = good.copy()
+    bad[3] = 300
+    with pytest.raises(IndexError):
+        opt.run(minibatch_size=64, indices=bad)
+    assert np.isfinite(opt.run(minibatch_size=64, indices=good))  # the flag is cleared by the failed call
