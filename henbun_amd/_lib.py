@@ -53,8 +53,8 @@ _TYPED = {
     "hb_gather_rows_multi_draw": [I, P, P, P, L, P, L, L, L, P, P, L, P, P],
     "hb_matutil": [P, P, L, L, L, I, L, L, D, P],
     "hb_rng_normal": [P, L, P, L, P],
-    "hb_diag_sample_kl_fwd": [P, P, P, P, L, P, P, P, L, P, P],
-    "hb_diag_sample_kl_bwd": [P, P, P, P, P, P, P, L, P],
+    "hb_diag_sample_kl_fwd": [P, P, P, P, L, P, P, P, L, L, L, L, P, P],
+    "hb_diag_sample_kl_bwd": [P, P, P, P, P, P, P, L, L, L, L, P],
     "hb_fullrank_sample_kl_fwd": [P, P, P, P, L, P, P, P, L, L, P, P],
     "hb_fullrank_sample_kl_bwd": [P, P, P, P, P, P, P, L, L, P],
     "hb_gram_fwd": [I, P, L, P, L, P, L, L, P, L, L, L, L, D, P],

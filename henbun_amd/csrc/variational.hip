@@ -17,8 +17,17 @@ template <typename T>
 __global__ void __launch_bounds__(256) diag_fwd_kernel(const T* __restrict__ mu, const T* __restrict__ s,
                                                        const T* __restrict__ u_in, uint64_t* rng, long rng_lanes,
                                                        T* __restrict__ u_out, T* __restrict__ x,
-                                                       T* __restrict__ partial, T* __restrict__ kl, long n) {
+                                                       T* __restrict__ partial, T* __restrict__ kl, long n, long L,
+                                                       long ldm, long lds_) {
   __shared__ T smem[16];
+  // element i = (row i / L, column i % L); mu / s may be column blocks of a wider row-major matrix (row strides ldm,
+  // lds_: the mean and log-std halves of an encoder output, read in place); x and u are dense
+  const bool dense = ldm == L && lds_ == L;
+  auto src = [&](long i, long ld) -> long {
+    if (dense) return i;
+    const long r = i / L;
+    return r * ld + (i - r * L);
+  };
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nthreads = rng ? rng_lanes : (long)gridDim.x * blockDim.x;
   const long npairs = (n + 1) / 2;
@@ -40,15 +49,15 @@ __global__ void __launch_bounds__(256) diag_fwd_kernel(const T* __restrict__ mu,
         if (i1 < n) u1 = u_in[i1];
       }
       {
-        const T sv = s[i0];
-        const T xv = mu[i0] + hb_exp(sv) * u0;
+        const T sv = s[src(i0, lds_)];
+        const T xv = mu[src(i0, ldm)] + hb_exp(sv) * u0;
         x[i0] = xv;
         if (u_out) u_out[i0] = u0;
         acc += T(2) * sv + u0 * u0 - xv * xv;
       }
       if (i1 < n) {
-        const T sv = s[i1];
-        const T xv = mu[i1] + hb_exp(sv) * u1;
+        const T sv = s[src(i1, lds_)];
+        const T xv = mu[src(i1, ldm)] + hb_exp(sv) * u1;
         x[i1] = xv;
         if (u_out) u_out[i1] = u1;
         acc += T(2) * sv + u1 * u1 - xv * xv;
@@ -76,8 +85,10 @@ __global__ void __launch_bounds__(256) kl_finish_kernel(const T* __restrict__ pa
 
 template <typename T>
 static int diag_fwd(const T* mu, const T* s, const T* u_in, uint64_t* rng, long rng_lanes, T* u_out, T* x, T* kl,
-                    long n, T* ws, hipStream_t stream) {
+                    long n, long L, long ldm, long lds_, T* ws, hipStream_t stream) {
   HB_REQUIRE(n >= 0, "hb_diag_sample_kl_fwd: n < 0");
+  HB_REQUIRE(L >= 1 && ldm >= L && lds_ >= L && n % L == 0, "hb_diag_sample_kl_fwd: bad row layout (L=%ld, ld=%ld/%ld, n=%ld)",
+             L, ldm, lds_, n);
   HB_REQUIRE(mu && s && x && kl && ws, "hb_diag_sample_kl_fwd: NULL pointer");
   HB_REQUIRE(u_in || (rng && rng_lanes > 0), "hb_diag_sample_kl_fwd: neither u_in nor rng given");
   if (u_in) rng = nullptr;  // injected noise wins
@@ -92,7 +103,7 @@ static int diag_fwd(const T* mu, const T* s, const T* u_in, uint64_t* rng, long 
   const int need = hb_cdiv((n + 1) / 2, 256);
   if (grid > need) grid = need > 0 ? need : 1;
   hipLaunchKernelGGL(diag_fwd_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, s, u_in, rng, rng_lanes, u_out, x, ws,
-                     kl, n);
+                     kl, n, L, ldm, lds_);
   HB_LAUNCH_CHECK();
   if (grid > 1) {
     hipLaunchKernelGGL(kl_finish_kernel<T>, dim3(1), dim3(256), 0, stream, ws, grid, kl);
@@ -102,48 +113,60 @@ static int diag_fwd(const T* mu, const T* s, const T* u_in, uint64_t* rng, long 
 }
 
 extern "C" int hb_diag_sample_kl_fwd_f32(const float* mu, const float* s, const float* u_in, uint64_t* rng,
-                                         long rng_lanes, float* u_out, float* x, float* kl, long n, float* ws,
-                                         void* stream) {
-  return diag_fwd<float>(mu, s, u_in, rng, rng_lanes, u_out, x, kl, n, ws, (hipStream_t)stream);
+                                         long rng_lanes, float* u_out, float* x, float* kl, long n, long L, long ld_mu,
+                                         long ld_s, float* ws, void* stream) {
+  return diag_fwd<float>(mu, s, u_in, rng, rng_lanes, u_out, x, kl, n, L, ld_mu, ld_s, ws, (hipStream_t)stream);
 }
 extern "C" int hb_diag_sample_kl_fwd_f64(const double* mu, const double* s, const double* u_in, uint64_t* rng,
-                                         long rng_lanes, double* u_out, double* x, double* kl, long n, double* ws,
-                                         void* stream) {
-  return diag_fwd<double>(mu, s, u_in, rng, rng_lanes, u_out, x, kl, n, ws, (hipStream_t)stream);
+                                         long rng_lanes, double* u_out, double* x, double* kl, long n, long L,
+                                         long ld_mu, long ld_s, double* ws, void* stream) {
+  return diag_fwd<double>(mu, s, u_in, rng, rng_lanes, u_out, x, kl, n, L, ld_mu, ld_s, ws, (hipStream_t)stream);
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) diag_bwd_kernel(const T* __restrict__ s, const T* __restrict__ u,
                                                        const T* __restrict__ x, const T* __restrict__ xbar,
                                                        const T* __restrict__ klbar, T* __restrict__ mubar,
-                                                       T* __restrict__ sbar, long n) {
+                                                       T* __restrict__ sbar, long n, long L, long lds_, long ldo) {
   const T kb = klbar ? klbar[0] : T(0);
   const long stride = (long)gridDim.x * blockDim.x;
+  const bool dense = lds_ == L && ldo == L;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    // s read from, and the two gradients written into, column blocks of wider row-major matrices (see diag_fwd_kernel)
+    long is = i, io = i;
+    if (!dense) {
+      const long r = i / L, c = i - r * L;
+      is = r * lds_ + c;
+      io = r * ldo + c;
+    }
     const T mb = (xbar ? xbar[i] : T(0)) + kb * x[i];
-    mubar[i] = mb;
-    sbar[i] = mb * hb_exp(s[i]) * u[i] - kb;
+    mubar[io] = mb;
+    sbar[io] = mb * hb_exp(s[is]) * u[i] - kb;
   }
 }
 
 template <typename T>
 static int diag_bwd(const T* s, const T* u, const T* x, const T* xbar, const T* klbar, T* mubar, T* sbar, long n,
-                    hipStream_t stream) {
+                    long L, long lds_, long ldo, hipStream_t stream) {
   HB_REQUIRE(n >= 0, "hb_diag_sample_kl_bwd: n < 0");
+  HB_REQUIRE(L >= 1 && lds_ >= L && ldo >= L && n % L == 0, "hb_diag_sample_kl_bwd: bad row layout (L=%ld, ld=%ld/%ld, n=%ld)", L,
+             lds_, ldo, n);
   HB_REQUIRE(s && u && x && mubar && sbar, "hb_diag_sample_kl_bwd: NULL pointer");
   if (n == 0) return 0;
   hipLaunchKernelGGL(diag_bwd_kernel<T>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, s, u, x, xbar, klbar,
-                     mubar, sbar, n);
+                     mubar, sbar, n, L, lds_, ldo);
   HB_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int hb_diag_sample_kl_bwd_f32(const float* s, const float* u, const float* x, const float* xbar,
-                                         const float* klbar, float* mubar, float* sbar, long n, void* stream) {
-  return diag_bwd<float>(s, u, x, xbar, klbar, mubar, sbar, n, (hipStream_t)stream);
+                                         const float* klbar, float* mubar, float* sbar, long n, long L, long ld_s,
+                                         long ld_out, void* stream) {
+  return diag_bwd<float>(s, u, x, xbar, klbar, mubar, sbar, n, L, ld_s, ld_out, (hipStream_t)stream);
 }
 extern "C" int hb_diag_sample_kl_bwd_f64(const double* s, const double* u, const double* x, const double* xbar,
-                                         const double* klbar, double* mubar, double* sbar, long n, void* stream) {
-  return diag_bwd<double>(s, u, x, xbar, klbar, mubar, sbar, n, (hipStream_t)stream);
+                                         const double* klbar, double* mubar, double* sbar, long n, long L, long ld_s,
+                                         long ld_out, void* stream) {
+  return diag_bwd<double>(s, u, x, xbar, klbar, mubar, sbar, n, L, ld_s, ld_out, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -597,9 +597,31 @@ def strided_view(x, out_shape, strides, offset=0) -> Tensor:
                                   "offset": int(offset)}, [tuple(out_shape)]).outputs[0]
 
 
+def _column_block(node):
+    """(L, ld, offset) when a strided node is a column block [rows, L] of a row-major [rows, ld] matrix, else None."""
+    a = node.attrs
+    xs = node.inputs[0].shape
+    if len(a["shape"]) != 2 or len(xs) != 2:
+        return None
+    rows, L = a["shape"]
+    if a["strides"] != (xs[1], 1) or rows != xs[0] or not 0 <= a["offset"] or a["offset"] + L > xs[1]:
+        return None
+    return L, xs[1], a["offset"]
+
+
 def _strided_emit(plan, node):
     H = plan.H
-    x, out = plan.buf(node.inputs[0]), plan.out(node.outputs[0])
+    y = node.outputs[0]
+    cb = _column_block(node)
+    cons = plan._consumers.get(y, [])
+    if (cb is not None and cons and y not in plan.outputs and y not in plan._bind
+            and all((c.op == "diag_sample_kl" and y in c.inputs[:2] and (len(c.inputs) < 3 or c.inputs[2] is not y))
+                    or (c.op == "diag_sample_kl_grad" and c.inputs[0] is y and y not in c.inputs[1:]) for c in cons)):
+        # the mean / log-std halves of an encoder output feeding the diagonal sampler (and `s` again in its VJP):
+        # the kernels read the column block in place (row stride = the source's width), no copy is made
+        plan._lazy_cols[y] = (plan.buf(node.inputs[0]), cb)
+        return
+    x, out = plan.buf(node.inputs[0]), plan.out(y)
     a = node.attrs
     shp = list(a["shape"])
     ostr = _contig_strides(shp)
@@ -775,6 +797,8 @@ def concat(values, axis) -> Tensor:
 
 def _concat_emit(plan, node):
     H = plan.H
+    if node.id in plan._fused_concat:
+        return  # its producer wrote the parts in place (see _diag_skl_grad_emit)
     out = plan.out(node.outputs[0])
     axis = node.attrs["axis"]
     ostr = _contig_strides(node.outputs[0].shape)
@@ -1069,14 +1093,27 @@ def diag_sample_kl(mu, s, u=None, stream="global") -> Tuple[Tensor, Tensor, Tens
     return n.outputs[0], n.outputs[1], n.outputs[2]
 
 
+def _col_view(plan, t):
+    """(1-D view starting at the operand's first element, row stride) for a lazily sliced column block, else (buffer, None)."""
+    lz = plan._lazy_cols.get(t)
+    if lz is None:
+        return plan.buf(t), None
+    src, (L, ld, off) = lz
+    return src.reshape(-1)[off:], ld
+
+
 def _diag_skl_emit(plan, node):
     H = plan.H
-    mu, s = plan.buf(node.inputs[0]), plan.buf(node.inputs[1])
+    (mu, ldm), (s, lds) = _col_view(plan, node.inputs[0]), _col_view(plan, node.inputs[1])
     u_in = plan.buf(node.inputs[2]) if len(node.inputs) > 2 else None
     outs = tuple(plan.out(t) for t in node.outputs)
     x, kl, u = outs
     rng = None if u_in is not None else plan.rng(node.attrs["stream"])
-    plan.steps.append(lambda: H.diag_sample_kl_fwd(mu, s, u_in=u_in, rng=rng, out=(x, kl, u)))
+    rows = None
+    if ldm is not None or lds is not None:
+        nrows, L = node.inputs[0].shape
+        rows = (nrows, L, ldm or L, lds or L)
+    plan.steps.append(lambda: H.diag_sample_kl_fwd(mu, s, u_in=u_in, rng=rng, out=(x, kl, u), rows=rows))
 
 
 def _diag_skl_vjp(node, gs):
@@ -1097,8 +1134,9 @@ def _diag_skl_vjp(node, gs):
 
 def _diag_skl_grad_emit(plan, node):
     H = plan.H
-    bufs = [plan.buf(t) for t in node.inputs]
-    s, u, x = bufs[:3]
+    s, lds = _col_view(plan, node.inputs[0])
+    bufs = [None] + [plan.buf(t) for t in node.inputs[1:]]
+    u, x = bufs[1:3]
     k = 3
     xbar = klbar = None
     if node.attrs["has_x"]:
@@ -1106,8 +1144,27 @@ def _diag_skl_grad_emit(plan, node):
         k += 1
     if node.attrs["has_kl"]:
         klbar = bufs[k]
-    outs = tuple(plan.out(t) for t in node.outputs)
-    plan.steps.append(lambda: H.diag_sample_kl_bwd(s, u, x, xbar, klbar, out=outs))
+    o0, o1 = node.outputs
+    c0, c1 = plan._consumers.get(o0, []), plan._consumers.get(o1, [])
+    packed = None
+    if (len(c0) == 1 and len(c1) == 1 and c0[0] is c1[0] and c0[0].op == "concat" and len(o0.shape) == 2
+            and c0[0].attrs["axis"] == 1 and len(c0[0].inputs) == 2 and set(c0[0].inputs) == {o0, o1}
+            and not any(t in plan.outputs or t in plan._bind for t in (o0, o1))):
+        # both gradients are the two halves of ONE [rows, 2L] matrix (the gradient of the encoder output): written
+        # in place with the wide row stride, the concat that would assemble them is not emitted
+        cat = c0[0]
+        L = o0.shape[1]
+        dst = plan.out(cat.outputs[0]).reshape(-1)
+        first = cat.inputs[0] is o0
+        packed = (dst[0:] if first else dst[L:], dst[L:] if first else dst[0:])
+        plan._fused_concat.add(cat.id)
+    if packed is not None or lds is not None:
+        nrows, L = o0.shape if len(o0.shape) == 2 else (1, o0.size)
+        outs = packed if packed is not None else tuple(plan.out(t) for t in node.outputs)
+        rows = (nrows, L, lds or L, 2 * L if packed is not None else L)
+    else:
+        outs, rows = tuple(plan.out(t) for t in node.outputs), None
+    plan.steps.append(lambda: H.diag_sample_kl_bwd(s, u, x, xbar, klbar, out=outs, rows=rows))
 
 
 defop("diag_sample_kl", _diag_skl_emit, _diag_skl_vjp)
@@ -1593,6 +1650,8 @@ class Plan:
         self._extra_copies = []
         self._fused_trinv = set()
         self._fused_matutil = set()
+        self._fused_concat = set()
+        self._lazy_cols: Dict[Tensor, object] = {}
         for t, b in (binds or []):
             self._prebind(t, b)
         if prologue:

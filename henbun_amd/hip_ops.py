@@ -330,10 +330,19 @@ def _rng_args(rng):
 
 
 # ---- K1/K2 variational sampler + MC-KL --------------------------------------
-def diag_sample_kl_fwd(mu, s, u_in=None, rng=None, out=None):
-    """x = mu + exp(s)*u ; kl = -0.5*sum(2s + u^2 - x^2).  Returns (x, kl[1], u)."""
+def diag_sample_kl_fwd(mu, s, u_in=None, rng=None, out=None, rows=None):
+    """x = mu + exp(s)*u ; kl = -0.5*sum(2s + u^2 - x^2).  Returns (x, kl, u).
+    rows=(nrows, L, ld_mu, ld_s): mu and s are column blocks of wider row-major matrices (1-D views starting at their
+    first element), read in place; x and u are dense [nrows, L] (out= is then required)."""
     _chk(mu), _chk(s)
-    n = mu.numel()
+    if rows is None:
+        n = mu.numel()
+        L = ldm = lds = max(n, 1)
+    else:
+        nrows, L, ldm, lds = (int(v) for v in rows)
+        n = nrows * L
+        if out is None:
+            raise ValueError("diag_sample_kl_fwd: strided inputs need explicit outputs")
     if out is None:
         x, kl, u = _empty_like(mu), _empty(1, dtype=mu.dtype, device=mu.device), _empty_like(mu)
     else:
@@ -341,17 +350,26 @@ def diag_sample_kl_fwd(mu, s, u_in=None, rng=None, out=None):
     ws = workspace(mu.dtype, mu.device)
     rp, rl = _rng_args(rng)
     _lib.lib().call("hb_diag_sample_kl_fwd" + _suf(mu), _p(mu), _p(s), _p(u_in), rp, rl, _p(u), _p(x), _p(kl), n,
-                    _p(ws), stream())
+                    L, ldm, lds, _p(ws), stream())
     return x, kl, u
 
 
-def diag_sample_kl_bwd(s, u, x, xbar, klbar, out=None):
+def diag_sample_kl_bwd(s, u, x, xbar, klbar, out=None, rows=None):
+    """rows=(nrows, L, ld_s, ld_out): s read, mubar/sbar written, as column blocks of wider matrices (see _fwd)."""
+    if rows is None:
+        n = s.numel()
+        L = lds = ldo = max(n, 1)
+    else:
+        nrows, L, lds, ldo = (int(v) for v in rows)
+        n = nrows * L
+        if out is None:
+            raise ValueError("diag_sample_kl_bwd: strided layout needs explicit outputs")
     if out is None:
         mubar, sbar = _empty_like(s), _empty_like(s)
     else:
         mubar, sbar = out
     _lib.lib().call("hb_diag_sample_kl_bwd" + _suf(s), _p(s), _p(u), _p(x), _p(xbar), _p(klbar), _p(mubar), _p(sbar),
-                    s.numel(), stream())
+                    n, L, lds, ldo, stream())
     return mubar, sbar
 
 

@@ -189,20 +189,26 @@ int hb_rng_randint(uint64_t* state, long nlanes, long* out, long n, long lo, lon
  *      :225-230 Normal._KL) ------------------------------------------------ */
 /* diagonal q: x = mu + exp(s)*u ; kl = -0.5*sum(2 s + u^2 - x^2) over all n
  * elements.  u_in nullable (then drawn from rng, which must be non-null);
- * u_out, x: [n]; kl: 1 element; ws >= 2048 elements. */
+ * u_out, x: [n] dense; kl: 1 element; ws >= 2048 elements.
+ * mu and s are n/L rows of L elements with row strides ld_mu, ld_s (>= L): L = n, ld = n is the flat case; an
+ * encoder-fed (LOCAL) posterior passes the mean and log-std halves of the encoder's [rows, 2L] output in place
+ * (reference variationals.py:70-80 slices them out of the fed tensor). */
 int hb_diag_sample_kl_fwd_f32(const float* mu, const float* s, const float* u_in, uint64_t* rng,
-                              long rng_lanes, float* u_out, float* x, float* kl, long n, float* ws,
-                              void* stream);
+                              long rng_lanes, float* u_out, float* x, float* kl, long n, long L,
+                              long ld_mu, long ld_s, float* ws, void* stream);
 int hb_diag_sample_kl_fwd_f64(const double* mu, const double* s, const double* u_in, uint64_t* rng,
-                              long rng_lanes, double* u_out, double* x, double* kl, long n,
-                              double* ws, void* stream);
+                              long rng_lanes, double* u_out, double* x, double* kl, long n, long L,
+                              long ld_mu, long ld_s, double* ws, void* stream);
 /* VJP.  xbar nullable (= 0); klbar = d loss / d kl, one device scalar
- * (nullable = 0).  mubar = xbar + klbar*x ; sbar = mubar*exp(s)*u - klbar. */
+ * (nullable = 0).  mubar = xbar + klbar*x ; sbar = mubar*exp(s)*u - klbar.
+ * s has row stride ld_s; mubar and sbar are written with row stride ld_out (both halves of one [rows, 2L]
+ * gradient of the encoder output, or dense with ld_out = L). */
 int hb_diag_sample_kl_bwd_f32(const float* s, const float* u, const float* x, const float* xbar,
-                              const float* klbar, float* mubar, float* sbar, long n, void* stream);
+                              const float* klbar, float* mubar, float* sbar, long n, long L, long ld_s,
+                              long ld_out, void* stream);
 int hb_diag_sample_kl_bwd_f64(const double* s, const double* u, const double* x, const double* xbar,
-                              const double* klbar, double* mubar, double* sbar, long n,
-                              void* stream);
+                              const double* klbar, double* mubar, double* sbar, long n, long L, long ld_s,
+                              long ld_out, void* stream);
 /* full-rank q over `rows` independent blocks: x_r = mu_r + tril(S_r) u_r ;
  * kl = -0.5*sum(log S_kk^2 + u^2 - x^2).  S: [rows,size,size] (upper part
  * ignored), mu/u/x: [rows,size]. */

@@ -724,6 +724,41 @@ def test_gather_rows_multi(H, p):
 
 
 @pytest.mark.parametrize("p", ["f32", "f64"])
+def test_diag_sample_kl_on_column_blocks_in_place(H, p):
+    """The sampler / its VJP reading mu, s as column blocks of a wider [rows, 2L] matrix and writing both gradients as
+    the two halves of one [rows, 2L] matrix == the dense form on sliced copies (the encoder-fed LOCAL posterior,
+    reference variationals.py:70-80)."""
+    dt = DT[p]
+    rng = np.random.RandomState(2)
+    rows, L = 37, 5
+    enc = rng.randn(rows, 2 * L) * 0.3
+    u = rng.randn(rows, L)
+    xbar, klbar = rng.randn(rows, L), np.array([0.7])
+    d_enc, d_u = dev(enc, dt), dev(u, dt)
+    mu_c, s_c = dev(enc[:, :L].copy(), dt), dev(enc[:, L:].copy(), dt)
+    x0, kl0, _ = H.diag_sample_kl_fwd(mu_c, s_c, u_in=d_u)
+    out = (torch.empty(rows, L, dtype=dt, device="cuda"), torch.empty(1, dtype=dt, device="cuda"),
+           torch.empty(rows, L, dtype=dt, device="cuda"))
+    flat = d_enc.reshape(-1)
+    x1, kl1, u1 = H.diag_sample_kl_fwd(flat[0:], flat[L:], u_in=d_u, out=out, rows=(rows, L, 2 * L, 2 * L))
+    assert torch.equal(x0, x1) and torch.equal(u1, d_u)
+    assert_close(kl1, host(kl0), TOL[p] if p == "f64" else dict(rtol=1e-5, atol=1e-4))
+    # halves given the other way round (log-std first), in-kernel noise: same stream as the dense call
+    r1, r2 = H.Rng(seed=3, nlanes=256), H.Rng(seed=3, nlanes=256)
+    xa, kla, ua = H.diag_sample_kl_fwd(s_c, mu_c, rng=r1)
+    xb, klb, ub = H.diag_sample_kl_fwd(flat[L:], flat[0:], rng=r2, out=out, rows=(rows, L, 2 * L, 2 * L))
+    assert torch.equal(xa, xb) and torch.equal(ua, ub) and torch.equal(r1.state, r2.state)
+    # VJP: s in place, gradients packed
+    mb0, sb0 = H.diag_sample_kl_bwd(s_c, d_u, x0, dev(xbar, dt), dev(klbar, dt))
+    g = torch.full((rows, 2 * L), float("nan"), dtype=dt, device="cuda")
+    gf = g.reshape(-1)
+    H.diag_sample_kl_bwd(flat[L:], d_u, x0, dev(xbar, dt), dev(klbar, dt), out=(gf[0:], gf[L:]), rows=(rows, L, 2 * L, 2 * L))
+    assert torch.equal(g[:, :L], mb0) and torch.equal(g[:, L:], sb0)
+    with pytest.raises(Exception, match="row layout"):
+        H.diag_sample_kl_fwd(flat[0:], flat[L:], u_in=d_u, out=out, rows=(rows, L, L - 1, 2 * L))
+
+
+@pytest.mark.parametrize("p", ["f32", "f64"])
 @pytest.mark.parametrize("widths", [(1, 1), (1, 5, 6), (64,), (20, 3)])
 def test_gather_rows_multi_with_in_kernel_draw(H, p, widths):
     """Index draw + gather in one launch == hb_rng_randint followed by the gather: same indices, same rows, same
