@@ -339,10 +339,10 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
 #define SGP_SM_MAX 512
 #define SGP_SLD (SGP_SM_MAX + 4)
 
-__device__ __forceinline__ int sgp_strip_tile(int w, int j) { return (j & 1) ? 8 * (j >> 1) + 7 - w : 8 * (j >> 1) + w; }
+#define SGP_STRIP_THREADS 512  // 8 waves: two per SIMD, so one wave's W loads are in flight under the other's MFMAs
 
 template <int D>
-__global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
+__global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<float> a) {
   typedef float V4 __attribute__((ext_vector_type(4)));
   typedef Mma<float> MM;
   __shared__ __attribute__((aligned(16))) float Ks[SGP_SN][SGP_SLD];
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
 
   HB_SSTAMP(0);
-  // ---- K(z, x[strip]) -> LDS, [column][k]: thread (c = tid % 32, kq = tid / 32) takes the 16-byte groups kq, kq+8, ...
+  // ---- K(z, x[strip]) -> LDS, [column][k]: thread (c = tid % 32, kq = tid / 32) takes the 16-byte groups kq, kq+16, ...
   // z is staged (pre-scaled) in LDS first: read straight from global, every group would be a dependent
   // load round trip (measured: the prologue alone cost ~10 us).
   {
@@ -375,36 +375,38 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
     }
     // all staging loads are issued before any is consumed (a load -> LDS store loop would pay one dependent
     // round trip per iteration: five of them, ~5 us, in the first version of this prologue)
-    constexpr int ZIT = (SGP_SM_MAX * D) / 256, UIT = SGP_SM_MAX / 256;
+    constexpr int NTH = SGP_STRIP_THREADS;
+    constexpr int ZIT = (SGP_SM_MAX * D) / NTH, UIT = SGP_SM_MAX / NTH;
+    static_assert(ZIT >= 1 && UIT >= 1, "staging loops");
     float zt[ZIT], ut[4][UIT];
     const int npu = a.part ? ((int)a.P < 4 ? (int)a.P : 4) : 0;
 #pragma unroll
     for (int it = 0; it < ZIT; ++it) {
-      const int i = tid + 256 * it;
+      const int i = tid + NTH * it;
       zt[it] = z[i < M * D ? i : 0];
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int it = 0; it < UIT; ++it) {
-        const int i = tid + 256 * it;
+        const int i = tid + NTH * it;
         ut[p][it] = p < npu ? a.u[e * a.P * a.M + (long)p * M + (i < M ? i : 0)] : 0.f;
       }
 #pragma unroll
     for (int it = 0; it < ZIT; ++it) {
-      const int i = tid + 256 * it;
+      const int i = tid + NTH * it;
       if (i < M * D) zs[i] = zt[it] * sc[i % D];
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int it = 0; it < UIT; ++it) {
-        const int i = tid + 256 * it;
+        const int i = tid + NTH * it;
         if (p < npu && i < M) us[p][i] = ut[p][it];
       }
     __syncthreads();
 #pragma unroll 4
-    for (int k4 = kq * 4; k4 < M; k4 += 32) {
+    for (int k4 = kq * 4; k4 < M; k4 += NTH / 8) {
       float zq[4 * D];
 #pragma unroll
       for (int q = 0; q < 4 * D; q += 4) {
@@ -429,39 +431,39 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
   __syncthreads();
 
   HB_SSTAMP(1);
-  // (w, 7-w, 8+w, 15-w) is ascending; the tiles that exist (< nT) are a prefix of it.  They go to the LAST slots,
-  // so that "slots >= P" is always a set of real tiles in order of increasing depth.
+  // Wave w takes the 32-row tiles (w, nT-1-w): one shallow and one deep, the same total depth (nT + 1 chunks of 32)
+  // for every wave.  A single tile (the middle one of an odd count) sits in the LAST slot, so that "slots >= P" is
+  // always a set of real tiles in order of increasing depth; waves beyond ceil(nT/2) have nothing to do.
   const int nT = M / 32;
-  int nv = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) nv += sgp_strip_tile(w, j) < nT ? 1 : 0;
-  int tile[4];
-  bool tv[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    tv[j] = j >= 4 - nv;
-    tile[j] = tv[j] ? sgp_strip_tile(w, j - (4 - nv)) : 0;  // empty slots point at a valid row block (prefetch stays in bounds)
+  int tile[2];
+  bool tv[2];
+  {
+    const int deep = nT - 1 - w;
+    tv[1] = w <= deep;
+    tv[0] = w < deep;
+    tile[1] = tv[1] ? deep : 0;  // empty slots point at a valid row block (prefetch stays in bounds)
+    tile[0] = tv[0] ? w : 0;
   }
-  typename MM::Acc acc[4];
+  typename MM::Acc acc[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   // The wave's tiles are in order of increasing depth (tile j is active while Q < dep[j] = tile_j + 1 steps of 32),
-  // so the loop splits into four phases with tiles j >= P active: no per-tile branch inside a phase (the
+  // so the loop splits into two phases with tiles j >= P active: no per-tile branch inside a phase (the
   // accumulators stay in AGPRs), and only tile P's last step crosses the diagonal and needs the k <= row mask.
   // A step is 32 deep: lane (row, h) reads the 64 contiguous bytes k = 32Q + 16h .. +15 of its W row, so the
   // two lanes of a row consume one whole 128-byte line per step (16-deep steps fetched every line twice: the
   // 64 KB of lines a workgroup touches per step do not survive in L1 until the next one).
-  int dep[4];
+  int dep[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) dep[j] = tv[j] ? tile[j] + 1 : 0;
-  V4 an[4][4];
+  for (int j = 0; j < 2; ++j) dep[j] = tv[j] ? tile[j] + 1 : 0;
+  V4 an[2][4];
   auto load_a = [&](int Q, auto pc) {
     constexpr int P = decltype(pc)::value;
 #pragma unroll
-    for (int j = P; j < 4; ++j) {
+    for (int j = P; j < 2; ++j) {
       int qq = Q < dep[j] ? Q : dep[j] - 1;  // finished tile: re-read its last step (never used)
       qq = qq < 0 ? 0 : qq;                   // empty slot (depth 0): stay inside W
       const float* p = W + (32 * tile[j] + li) * M + 32 * qq + 16 * h;
@@ -472,12 +474,12 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
   auto step = [&](int Q, auto pc, auto mc) {
     constexpr int P = decltype(pc)::value;
     constexpr bool MASK = decltype(mc)::value;
-    V4 ac[4][4];
+    V4 ac[2][4];
 #pragma unroll
-    for (int j = P; j < 4; ++j)
+    for (int j = P; j < 2; ++j)
 #pragma unroll
       for (int v = 0; v < 4; ++v) ac[j][v] = an[j][v];
-    if (!(HB_STRIP_ABLATE & 2) && Q + 1 < dep[3]) load_a(Q + 1, pc);  // prefetch (a tile that finishes now re-reads its last step: harmless)
+    if (!(HB_STRIP_ABLATE & 2) && Q + 1 < dep[1]) load_a(Q + 1, pc);  // prefetch (a tile that finishes now re-reads its last step: harmless)
     V4 bv[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) bv[v] = *reinterpret_cast<const V4*>(&Ks[li][32 * Q + 16 * h + 4 * v]);
@@ -494,7 +496,7 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int j = P; j < 4; ++j) {
+        for (int j = P; j < 2; ++j) {
           if (HB_STRIP_ABLATE & 1)
             asm volatile("" ::"v"(ac[j][v][s]), "v"(bv[v][s]));
           else
@@ -530,7 +532,7 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
       }
     }
   };
-  if (dep[3] > 0) {
+  if (dep[1] > 0) {
     load_a(0, std::integral_constant<int, 0>());
     int Q = 0;
     Q = phase(Q, std::integral_constant<int, 0>());
@@ -539,11 +541,6 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
     Q = phase(Q, std::integral_constant<int, 1>());
     retire(std::integral_constant<int, 1>());
     HB_SSTAMP(3);
-    Q = phase(Q, std::integral_constant<int, 2>());
-    retire(std::integral_constant<int, 2>());
-    HB_SSTAMP(4);
-    Q = phase(Q, std::integral_constant<int, 3>());
-    retire(std::integral_constant<int, 3>());
   }
   HB_SSTAMP(5);
 
@@ -552,7 +549,7 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) cs[q] += __shfl_xor(cs[q], 32);
     __syncthreads();  // every wave is done reading the K block
-    float* red = &Ks[0][0];  // [4 waves][5][32]
+    float* red = &Ks[0][0];  // [8 waves][5][32]
     if (lane < 32) {
 #pragma unroll
       for (int q = 0; q < 5; ++q) red[(w * 5 + q) * 32 + lane] = cs[q];
@@ -560,8 +557,12 @@ __global__ void __launch_bounds__(256) sgp_A_strip_kernel(SgpArgs<float> a) {
     __syncthreads();
     if (tid < 32 && col0 + tid < n) {
       float* pp = a.part + e * 5 * a.n + col0 + tid;  // gy = 1
-      for (int q = 0; q < 1 + npart; ++q)
-        pp[(long)q * n] = red[q * 32 + tid] + red[(5 + q) * 32 + tid] + red[(10 + q) * 32 + tid] + red[(15 + q) * 32 + tid];
+      for (int q = 0; q < 1 + npart; ++q) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SGP_STRIP_THREADS / 64; ++ww) sum += red[(ww * 5 + q) * 32 + tid];  // fixed order
+        pp[(long)q * n] = sum;
+      }
     }
   }
   HB_SSTAMP(6);
@@ -583,13 +584,13 @@ static inline bool sgp_strip_ok(long E, long n, long M, long d, const void* W) {
 static int sgp_A_strip_launch(SgpArgs<float> a, long E, hipStream_t stream) {
   dim3 grid = sgp_grid(hb_cdiv(a.n, SGP_SN), 1, E, a.efast);
   if (a.d == 1)
-    hipLaunchKernelGGL(sgp_A_strip_kernel<1>, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(sgp_A_strip_kernel<1>, grid, dim3(SGP_STRIP_THREADS), 0, stream, a);
   else if (a.d == 2)
-    hipLaunchKernelGGL(sgp_A_strip_kernel<2>, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(sgp_A_strip_kernel<2>, grid, dim3(SGP_STRIP_THREADS), 0, stream, a);
   else if (a.d == 3)
-    hipLaunchKernelGGL(sgp_A_strip_kernel<3>, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(sgp_A_strip_kernel<3>, grid, dim3(SGP_STRIP_THREADS), 0, stream, a);
   else
-    hipLaunchKernelGGL(sgp_A_strip_kernel<4>, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(sgp_A_strip_kernel<4>, grid, dim3(SGP_STRIP_THREADS), 0, stream, a);
   HB_LAUNCH_CHECK();
   return 0;
 }

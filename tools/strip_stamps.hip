@@ -1,6 +1,6 @@
 // Diagnostic build of the column-strip contraction with in-kernel phase stamps (not part of the product).
 #include <hip/hip_runtime.h>
-__device__ long long hb_sstamps[4 * 8];
+__device__ long long hb_sstamps[8 * 8];
 #define HB_SSTAMP(i)                                                                              \
   do {                                                                                            \
     if (blockIdx.x == 7 && (threadIdx.x & 63) == 0) hb_sstamps[(threadIdx.x >> 6) * 8 + (i)] = clock64(); \
@@ -30,12 +30,12 @@ int main() {
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   printf("hb_sgp_A_f32 (strip): %.2f us per launch (back-to-back stream launches)\n", ms * 1e3 / 50);
-  long long st[32];
+  long long st[64];
   (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(hb_sstamps), sizeof(st));
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < 8; ++w) {
     long long* s = st + w * 8;
-    printf("wave %d: synth %6lld  setup %6lld  phase0 %6lld  phase1 %6lld  phase2 %6lld  phase3 %6lld  epilogue %6lld   total %6lld cycles = %.2f us\n", w,
-           s[1] - s[0], 0LL, s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4], s[6] - s[5], s[6] - s[0], (s[6] - s[0]) / 2400.0);
+    printf("wave %d: synth %6lld  phase0 (both tiles) %6lld  phase1 (deep tile) %6lld  epilogue %6lld   total %6lld cycles = %.2f us\n", w,
+           s[1] - s[0], s[2] - s[1], s[3] - s[2], s[6] - s[5], s[6] - s[0], (s[6] - s[0]) / 2400.0);
   }
   return 0;
 }
