@@ -573,12 +573,13 @@ static inline bool hb_sgp_no_strip() {
   static const bool v = getenv("HB_SGP_NO_STRIP") != nullptr;
   return v;
 }
-// The strip form wins when the tiled kernel would leave ~one workgroup per CU (cfg 2: 35.7 -> 32.9 us); with
-// many experts / a long minibatch the tiled kernel runs several workgroups per CU and is the faster one
-// (cfg 5, E = 8, n = 65536: 1.83 ms tiled vs 2.10 ms strip).
+// The strip form wins when the tiled kernel would leave ~one workgroup per CU (cfg 2: 33.5 -> 28.8 us); with
+// many experts / a long minibatch the tiled kernel runs several workgroups per CU and stays the faster one
+// (cfg 5, E = 8, n = 65536: 1.68 ms tiled vs 1.76 ms strip, HB_SGP_FORCE_STRIP=1).
 static inline bool sgp_strip_ok(long E, long n, long M, long d, const void* W) {
   const long tiled_wgs = E * hb_cdiv(n, SGP_BN) * ((hb_cdiv(M, SGP_BM) + 1) / 2);
-  return M >= 32 && M <= SGP_SM_MAX && M % 32 == 0 && d <= SGP_DREG && ((uintptr_t)W % 16 == 0) && tiled_wgs < 1024;
+  static const bool force = getenv("HB_SGP_FORCE_STRIP") != nullptr;  // diagnostic: strip form whenever it is applicable
+  return M >= 32 && M <= SGP_SM_MAX && M % 32 == 0 && d <= SGP_DREG && ((uintptr_t)W % 16 == 0) && (tiled_wgs < 1024 || force);
 }
 
 static int sgp_A_strip_launch(SgpArgs<float> a, long E, hipStream_t stream) {
