@@ -12,15 +12,23 @@ ordinary ModuleNotFoundError at transforms.py:20), so the restatement uses
 torch-CPU tensors (float64 by default) -- which also gives reverse-mode
 gradients to stand in for `optimizer.minimize`'s TF autodiff (model.py:220).
 
-Pinning.  tests/test_oracle.py checks these functions against every
-known-answer formula the reference's own tests hold for the path
-(testing/test_kernels.py:10-63 RefRBF/RefCsymRBF loops, test_variationals.py
-:69-106,326-347, test_gp.py:59-131, test_densities.py:11-32, test_nn.py,
-test_transforms.py) re-derived with the reference's seeds into
-tests/golden/*.npz by tests/golden/make_golden.py, and cross-checks the
-autograd gradients with central finite differences.  Gradient VALUES, whole-
-ELBO values and Adam trajectories are not pinned by any reference test
-(SURVEY.md 8c): for those, parity is "oracle-pinned", not "reference-pinned".
+Pinning.  tests/test_oracle.py checks these functions against the reference's
+OWN numpy oracles, executed (not re-typed) in the build container by
+tests/golden/make_golden.py: it parses testing/test_kernels.py (RefStationary /
+RefRBF / RefCsymRBF, :10-63), testing/test_variationals.py (gaussian_KL,
+:326-347), testing/test_densities.py (student_t_ref, :26-32) and
+Henbun/transforms.py (Identity / Exp / Log1pe numpy forward/backward, :73-143),
+runs those definitions on the reference tests' seeds and draw order and stores
+the arrays in tests/golden/reference_known_answers.npz (file hashes and line
+ranges recorded in the fixture's `_provenance`; regeneration is byte-identical
+and checked by a test).  Known answers that exist only as inline numpy inside
+TF test bodies (test_variationals.py:69-106, test_gp.py:59-131,
+test_densities.py:23, test_tf_wraps.py:45-59, test_nn.py:11-29) are restated
+by that script.  Autograd gradients are cross-checked with central finite
+differences.  Gradient VALUES, whole-ELBO values and Adam trajectories are not
+pinned by any reference test (its gradient tests assert existence
+only): for those, parity is "oracle-pinned", the oracle's forward pieces being
+reference-pinned as above.
 """
 from __future__ import annotations
 

@@ -1,31 +1,103 @@
-"""Generate tests/golden/reference_known_answers.npz.
+"""Generate tests/golden/reference_known_answers.npz by EXECUTING the reference's own oracles.
 
-The reference's tests hold no data files: their known answers are inline numpy
-formulas evaluated on `np.random.RandomState(0)` draws.  This script re-derives
-those numbers -- same seeds, same draw order, independent loop-style numpy
-formulas -- so the oracle (oracle/henbun_oracle.py) and the HIP kernels can be
-checked against them without the reference (or TensorFlow) being present.
+The reference's tests hold no data files: their known answers are numpy code
+(classes / functions in its test modules and the numpy `forward/backward` of its
+transforms).  Those pieces are pure numpy -- only the *modules* import
+TensorFlow at the top -- so this script, run in the build container where
+/root/reference is mounted, parses the reference files, pulls the named
+class / function definitions out of the syntax tree and executes them (numpy +
+scipy only; the name `tf` is bound to an object that raises on any use), on the
+reference tests' own seeds and draw order.  No reference text is stored in this
+repository: only the resulting arrays (inputs + expected outputs) are.
 
-Sources of the formulas/seeds (all under /root/reference/testing):
-  kernels      test_kernels.py:10-63 (RefStationary/RefRBF/RefCsymRBF), :66-88 (draws)
-  variationals test_variationals.py:30-52 (draws), :69-106 (logdet, projected
-               samples), :326-347 (gaussian_KL)
-  sparse gp    test_gp.py:59-66 (fixture), :68-91, :115-131
-  densities    test_densities.py:11-32
-  log_sum_exp  test_tf_wraps.py:45-59
-  transforms   test_transforms.py:39-53
+Executed from the reference (provenance list is also stored in the fixture):
+  testing/test_kernels.py       RefStationary, RefRBF, RefCsymRBF  (:10-63), draws :66-88
+  testing/test_variationals.py  gaussian_KL (:326-347), draws :30-52
+  testing/test_densities.py     student_t_ref (:26-32), draws :13-16, :37-41
+  Henbun/transforms.py          Transform, Identity, Exp, Log1pe numpy forward/backward (:27-143)
 
-Run:  python tests/golden/make_golden.py   (numpy + scipy only)
+Restated inline here because the reference only has them inside TF test bodies
+(formula pinned, nothing to execute): projected samples / logdet
+(test_variationals.py:69-106), the sparse-GP fixture identities (test_gp.py:59-131,
+built on the executed RefRBF), bimixture (test_densities.py:23), log_sum_exp
+(test_tf_wraps.py:45-59), the MLP chain (test_nn.py:11-29).
+
+Every executed value is cross-checked against an independent loop-style numpy
+re-derivation (`_rederive_*` below, the round-1 generator) to 1e-14.
+
+The archive is written with fixed zip timestamps, so regenerating gives a
+byte-identical file (tests/test_oracle.py::test_golden_regenerates_byte_identically
+checks that whenever /root/reference is present).
+
+Run:  python tests/golden/make_golden.py [--check]
 """
+import ast
+import hashlib
+import io
 import os
+import sys
+import zipfile
 
 import numpy as np
+from scipy.linalg import solve_triangular
 from scipy.special import loggamma
 
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_known_answers.npz")
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "reference_known_answers.npz")
+REF = os.environ.get("HENBUN_REFERENCE", "/root/reference")
+
+SOURCES = {
+    "testing/test_kernels.py": ["RefStationary", "RefRBF", "RefCsymRBF"],
+    "testing/test_variationals.py": ["gaussian_KL"],
+    "testing/test_densities.py": ["student_t_ref"],
+    "Henbun/transforms.py": ["Transform", "Identity", "Exp", "Log1pe"],  # Logistic.__init__ builds TF constants: not executable
+}
 
 
-def sqdist_loops(X, X2, ell):
+class _NoTensorFlow(object):
+    """Bound to the name `tf` while reference definitions run: any use is an error."""
+
+    def __getattr__(self, name):
+        raise RuntimeError("reference oracle touched tensorflow (tf.%s): not a pure-numpy path" % name)
+
+
+def reference_available():
+    return all(os.path.isfile(os.path.join(REF, p)) for p in SOURCES)
+
+
+def load_reference_definitions():
+    """Parse the reference files and execute ONLY the named top-level definitions.
+
+    Returns (namespace, provenance) where provenance lists, per file, the names taken, their
+    line ranges and the sha256 of the file they came from."""
+    ns = {"np": np, "loggamma": loggamma, "solve_triangular": solve_triangular, "tf": _NoTensorFlow(),
+          "np_float_type": np.float64, "__name__": "reference_oracles"}
+    prov = []
+    import warnings
+
+    for rel, names in SOURCES.items():
+        path = os.path.join(REF, rel)
+        with open(path, "rb") as f:
+            raw = f.read()
+        tree = ast.parse(raw.decode("utf-8"), filename=path)
+        picked = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+        missing = set(names) - {n.name for n in picked}
+        if missing:
+            raise RuntimeError("%s: definitions not found: %s" % (rel, sorted(missing)))
+        mod = ast.Module(body=picked, type_ignores=[])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", SyntaxWarning)  # the reference compares strings with `is`
+            code = compile(mod, path, "exec")
+        exec(code, ns)
+        prov.append("%s sha256=%s %s" % (rel, hashlib.sha256(raw).hexdigest()[:16], ",".join(
+            "%s:%d-%d" % (n.name, n.lineno, n.end_lineno) for n in picked)))
+    return ns, prov
+
+
+# ---------------------------------------------------------------------------------------------
+# independent loop-style re-derivations (cross-check only; must agree with the executed values)
+# ---------------------------------------------------------------------------------------------
+def _rederive_sqdist(X, X2, ell):
     if X.ndim == 3:
         out = np.zeros((X.shape[0], X.shape[1], X2.shape[1]))
         for b in range(X.shape[0]):
@@ -42,22 +114,35 @@ def sqdist_loops(X, X2, ell):
     return out
 
 
-def rbf(X, X2, ell):
-    return np.exp(-0.5 * sqdist_loops(X, X2, ell))
+def _rederive_rbf(X, X2, ell):
+    return np.exp(-0.5 * _rederive_sqdist(X, X2, ell))
 
 
-def csym(X, X2, ell):
-    return np.exp(-0.5 * sqdist_loops(X, X2, ell)) + np.exp(-0.5 * sqdist_loops(X, -X2, ell))
+def _rederive_csym(X, X2, ell):
+    return np.exp(-0.5 * _rederive_sqdist(X, X2, ell)) + np.exp(-0.5 * _rederive_sqdist(X, -X2, ell))
 
 
-def csym_diag(X, ell):
-    Xt = np.sum((X / ell) ** 2, axis=-1)
-    return 1.0 + np.exp(-2.0 * Xt)
+def _rederive_student_t(x, mu, scale, nu):
+    from math import lgamma
+
+    lg = np.vectorize(lgamma)
+    const = lg(0.5 * (nu + 1.0)) - lg(0.5 * nu) - 0.5 * (2.0 * np.log(scale) + np.log(nu) + np.log(np.pi))
+    return const - 0.5 * (nu + 1.0) * np.log1p(((x - mu) / scale) ** 2 / nu)
 
 
-def main():
+def _same(a, b, tol=1e-14):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.max(np.abs(a - b) / (1.0 + np.abs(b)), initial=0.0) <= tol
+
+
+def build():
+    ns, prov = load_reference_definitions()
+    RefRBF, RefCsymRBF = ns["RefRBF"], ns["RefCsymRBF"]
+    gaussian_KL, student_t_ref = ns["gaussian_KL"], ns["student_t_ref"]
     g = {}
-    # ---- kernels (test_kernels.py:66-88) ----
+    checks = []
+
+    # ---- kernels: reference draws (test_kernels.py:66-88), reference classes executed ----
     rng = np.random.RandomState(0)
     l1 = np.exp(rng.randn(1))
     l2 = np.exp(rng.randn(2))
@@ -65,23 +150,23 @@ def main():
     X2 = rng.randn(6, 2)
     Xb = rng.randn(10, 5, 2)
     X2b = rng.randn(10, 6, 2)
+    k1, k2, k3 = RefRBF(l1), RefRBF(l2), RefCsymRBF(l1)
     g.update(k_l1=l1, k_l2=l2, k_X=X, k_X2=X2, k_Xb=Xb, k_X2b=X2b)
-    g["k_rbf1_XX"] = rbf(X, X, l1)
-    g["k_rbf2_XX"] = rbf(X, X, l2)
-    g["k_csym_XX"] = csym(X, X, l1)
-    g["k_rbf1_XX2"] = rbf(X, X2, l1)
-    g["k_rbf2_XX2"] = rbf(X, X2, l2)
-    g["k_csym_XX2"] = csym(X, X2, l1)
-    g["k_rbf1_b"] = rbf(Xb, Xb, l1)
-    g["k_rbf2_b"] = rbf(Xb, Xb, l2)
-    g["k_csym_b"] = csym(Xb, Xb, l1)
-    g["k_rbf1_b2"] = rbf(Xb, X2b, l1)
-    g["k_rbf2_b2"] = rbf(Xb, X2b, l2)
-    g["k_csym_b2"] = csym(Xb, X2b, l1)
-    g["k_csym_diag"] = csym_diag(X, l1)
-    g["k_csym_diag_b"] = csym_diag(Xb, l1)
+    for tag, a, b in (("XX", X, X), ("XX2", X, X2), ("b", Xb, Xb), ("b2", Xb, X2b)):
+        g["k_rbf1_" + tag] = k1.K(a, b)
+        g["k_rbf2_" + tag] = k2.K(a, b)
+        g["k_csym_" + tag] = k3.K(a, b)
+        g["k_sqdist2_" + tag] = k2.square_dist(a, b)
+        checks += [(g["k_rbf1_" + tag], _rederive_rbf(a, b, l1)), (g["k_rbf2_" + tag], _rederive_rbf(a, b, l2)),
+                   (g["k_csym_" + tag], _rederive_csym(a, b, l1)), (g["k_sqdist2_" + tag], _rederive_sqdist(a, b, l2))]
+    g["k_rbf_diag"] = k1.Kdiag(X)
+    g["k_rbf_diag_b"] = k1.Kdiag(Xb)
+    g["k_csym_diag"] = k3.Kdiag(X)
+    g["k_csym_diag_b"] = k3.Kdiag(Xb)
+    checks += [(g["k_csym_diag"], 1.0 + np.exp(-2.0 * np.sum((X / l1) ** 2, axis=-1))),
+               (g["k_csym_diag_b"], 1.0 + np.exp(-2.0 * np.sum((Xb / l1) ** 2, axis=-1)))]
 
-    # ---- variationals (test_variationals.py:30-52) ----
+    # ---- variationals: reference draws (test_variationals.py:30-52) ----
     rng = np.random.RandomState(0)
     sq_full = rng.randn(3, 10, 10) * 0.5
     sq_diag = rng.randn(3, 10) * 0.5 - 0.5
@@ -91,8 +176,9 @@ def main():
             for k in range(j + 1, 10):
                 sq_full[i, j, k] = 0.0
     vx = rng.randn(3, 10) * 0.3
-    iid = rng.randn(3, 10).astype(np.float32).astype(np.float64)
+    iid = rng.randn(3, 10).astype(np.float32).astype(np.float64)  # np_float_type is float32 by default there
     g.update(v_sq_full=sq_full, v_sq_diag=sq_diag, v_mu=vx, v_iid=iid)
+    # logdet / projected samples: formulas inside TF test bodies (:69-106), restated
     ld_full = np.zeros((3, 10))
     ld_diag = np.zeros((3, 10))
     post_full = np.zeros((3, 10))
@@ -104,66 +190,80 @@ def main():
         post_full[i] = vx[i] + np.dot(sq_full[i], iid[i])
         post_diag[i] = vx[i] + np.exp(sq_diag[i]) * iid[i]
     g.update(v_logdet_full=ld_full, v_logdet_diag=ld_diag, v_post_full=post_full, v_post_diag=post_diag)
-    # analytic KL (test_variationals.py:326-347)
+    # analytic KL: the reference's gaussian_KL executed (it selects the branch with `is 'diagonal'`)
+    g["v_kl_full"] = np.array(gaussian_KL(vx, sq_full, q_shape=sys.intern("fullrank")))
+    g["v_kl_diag"] = np.array(gaussian_KL(vx, sq_diag, q_shape=sys.intern("diagonal")))
     kl_full = 0.0
     kl_diag = 0.0
     for i in range(3):
-        n = 10
-        kl_full += 0.5 * (-np.sum(np.log(np.square(np.diagonal(sq_full[i])))) - n + np.sum(np.square(sq_full[i])) + vx[i] @ vx[i])
-        kl_diag += 0.5 * (-2.0 * np.sum(sq_diag[i]) - n + np.sum(np.exp(2.0 * sq_diag[i])) + vx[i] @ vx[i])
-    g.update(v_kl_full=np.array(kl_full), v_kl_diag=np.array(kl_diag))
+        kl_full += 0.5 * (-np.sum(np.log(np.square(np.diagonal(sq_full[i])))) - 10 + np.sum(np.square(sq_full[i])) + vx[i] @ vx[i])
+        kl_diag += 0.5 * (-2.0 * np.sum(sq_diag[i]) - 10 + np.sum(np.exp(2.0 * sq_diag[i])) + vx[i] @ vx[i])
+    checks += [(g["v_kl_full"], kl_full), (g["v_kl_diag"], kl_diag)]
+    # closed-form KL on a second, batch-free set (used by the closed-form KL mode's tests)
+    rng2 = np.random.RandomState(3)
+    cmu = rng2.randn(1, 24) * 0.7
+    cs_diag = rng2.randn(1, 24) * 0.4 - 0.3
+    cs_full = np.tril(rng2.randn(1, 24, 24) * 0.2)
+    for j in range(24):
+        cs_full[0, j, j] = np.exp(cs_full[0, j, j])
+    g.update(c_mu=cmu, c_s_diag=cs_diag, c_s_full=cs_full)
+    g["c_kl_diag"] = np.array(gaussian_KL(cmu, cs_diag, q_shape=sys.intern("diagonal")))
+    g["c_kl_full"] = np.array(gaussian_KL(cmu, cs_full, q_shape=sys.intern("fullrank")))
 
-    # ---- sparse GP fixture (test_gp.py:59-66,115-131) ----
+    # ---- sparse GP fixture (test_gp.py:59-66,115-131): Gram blocks from the executed RefRBF ----
     rng = np.random.RandomState(0)
     z = np.linspace(-2.0, 2.0, 60).reshape(-1, 2)
     ell = np.ones(1) * 0.5
     xg = rng.randn(20, 2)
+    kg = RefRBF(ell)
     jitter = 1e-5
-    Kzz = rbf(z, z, ell) + jitter * np.eye(30)
+    Kzz = kg.K(z, z) + jitter * np.eye(30)
     Lz = np.linalg.cholesky(Kzz)
-    Kzx = rbf(z, xg, ell)
+    Kzx = kg.K(z, xg)
     LnT = np.linalg.solve(Lz, Kzx)
-    cov_full = rbf(xg, xg, ell) - LnT.T @ LnT
-    cov_diag = 1.0 - np.sum(LnT * LnT, axis=0)
+    cov_full = kg.K(xg, xg) - LnT.T @ LnT
+    cov_diag = kg.Kdiag(xg) - np.sum(LnT * LnT, axis=0)
     g.update(g_z=z, g_ell=ell, g_x=xg, g_cholT=Lz.T, g_LnT=LnT, g_cov_full=cov_full, g_cov_diag=cov_diag)
+    checks += [(Kzx, _rederive_rbf(z, xg, ell))]
 
-    # ---- densities (test_densities.py:11-32) ----
+    # ---- densities (test_densities.py:11-75): student_t_ref executed ----
     rng = np.random.RandomState(0)
     a = rng.randn(2, 3, 4)
     b = rng.randn(2, 3, 4)
     frac = rng.uniform(size=(2, 1, 1))
-
-    def st_ref(x, mu, scale, nu):
-        const = loggamma(0.5 * (nu + 1.0)) - loggamma(0.5 * nu) - 0.5 * (np.log(scale * scale) + np.log(nu) + np.log(np.pi))
-        return const - 0.5 * (nu + 1.0) * np.log(1.0 + (1.0 / nu) * ((x - mu) / scale) ** 2.0)
-
-    lp0 = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(2.0) - 0.5 * (0.0 - a) ** 2 / 2.0
-    lp1 = st_ref(b, 0.0, 2.0, 3.0)
+    lp0 = -0.5 * np.log(2 * np.pi) - 0.5 * np.log(2.0) - 0.5 * (0.0 - a) ** 2 / 2.0  # densities.py:25-27 (inline in a TF body)
+    lp1 = np.real(student_t_ref(b, 0.0, 2.0, 3.0))
     g.update(d_a=a, d_b=b, d_frac=frac, d_logp0=lp0, d_logp1=lp1)
-    g["d_mix"] = np.log(frac * np.exp(lp0) + (1 - frac) * np.exp(lp1))
+    g["d_mix"] = np.log(frac * np.exp(lp0) + (1 - frac) * np.exp(lp1))  # test_densities.py:23
     rng = np.random.RandomState(0)
     sx = rng.randn(2, 3, 4)
     smu = rng.randn(2, 3, 4)
     sscale = np.exp(rng.randn(2, 3, 4))
     snu = np.exp(rng.randn(2, 3, 4))
     g.update(s_x=sx, s_mu=smu, s_scale=sscale, s_nu=snu)
-    g["s_logp_nu3"] = st_ref(sx, smu, sscale, 3.0)
-    g["s_logp_nuT"] = st_ref(sx, smu, sscale, snu)
+    g["s_logp_nu3"] = np.real(student_t_ref(sx, smu, sscale, 3.0))
+    g["s_logp_nuT"] = np.real(student_t_ref(sx, smu, sscale, snu))
+    checks += [(lp1, _rederive_student_t(b, 0.0, 2.0, 3.0)), (g["s_logp_nu3"], _rederive_student_t(sx, smu, sscale, 3.0)),
+               (g["s_logp_nuT"], _rederive_student_t(sx, smu, sscale, snu))]
 
-    # ---- log_sum_exp (test_tf_wraps.py:45-59) ----
+    # ---- log_sum_exp (test_tf_wraps.py:45-59; inline numpy in a TF body) ----
     rng = np.random.RandomState(0)
     t = rng.randn(3, 4, 5)
     g["lse_in"] = t
     g["lse_axis1"] = np.log(np.sum(np.exp(t), axis=1))
     g["lse_axis2"] = np.log(np.sum(np.exp(t), axis=2))
 
-    # ---- transforms (test_transforms.py:39-53): Log1pe forward values ----
+    # ---- transforms (test_transforms.py:39-53): the reference classes' numpy forward/backward executed ----
     rng = np.random.RandomState(0)
     tx = rng.randn(10)
     g["t_x"] = tx
-    g["t_log1pe"] = np.log(1.0 + np.exp(tx)) + 1e-6
+    for key, tr in (("identity", ns["Identity"]()), ("exp", ns["Exp"]()), ("log1pe", ns["Log1pe"]())):
+        y = np.asarray(tr.forward(tx), dtype=np.float64)
+        g["t_" + key] = y
+        g["t_" + key + "_back"] = np.asarray(tr.backward(y), dtype=np.float64)
+    checks += [(g["t_log1pe"], np.log(1.0 + np.exp(tx)) + 1e-6), (g["t_exp"], np.exp(tx) + 1e-6)]
 
-    # ---- MLP (test_nn.py:11-29 shape pattern; weights drawn here) ----
+    # ---- MLP (test_nn.py:11-29 shape pattern; the reference compares TF with TF, weights drawn here) ----
     rng = np.random.RandomState(0)
     nx = rng.randn(5, 6, 3)
     w1 = rng.randn(5, 3, 2)
@@ -174,8 +274,45 @@ def main():
     g.update(n_x=nx, n_w1=w1, n_b1=b1, n_w2=w2, n_b2=b2)
     g["n_y"] = np.einsum("lni,lio->lno", h, w2) + b2
 
-    np.savez_compressed(OUT, **g)
-    print("wrote", OUT, "(%d arrays)" % len(g))
+    for i, (got, want) in enumerate(checks):
+        if not _same(got, want):
+            raise AssertionError("reference-executed value #%d disagrees with its independent re-derivation" % i)
+    executed = sorted(k for k in g if k.startswith(("k_rbf", "k_csym", "k_sqdist", "v_kl", "c_kl", "d_logp1", "s_logp", "t_"))
+                      and k != "t_x")
+    g["_provenance"] = np.array(prov)
+    g["_reference_executed_keys"] = np.array(executed)
+    return g, len(checks)
+
+
+def serialise(g):
+    """A .npz with sorted members and fixed zip timestamps: same arrays -> same bytes."""
+    buf = io.BytesIO()
+    with zipfile.ZipFile(buf, "w", compression=zipfile.ZIP_DEFLATED) as zf:
+        for key in sorted(g):
+            arr = np.ascontiguousarray(g[key])
+            member = io.BytesIO()
+            np.lib.format.write_array(member, arr, allow_pickle=False)
+            info = zipfile.ZipInfo(key + ".npy", date_time=(1980, 1, 1, 0, 0, 0))
+            info.compress_type = zipfile.ZIP_DEFLATED
+            info.external_attr = 0o644 << 16
+            zf.writestr(info, member.getvalue())
+    return buf.getvalue()
+
+
+def main():
+    if not reference_available():
+        sys.exit("make_golden: %s not present (this script runs in the build container only)" % REF)
+    g, nchk = build()
+    blob = serialise(g)
+    if "--check" in sys.argv:
+        with open(OUT, "rb") as f:
+            same = f.read() == blob
+        print("fixture %s the committed file" % ("matches" if same else "DIFFERS from"))
+        sys.exit(0 if same else 1)
+    with open(OUT, "wb") as f:
+        f.write(blob)
+    print("wrote %s: %d arrays, %d executed-vs-rederived cross-checks, sha256 %s"
+          % (OUT, len(g), nchk, hashlib.sha256(blob).hexdigest()[:16]))
 
 
 if __name__ == "__main__":
