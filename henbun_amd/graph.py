@@ -1605,6 +1605,9 @@ def cluster_elementwise(order, enabled=True):
     return member
 
 
+INFO_POOL_WORDS = 65536
+
+
 class CholeskyError(ArithmeticError):
     """A Cholesky factorisation met a non-positive pivot (TensorFlow raises
     InvalidArgumentError from tf.cholesky at the same point)."""
@@ -1634,6 +1637,10 @@ class Plan:
         self._infos: List[Tuple[object, str]] = []
         self._nocap: List[str] = []
         self._graph = None
+        self._graphs: Dict[object, object] = {}   # injection state -> captured graph (see _state_key)
+        self._capture_enabled = False
+        self._info_pool = None          # every factorisation status word of the plan, contiguous (Adam reads them)
+        self._info_used = 0
         self.stream = stream          # torch.cuda.Stream the plan runs on (None = current)
         self.side_effect_steps = set()  # steps skipped by the capture warm-up (e.g. the Adam update)
         self.step_labels = {}           # id(step closure) -> op label (profiling)
@@ -1716,9 +1723,21 @@ class Plan:
         return self.torch.empty(tuple(shape), dtype=self.dtype, device=self.device)
 
     def new_info(self, n, label):
-        info = self.torch.zeros(max(int(n), 1), dtype=self.torch.int32, device=self.device)
+        """`n` LAPACK-style status words for one (batched) factorisation, carved from one pool so that the
+        optimiser step can look at all of them in one launch (hb_adam_step's failure containment)."""
+        n = max(int(n), 1)
+        if self._info_pool is None:
+            self._info_pool = self.torch.zeros(INFO_POOL_WORDS, dtype=self.torch.int32, device=self.device)
+        if self._info_used + n > INFO_POOL_WORDS:
+            raise ValueError("more than %d factorisations in one plan" % INFO_POOL_WORDS)
+        info = self._info_pool[self._info_used:self._info_used + n]
+        self._info_used += n
         self._infos.append((info, label))
         return info
+
+    def info_words(self):
+        """The used part of the status pool (None when the plan factorises nothing)."""
+        return None if self._info_used == 0 else self._info_pool[:self._info_used]
 
     def rng(self, stream):
         return self._rngs[stream]
@@ -1845,7 +1864,7 @@ class Plan:
         b = self.noise_inputs[t]
         b.copy_(self.torch.as_tensor(np.asarray(value)).to(dtype=self.dtype, device=self.device).reshape(b.shape))
         self._injected[t] = True
-        self._graph = None
+        self._graph = self._graphs.get(self._state_key())
 
     # -- execution
     def _on_stream(self):
@@ -1853,8 +1872,18 @@ class Plan:
 
         return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
+    def _state_key(self):
+        """What the recorded launch sequence depends on besides buffer contents: which noise leaves are injected
+        (their draw launches are left out).  Subclasses add their own state (injected minibatch indices)."""
+        return frozenset(self._injected)
+
     def run(self):
         with self._on_stream():
+            if self._graph is None and self._capture_enabled and not self._nocap:
+                # the injection state changed since the last capture: one hipGraph per state, captured on demand
+                self._graph = self._graphs.get(self._state_key())
+                if self._graph is None:
+                    self._capture_now()
             if self._graph is not None:
                 self._graph.launch()
             else:
@@ -1864,24 +1893,35 @@ class Plan:
     def capture(self):
         """Record the launch sequence into one hipGraph (replayed by run()).  A
         warm-up pass first lets lazily sized workspaces allocate outside the
-        capture; steps with side effects on the parameters are skipped in it."""
+        capture; steps with side effects on the parameters are skipped in it.
+        Later changes of the injection state (set_indices / clear_indices /
+        inject_noise) re-capture on the next run; graphs are kept per state."""
         if self._nocap:
             return False
+        self._capture_enabled = True
         self.torch.cuda.synchronize()
         with self._on_stream():
-            for s in self.steps:
-                if s not in self.side_effect_steps:
-                    s()
-            self.torch.cuda.current_stream().synchronize()
-            g = self.H.CapturedGraph()
-            g.begin()
-            try:
-                for s in self.steps:
-                    s()
-            finally:
-                g.end()
-        self._graph = g
+            self._capture_now()
         return True
+
+    def _capture_now(self):
+        for s in self.steps:
+            if s not in self.side_effect_steps:
+                s()
+        self.torch.cuda.current_stream().synchronize()
+        g = self.H.CapturedGraph()
+        g.begin()
+        try:
+            for s in self.steps:
+                s()
+        finally:
+            g.end()
+        self._graph = g
+        self._graphs[self._state_key()] = g
+
+    @property
+    def is_captured(self):
+        return self._graph is not None
 
     def profile(self, iters=20):
         """Per-op device time (us) from an eager, event-bracketed replay of the
@@ -1913,8 +1953,15 @@ class Plan:
             self.stream.synchronize()
         else:
             self.torch.cuda.synchronize()
+        if self._info_used == 0:
+            return
+        pool = self._info_pool[:self._info_used].cpu().numpy()  # ONE small copy for every factorisation of the plan
+        if not pool.any():
+            return
+        off = 0
         for info, label in self._infos:
-            host = info.cpu().numpy().reshape(-1)  # one small copy: `nonzero()` costs a launch and a second sync
+            host = pool[off:off + info.numel()]
+            off += info.numel()
             bad = np.flatnonzero(host)
             if bad.size:
                 raise CholeskyError("%s: leading minor %d is not positive definite (matrix %d)"

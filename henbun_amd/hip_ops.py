@@ -638,11 +638,23 @@ def sgp_bwd(x, z, ell, W, u, eps, A, v, fbar, mode=SGP_DIAGONAL, need_xbar=False
 
 
 # ---- K9 Adam ---------------------------------------------------------------------
-def adam_step(theta, g, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0):
-    """In-place TF-1 Adam on flat buffers; `t` is a 1-element int64 device tensor."""
+def adam_step(theta, g, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0, tick=True, info=None, dpflag=None,
+              fail=None):
+    """In-place TF-1 Adam on flat buffers; `t` is a 1-element int64 device tensor (advanced when `tick`).
+    `info` (int32 status words of this step's factorisations), `dpflag` (one element of theta's dtype: the
+    all-reduced failure flag) and `fail` (int64[2], sticky) make the update a no-op when a factorisation failed."""
     assert t.dtype == torch.int64
+    n_info = 0
+    if info is not None:
+        assert info.dtype == torch.int32 and info.is_contiguous()
+        n_info = info.numel()
+    if fail is not None:
+        assert fail.dtype == torch.int64 and fail.numel() == 2
+    if dpflag is not None:
+        assert dpflag.dtype == theta.dtype and dpflag.numel() == 1
     _lib.lib().call("hb_adam_step" + _suf(theta), _p(theta), _p(g), _p(m), _p(v), theta.numel(), float(lr), float(b1),
-                    float(b2), float(eps), float(gscale), _p(t), stream())
+                    float(b2), float(eps), float(gscale), _p(t), int(bool(tick)), _p(info) if n_info else None, n_info,
+                    _p(dpflag) if dpflag is not None else None, _p(fail) if fail is not None else None, stream())
 
 
 # ---- hipGraph capture ---------------------------------------------------------------

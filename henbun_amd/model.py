@@ -47,6 +47,8 @@ class AdamOptimizer:
                 "m": torch.zeros(n, dtype=session.torch_dtype, device=session.device),
                 "v": torch.zeros(n, dtype=session.torch_dtype, device=session.device),
                 "t": torch.zeros(1, dtype=torch.int64, device=session.device),
+                # sticky failure record of hb_adam_step: {step number of the first blocked update, its status word}
+                "fail": torch.zeros(2, dtype=torch.int64, device=session.device),
             }
             self._slots[key] = s
         return s
@@ -236,18 +238,19 @@ class Optimizer:
             theta = sess.theta
             gscale = -parallel.gradient_scale(sess.world_size, self.dp_reduce)
 
-            def adam():
-                # one fused launch per contiguous segment; the shared step counter ticks once
-                t = slots["t"]
-                for i, (o, s) in enumerate(merged):
-                    last = i == len(merged) - 1
-                    tt = t if last else plan.t_scratch
-                    if not last:
-                        tt.copy_(t)
-                    H.adam_step(theta[o:o + s], gflat[o:o + s], slots["m"][o:o + s], slots["v"][o:o + s], tt,
-                                lr=opt.learning_rate, b1=opt.beta1, b2=opt.beta2, eps=opt.epsilon, gscale=gscale)
+            info = plan.info_words()
+            plan.fail = slots["fail"]
 
-            plan.t_scratch = torch.zeros(1, dtype=torch.int64, device=sess.device)
+            def adam():
+                # one fused launch per contiguous segment; they share the step counter, which the last one advances.
+                # A factorisation that failed in this step turns the update into a no-op (hb_adam_step): the
+                # parameters stay at the last good step, as when tf.cholesky raises before apply_gradients.
+                for i, (o, s) in enumerate(merged):
+                    H.adam_step(theta[o:o + s], gflat[o:o + s], slots["m"][o:o + s], slots["v"][o:o + s], slots["t"],
+                                lr=opt.learning_rate, b1=opt.beta1, b2=opt.beta2, eps=opt.epsilon, gscale=gscale,
+                                tick=(i == len(merged) - 1), info=info, dpflag=plan.dpflag, fail=slots["fail"])
+
+            plan.dpflag = None
             plan.adam = adam
             if sess.world_size == 1:
                 plan.steps.append(adam)
@@ -275,19 +278,26 @@ class Optimizer:
         `indices` optionally fixes the minibatch rows (indices into the data array)."""
         self._ensure_compiled()
         plan = self._get_plan("run", minibatch_size, training)
-        if indices is not None:
-            plan.set_indices(indices)
+        self._apply_indices(plan, indices)
         plan.run()
         plan.check()
         self.last_plan = plan
         return float(plan.value(plan.objective))
 
+    @staticmethod
+    def _apply_indices(plan, indices):
+        """`indices` fixes the rows of THIS call only; without it every call draws afresh
+        (reference model.py:232-267)."""
+        if indices is not None:
+            plan.set_indices(indices)
+        elif plan.index_buffer is not None:
+            plan.clear_indices()
+
     def optimize(self, maxiter=1, minibatch_size=None, indices=None):
         """`maxiter` Adam steps (reference model.py:255-269)."""
         self._ensure_compiled()
         plan = self._get_plan("opt", minibatch_size)
-        if indices is not None:
-            plan.set_indices(indices)
+        self._apply_indices(plan, indices)
         sess = self.model._session
         if sess.world_size == 1:
             for _ in range(int(maxiter)):
@@ -298,8 +308,22 @@ class Optimizer:
                 with plan._on_stream():
                     parallel.allreduce_gradient(plan.gflat, plan.segments)
                     plan.adam()
-        plan.check()
         self.last_plan = plan
+        self._check_step_failure(plan)
+        plan.check()
+
+    def _check_step_failure(self, plan):
+        """Raise CholeskyError if an update was blocked by a failed factorisation.  The parameters, Adam slots and
+        step count are those of the last good step; the record is cleared so that the caller may continue."""
+        plan.stream.synchronize() if plan.stream is not None else plan.torch.cuda.synchronize()
+        step, what = (int(x) for x in plan.fail.cpu().numpy())
+        if step != 0:
+            plan.fail.zero_()
+            plan.torch.cuda.synchronize()
+            why = ("a factorisation on another rank failed" if what < 0 else
+                   "leading minor %d is not positive definite" % what)
+            raise G.CholeskyError("optimize: Adam step %d was not applied: %s; the parameters were left at the "
+                                  "last good step" % (step, why))
 
     # ------------------------------------------------------------------ exact resume (SURVEY.md 8(f)1)
     def save_state(self, path):
@@ -315,9 +339,10 @@ class Optimizer:
         out = {
             "theta": sess.theta.cpu().numpy(),
             "adam_m": slots["m"].cpu().numpy(), "adam_v": slots["v"].cpu().numpy(), "adam_t": slots["t"].cpu().numpy(),
-            "layout": np.array(sorted((v.long_name, o, s) for v in self.model.get_variables()
-                                      for o, s in [sess._offsets.get(id(v), (-1, -1))] if o >= 0), dtype=object),
         }
+        layout = self._layout_rows()
+        out["layout_names"] = np.array([r[0] for r in layout], dtype=np.str_)
+        out["layout_spans"] = np.array([[r[1], r[2]] for r in layout], dtype=np.int64).reshape(-1, 2)
         for k, r in sess.rngs.items():
             out["rng_" + k] = r.state.cpu().numpy()
         idx = self.model._index
@@ -327,6 +352,11 @@ class Optimizer:
         np.savez(p, **out)
         return p
 
+    def _layout_rows(self):
+        sess = self.model._session
+        return sorted((v.long_name, int(o), int(s)) for v in self.model.get_variables()
+                      for o, s in [sess._offsets.get(id(v), (-1, -1))] if o >= 0)
+
     def restore_state(self, path):
         """Inverse of save_state.  All device buffers are overwritten IN PLACE, so plans captured before the call
         keep replaying on the restored state."""
@@ -335,11 +365,9 @@ class Optimizer:
         sess = self.model._session
         torch = sess.torch
         p = path if path.endswith(".npz") else path + ".npz"
-        with np.load(p, allow_pickle=True) as f:
-            layout = sorted((v.long_name, o, s) for v in self.model.get_variables()
-                            for o, s in [sess._offsets.get(id(v), (-1, -1))] if o >= 0)
-            saved = [tuple(r) for r in f["layout"].tolist()]
-            if [(a, int(b), int(c)) for a, b, c in saved] != layout:
+        with np.load(p, allow_pickle=False) as f:
+            saved = [(str(a), int(b), int(c)) for a, (b, c) in zip(f["layout_names"].tolist(), f["layout_spans"].tolist())]
+            if saved != self._layout_rows():
                 raise ValueError("checkpoint %s was written for a different parameter layout" % p)
             slots = self._optimizer.slots(sess)
             torch.cuda.synchronize()
@@ -376,8 +404,7 @@ class Optimizer:
         grads = G.gradients(obj, leaves)
         outs = [obj] + [g for g in grads if g is not None]
         plan = sess.make_plan(outs, minibatch=minibatch_size)
-        if indices is not None:
-            plan.set_indices(indices)
+        self._apply_indices(plan, indices)
         plan.run()
         plan.check()
         res = {}

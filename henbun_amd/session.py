@@ -312,10 +312,18 @@ class _SessionPlan(G.Plan):
         self.torch.cuda.synchronize()
         self.index_buffer.copy_(self.torch.as_tensor(idx).to(self.device))
         self.torch.cuda.synchronize()
-        changed = (not self.indices_injected) or (self.indices_raw != raw)
         self.indices_injected, self.indices_raw = True, raw
-        if changed:
-            self._graph = None
+        self._graph = self._graphs.get(self._state_key())
+
+    def clear_indices(self):
+        """Back to drawing fresh minibatch indices on every run (reference model.py:232-267 draws per call):
+        injection lasts for the call that asked for it."""
+        if self.indices_injected:
+            self.indices_injected, self.indices_raw = False, False
+            self._graph = self._graphs.get(self._state_key())
+
+    def _state_key(self):
+        return (G.Plan._state_key(self), self.indices_injected, self.indices_raw)
 
     def check(self):
         """Cholesky status (G.Plan.check) and, when the row indices came from the caller, their range: a row index

@@ -352,11 +352,20 @@ int hb_sgp_bwd_f64(int kind, int mode, const double* x, long sx, const double* z
  *   t <- t+1 ; lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
  *   m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; theta <- theta - lr_t m/(sqrt(v)+eps)
  * g is read as gscale*g (gscale = 1/world_size for data-parallel means).
- * t is a device-side step counter (one int64), incremented by the call. */
+ * t is a device-side step counter (one int64), incremented by the call when `tick` != 0 (several
+ * calls on disjoint segments of one parameter set share a step: only the last one ticks).
+ * Failure containment: tf.cholesky raises inside session.run BEFORE apply_gradients (reference
+ * model.py:265-266), leaving the parameters at the last good step.  Calls here are asynchronous,
+ * so the update reads this step's factorisation status words `info[n_info]` (nullable, LAPACK
+ * convention), the other ranks' all-reduced failure flag `dpflag` (nullable, one element) and the
+ * sticky record `fail[2]` (nullable): when any is non-zero the call changes nothing (theta, m, v,
+ * t) and `fail` keeps {step number t+1, status} of the FIRST blocked step until the host clears it. */
 int hb_adam_step_f32(float* theta, const float* g, float* m, float* v, long n, double lr, double b1,
-                     double b2, double eps, double gscale, long* t, void* stream);
+                     double b2, double eps, double gscale, long* t, int tick, const int* info,
+                     long n_info, const float* dpflag, long* fail, void* stream);
 int hb_adam_step_f64(double* theta, const double* g, double* m, double* v, long n, double lr,
-                     double b1, double b2, double eps, double gscale, long* t, void* stream);
+                     double b1, double b2, double eps, double gscale, long* t, int tick,
+                     const int* info, long n_info, const double* dpflag, long* fail, void* stream);
 
 #ifdef __cplusplus
 }

@@ -592,6 +592,50 @@ def test_adam_matches_tf_formula(H, p):
     assert_close(theta, ref, TOL[p] if p == "f64" else dict(rtol=1e-4, atol=1e-5))
 
 
+@pytest.mark.parametrize("n", [1000, 40000])   # one-block form (tick inside) and multi-block form (tick kernel)
+def test_adam_segments_share_a_step_and_failed_factorisations_block_the_update(H, p, n):
+    """hb_adam_step: `tick` lets several segment calls share one step; a non-zero factorisation status word
+    (or the other ranks' flag, or the sticky record) makes the call a no-op and records the first blocked step."""
+    dt = DT[p]
+    rng = np.random.RandomState(1)
+    th = rng.randn(n)
+    ref = O.T(th.copy())
+    opt = O.AdamTF([ref], lr=0.01)
+    theta, m, v = dev(th, dt), dev(np.zeros(n), dt), dev(np.zeros(n), dt)
+    t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    info = torch.zeros(5, dtype=torch.int32, device="cuda")
+    fail = torch.zeros(2, dtype=torch.int64, device="cuda")
+    flag = torch.zeros(1, dtype=dt, device="cuda")
+    h = n // 3
+    for step in range(3):
+        g = rng.randn(n)
+        opt.step([O.T(g)])
+        gd = dev(g, dt)
+        H.adam_step(theta[:h], gd[:h], m[:h], v[:h], t, lr=0.01, tick=False, info=info, dpflag=flag, fail=fail)
+        assert t.item() == step
+        H.adam_step(theta[h:], gd[h:], m[h:], v[h:], t, lr=0.01, tick=True, info=info, dpflag=flag, fail=fail)
+        assert t.item() == step + 1
+    assert_close(theta, ref, TOL[p] if p == "f64" else dict(rtol=1e-4, atol=1e-5))
+    before = [x.clone() for x in (theta, m, v)]
+    info[3] = 7   # "leading minor 7 is not positive definite"
+    H.adam_step(theta, dev(rng.randn(n), dt), m, v, t, lr=0.01, info=info, dpflag=flag, fail=fail)
+    torch.cuda.synchronize()
+    assert t.item() == 3 and fail.tolist() == [4, 7]
+    for a, b in zip(before, (theta, m, v)):
+        assert torch.equal(a, b)
+    info.zero_()      # the record is sticky: a later clean step is still blocked until the host clears it
+    H.adam_step(theta, dev(rng.randn(n), dt), m, v, t, lr=0.01, info=info, dpflag=flag, fail=fail)
+    assert t.item() == 3 and fail.tolist() == [4, 7] and torch.equal(before[0], theta)
+    fail.zero_()
+    flag.fill_(2.0)   # another rank failed
+    H.adam_step(theta, dev(rng.randn(n), dt), m, v, t, lr=0.01, info=info, dpflag=flag, fail=fail)
+    assert t.item() == 3 and fail.tolist() == [4, -1] and torch.equal(before[0], theta)
+    fail.zero_()
+    flag.zero_()
+    H.adam_step(theta, dev(rng.randn(n), dt), m, v, t, lr=0.01, info=info, dpflag=flag, fail=fail)
+    assert t.item() == 4 and fail.tolist() == [0, 0] and not torch.equal(before[0], theta)
+
+
 def test_graph_capture_replay(H):
     dt = torch.float32
     theta = dev(np.ones(100), dt)
