@@ -274,3 +274,109 @@ def test_batched_experts_train_in_graph_mode():
     opt.optimize(maxiter=150, minibatch_size=n)
     e1 = np.mean([opt.run(minibatch_size=n) for _ in range(4)])
     assert np.isfinite(e1) and e1 > e0, (e0, e1)
+
+
+def test_generic_kl_with_normal_prior_and_positive_transform():
+    """Variational._KL, the generic Monte-Carlo KL (reference variationals.py:198-209): a Variational that is NOT
+    the `Normal` class -- priors.Normal on the TRANSFORMED sample (priors.py:44-52) plus the log-Jacobian of a
+    non-identity transform (transforms.py:136-137).  Value and every leaf gradient == the oracle at injected noise,
+    diagonal and full-rank."""
+    rng = np.random.RandomState(4)
+    for q_shape in ("diagonal", "fullrank"):
+        class M(hb.model.Model):
+            def setUp(self):
+                self.v = hb.variationals.Variational([7], q_shape=q_shape, prior=hb.priors.Normal(),
+                                                     transform=hb.transforms.Log1pe())
+
+            @hb.model.AutoOptimize()
+            def obj(self):
+                return tf.reduce_sum(tf.log(self.v)) * 0.7 - self.KL()
+
+        np.random.seed(4)
+        m = M(dtype="float64")
+        if q_shape == "fullrank":
+            m.v.q_sqrt = 0.5 * np.eye(7) + 0.1 * rng.randn(7, 7)
+        u = rng.randn(7)
+        m.v.inject_noise(u)
+        opt = m.obj()
+        opt.compile()
+        val, grads = opt.gradients()
+        s = m._session
+        params = {"q_mu": O.T(s.read_raw(m.v.q_mu)), "q_sqrt": O.T(s.read_raw(m.v.q_sqrt))}
+
+        def fn(p):
+            x = (O.sample_diag if q_shape == "diagonal" else O.sample_fullrank)(p["q_mu"], p["q_sqrt"], O.T(u))
+            kl = O.kl_generic(p["q_sqrt"], O.T(u), x, q_shape, prior_logp=O.prior_normal_logp,
+                              transform=O.log1pe_forward, log_jacobian=O.log1pe_log_jacobian)
+            return 0.7 * torch.sum(torch.log(O.log1pe_forward(x))) - kl
+
+        ref_val, ref = O.grads_of(fn, params)
+        assert abs(val - ref_val.item()) <= 1e-10 * abs(ref_val.item()), (q_shape, val, ref_val.item())
+        assert rel_err(grads["model.v.q_mu"], ref["q_mu"].numpy()) <= 1e-9
+        assert rel_err(grads["model.v.q_sqrt"], ref["q_sqrt"].numpy()) <= 1e-9
+        # with the identity transform the generic form equals Normal._KL (variationals.py:213-230)
+        x = O.sample_diag(params["q_mu"], params["q_sqrt"], O.T(u)) if q_shape == "diagonal" else None
+        if x is not None:
+            assert np.isclose(O.kl_generic(params["q_sqrt"], O.T(u), x, q_shape, prior_logp=O.prior_normal_logp).item(),
+                              O.kl_normal(params["q_sqrt"], O.T(u), x, q_shape).item())
+
+
+def test_offset_gaussian_value_and_gradients():
+    """variationals.OffsetGaussian = scale * Normal + offset (reference variationals.py:293-314)."""
+    np.random.seed(6)
+    rng = np.random.RandomState(6)
+
+    class M(hb.model.Model):
+        def setUp(self):
+            self.g = hb.variationals.OffsetGaussian([4, 3], mean=1.5, stddev=0.4)
+
+        @hb.model.AutoOptimize()
+        def obj(self):
+            return tf.reduce_sum(tf.square(self.g - 1.0)) * -0.5 - self.KL()
+
+    m = M(dtype="float64")
+    u = rng.randn(12)
+    m.g.inject_noise(u)
+    opt = m.obj()
+    opt.compile()
+    val, grads = opt.gradients()
+    s = m._session
+    params = {"q_mu": O.T(s.read_raw(m.g.q_mu)), "q_sqrt": O.T(s.read_raw(m.g.q_sqrt)),
+              "scale_raw": O.T(s.read_raw(m.g.scale)), "offset": O.T(s.read_raw(m.g.offset))}
+    assert params["scale_raw"].shape == (1, 1) and params["offset"].shape == (1, 1)   # default shape [1]*rank
+
+    def fn(p):
+        x = O.sample_diag(p["q_mu"], p["q_sqrt"], O.T(u))
+        g = O.log1pe_forward(p["scale_raw"]) * x.reshape(4, 3) + p["offset"]
+        return -0.5 * torch.sum(torch.square(g - 1.0)) - O.kl_normal(p["q_sqrt"], O.T(u), x, "diagonal")
+
+    ref_val, ref = O.grads_of(fn, params)
+    assert abs(val - ref_val.item()) <= 1e-10 * abs(ref_val.item())
+    for mine, theirs in (("model.g.q_mu", "q_mu"), ("model.g.q_sqrt", "q_sqrt"), ("model.g.scale", "scale_raw"),
+                         ("model.g.offset", "offset")):
+        assert rel_err(grads[mine], ref[theirs].numpy()) <= 1e-9, mine
+
+
+@pytest.mark.parametrize("dtype,atol", [("float64", 1e-10), ("float32", 1e-4)])  # reference test_nn.py: atol 1e-4
+def test_layered_neural_net_golden(golden, dtype, atol):
+    """NeuralNet([3, 2, 4], n_layers=[5]) with layered weights w:[5,in,out], b:[5,1,out] (reference nn.py:10-32,
+    testing/test_nn.py:11-29) against the golden chain `n_y`, on the device."""
+    g = golden
+
+    class M(hb.model.Model):
+        def setUp(self):
+            self.net = hb.nn.NeuralNet([3, 2, 4], n_layers=[5])
+            self.x = hb.param.Data(g["n_x"])
+
+        @hb.model.AutoOptimize()
+        def obj(self):
+            return tf.reduce_sum(self.net(self.x))
+
+    m = M(dtype=dtype)
+    m.net.matbias0.w, m.net.matbias0.b = g["n_w1"], g["n_b1"]
+    m.net.matbias1.w, m.net.matbias1.b = g["n_w2"], g["n_b2"]
+    with m.tf_mode():
+        y = m.run(m.net(m.x))
+    assert y.shape == (5, 6, 4)
+    assert np.abs(y - g["n_y"]).max() <= atol
+    assert np.isclose(m.obj().run(), g["n_y"].sum(), rtol=1e-4 if dtype == "float32" else 1e-10)

@@ -592,6 +592,7 @@ def test_adam_matches_tf_formula(H, p):
     assert_close(theta, ref, TOL[p] if p == "f64" else dict(rtol=1e-4, atol=1e-5))
 
 
+@pytest.mark.parametrize("p", ["f32", "f64"])
 @pytest.mark.parametrize("n", [1000, 40000])   # one-block form (tick inside) and multi-block form (tick kernel)
 def test_adam_segments_share_a_step_and_failed_factorisations_block_the_update(H, p, n):
     """hb_adam_step: `tick` lets several segment calls share one step; a non-zero factorisation status word
