@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libhenbun_hip.so")
-SOURCES = ["runtime", "elementwise", "rng", "variational", "gram", "linalg", "sgp", "adam"]
+SOURCES = ["runtime", "elementwise", "rng", "variational", "gram", "linalg", "sgp", "adam", "comm"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wno-unused-result"]
 
@@ -70,7 +70,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

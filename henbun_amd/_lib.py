@@ -36,6 +36,10 @@ _SIGS = {
     "hb_sgp_ws_elems": [L, L, L, L, L],
     "hb_ewise_prog_image_bytes": [],
     "hb_ewise_prog_build": [I, P, P, I, P, P, I, P, P, P, I, P, P, P, P],
+    "hb_comm_available": [],
+    "hb_comm_unique_id": [P],
+    "hb_comm_init": [P, I, I, P],
+    "hb_comm_destroy": [P],
 }
 _RESTYPES = {"hb_last_error_string": c_char_p, "hb_sgp_ws_elems": c_long, "hb_ewise_prog_image_bytes": c_long}
 
@@ -67,6 +71,8 @@ _TYPED = {
     "hb_sgp_fwd": [I, I, P, L, P, P, L, P, P, P, P, L, P, P, P, P, L, L, L, L, L, P, P],
     "hb_sgp_bwd": [I, I, P, L, P, P, L, P, P, P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P],
     "hb_adam_step": [P, P, P, P, L, D, D, D, D, D, P, I, P, L, P, P, P],
+    "hb_allreduce_sum": [P, L, P, P],
+    "hb_dp_pack": [P, P, P, L, P],
 }
 
 

@@ -1644,6 +1644,7 @@ class Plan:
         self.stream = stream          # torch.cuda.Stream the plan runs on (None = current)
         self.side_effect_steps = set()  # steps skipped by the capture warm-up (e.g. the Adam update)
         self.step_labels = {}           # id(step closure) -> op label (profiling)
+        self.step_nodes = {}            # id(step closure) -> graph Node that emitted it (work models in bench.py)
         self.noise_inputs: Dict[Tensor, object] = {}
         self._injected: Dict[Tensor, bool] = {}
         self._leaf_resolver = leaf_resolver
@@ -1776,6 +1777,7 @@ class Plan:
         label = n.op if n.op != "ew" else "ew:" + n.attrs["f"]
         for s in self.steps[before:]:
             self.step_labels[id(s)] = label
+            self.step_nodes[id(s)] = n
 
     def _emit_cluster(self, c):
         """One hb_ewise_prog launch for the whole cluster."""

@@ -657,6 +657,20 @@ def adam_step(theta, g, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0
                     _p(dpflag) if dpflag is not None else None, _p(fail) if fail is not None else None, stream())
 
 
+# ---- data-parallel exchange ---------------------------------------------------------
+def allreduce_sum(flat, comm_handle):
+    """In-place RCCL all-reduce (sum) of a contiguous device buffer on the current stream."""
+    _chk(flat)
+    _lib.lib().call("hb_allreduce_sum" + _suf(flat), _p(flat), flat.numel(), comm_handle, stream())
+
+
+def dp_pack(tail, objective, info):
+    """tail[0] = objective, tail[1] = any(info != 0)  (hb_dp_pack)."""
+    assert tail.numel() == 2
+    n_info = 0 if info is None else info.numel()
+    _lib.lib().call("hb_dp_pack" + _suf(tail), _p(tail), _p(objective), _p(info) if n_info else None, n_info, stream())
+
+
 # ---- hipGraph capture ---------------------------------------------------------------
 class CapturedGraph:
     """A replayable hipGraph of whatever was launched between begin() and end()."""

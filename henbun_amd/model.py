@@ -186,7 +186,24 @@ class Optimizer:
     def _settings_key(self):
         n = settings.numerics
         return (n.jitter_level, n.clip_by_value, n.clip_value_min, n.clip_value_max,
-                str(settings.runtime.index_source), bool(settings.runtime.fuse_elementwise))
+                str(settings.runtime.index_source), bool(settings.runtime.fuse_elementwise),
+                bool(getattr(settings.runtime, "force_dp", False)))
+
+    @staticmethod
+    def _dp_active(sess):
+        """Data-parallel step: more than one rank, or `settings.runtime.force_dp` (runs the exchange step with a
+        one-rank communicator: how the multi-rank code path is exercised on a one-GPU box)."""
+        return sess.world_size > 1 or bool(getattr(settings.runtime, "force_dp", False))
+
+    def dp_objective(self):
+        """Mean over ranks of the objective of the last optimisation step (it rides behind the gradient in the
+        all-reduce); None outside data-parallel runs."""
+        plan = self.last_plan
+        if plan is None or getattr(plan, "dp_mode", "none") == "none":
+            return None
+        plan.stream.synchronize() if plan.stream is not None else plan.torch.cuda.synchronize()
+        sess = self.model._session
+        return float(plan.gflat[sess.theta.numel()].item()) / max(sess.world_size, 1)
 
     def _get_plan(self, kind, minibatch, training=True):
         sess = self.model._session
@@ -212,7 +229,10 @@ class Optimizer:
             grads = [g if g is None or not g.node.op.startswith("leaf:") else G.unary("COPY", g)
                      for g in G.gradients(obj, leaves)]
             torch = sess.torch
-            gflat = torch.zeros(sess.theta.numel(), dtype=sess.torch_dtype, device=sess.device)
+            # [gradient of every global leaf | objective value | failure flag]: the two tail words travel with the
+            # gradient through the data-parallel all-reduce (hb_dp_pack)
+            P = sess.theta.numel()
+            gflat = torch.zeros(P + 2, dtype=sess.torch_dtype, device=sess.device)
             binds, segs = [], []
             for t, g in zip(leaves, grads):
                 o, s = sess._offsets[id(t.node.attrs["var"])]
@@ -252,9 +272,32 @@ class Optimizer:
 
             plan.dpflag = None
             plan.adam = adam
-            if sess.world_size == 1:
+            plan.eager_tail = []
+            plan.dp_mode = "none"
+            if not self._dp_active(sess):
                 plan.steps.append(adam)
                 plan.side_effect_steps.add(adam)
+            else:
+                # data parallel: [forward + backward] -> pack -> ONE all-reduce of the whole flat buffer -> Adam.
+                # With RCCL behind the C ABI the exchange is issued on the plan's stream and is part of the
+                # captured graph; otherwise (no RCCL for this group) it runs eagerly through torch.distributed.
+                tail, objbuf = gflat[P:P + 2], plan.buf(obj)
+                plan.dpflag = gflat[P + 1:P + 2]
+
+                def pack():
+                    H.dp_pack(tail, objbuf, info)
+
+                comm = parallel.Communicator.create(sess.device)
+                if comm is not None and comm.graph_safe(sess):
+                    plan.steps += [pack, lambda: comm.allreduce_sum(gflat), adam]
+                    plan.side_effect_steps.add(adam)
+                    plan.dp_mode = "rccl-in-graph"
+                elif comm is not None:
+                    plan.eager_tail = [pack, lambda: comm.allreduce_sum(gflat), adam]
+                    plan.dp_mode = "rccl-eager"
+                else:
+                    plan.eager_tail = [pack, lambda: parallel.allreduce_gradient(gflat), adam]
+                    plan.dp_mode = "torch-eager"
         if settings.runtime.graph_capture:
             plan.capture()
         self._plans[key] = plan
@@ -298,19 +341,24 @@ class Optimizer:
         self._ensure_compiled()
         plan = self._get_plan("opt", minibatch_size)
         self._apply_indices(plan, indices)
-        sess = self.model._session
-        if sess.world_size == 1:
-            for _ in range(int(maxiter)):
-                plan.run()
-        else:
-            for _ in range(int(maxiter)):
-                plan.run()
-                with plan._on_stream():
-                    parallel.allreduce_gradient(plan.gflat, plan.segments)
-                    plan.adam()
+        self._run_steps(plan, int(maxiter))
         self.last_plan = plan
         self._check_step_failure(plan)
         plan.check()
+
+    @staticmethod
+    def _run_steps(plan, k):
+        """`k` asynchronous optimisation steps of a compiled 'opt' plan (one graph launch each; plus the eager
+        exchange + update when the data-parallel tail could not be captured)."""
+        if not plan.eager_tail:
+            for _ in range(k):
+                plan.run()
+        else:
+            for _ in range(k):
+                plan.run()
+                with plan._on_stream():
+                    for s in plan.eager_tail:
+                        s()
 
     def _check_step_failure(self, plan):
         """Raise CholeskyError if an update was blocked by a failed factorisation.  The parameters, Adam slots and

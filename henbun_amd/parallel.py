@@ -53,6 +53,103 @@ def allreduce_gradient(flat, segments=None):
     return flat
 
 
+class Communicator:
+    """This rank's RCCL communicator behind the C ABI (hb_comm_init / hb_allreduce_sum).
+
+    The 128-byte rendezvous token is created on rank 0 and handed round with torch.distributed's object broadcast
+    (any backend); the collective itself never goes through torch, so it can be issued on the plan's own HIP
+    stream and captured into the step graph.  `Communicator.create()` returns None when RCCL cannot serve this
+    process group (not resolvable, or several ranks sharing one device in the one-GPU rehearsal): the caller then
+    keeps torch.distributed's all_reduce, eagerly."""
+
+    _cached = {}
+
+    def __init__(self, handle, rank, world_size):
+        self.handle, self.rank, self.world_size = handle, rank, world_size
+
+    @classmethod
+    def create(cls, device):
+        import ctypes
+        import os
+
+        import torch.distributed as dist
+
+        from . import _lib
+
+        rank, ws = world()
+        key = (rank, ws, str(device))
+        if key in cls._cached:
+            return cls._cached[key]
+        lib = _lib.lib()
+        ok = bool(lib.raw("hb_comm_available")()) and not os.environ.get("HENBUN_ONE_DEVICE")
+        if dist.is_available() and dist.is_initialized() and ws > 1:
+            # every rank must take the same decision
+            votes = [None] * ws
+            dist.all_gather_object(votes, ok)
+            ok = all(votes)
+        comm = None
+        if ok:
+            buf = ctypes.create_string_buffer(128)
+            if rank == 0:
+                lib.call("hb_comm_unique_id", buf)
+            token = [buf.raw]
+            if dist.is_available() and dist.is_initialized() and ws > 1:
+                dist.broadcast_object_list(token, src=0)
+            handle = ctypes.c_void_p(None)
+            lib.call("hb_comm_init", ctypes.create_string_buffer(token[0], 128), rank, ws, ctypes.byref(handle))
+            comm = cls(handle, rank, ws)
+        cls._cached[key] = comm
+        return comm
+
+    def graph_safe(self, session):
+        """True when an RCCL all-reduce captured into a hipGraph replays correctly for this communicator: a
+        1024-element buffer of (rank + 1) is reduced by a captured graph, replayed twice, and compared with the
+        closed form R(R+1)/2 on every rank; the ranks then agree on the verdict.  Checked once."""
+        if getattr(self, "_graph_safe", None) is not None:
+            return self._graph_safe
+        import torch
+
+        from . import hip_ops
+
+        ok = True
+        try:
+            want = float(self.world_size * (self.world_size + 1) // 2)
+            x = torch.empty(1024, dtype=torch.float32, device=session.device)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(session.stream):
+                x.fill_(float(self.rank + 1))
+                hip_ops.allreduce_sum(x, self.handle)          # eager warm-up (connection set-up happens here)
+                session.stream.synchronize()
+                ok = ok and bool((x == want).all().item())
+                g = hip_ops.CapturedGraph()
+                g.begin()
+                try:
+                    hip_ops.allreduce_sum(x, self.handle)
+                finally:
+                    g.end()
+                for _ in range(2):
+                    x.fill_(float(self.rank + 1))
+                    g.launch()
+                    session.stream.synchronize()
+                    ok = ok and bool((x == want).all().item())
+        except Exception:
+            ok = False
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and self.world_size > 1:
+            votes = [None] * self.world_size
+            dist.all_gather_object(votes, bool(ok))
+            ok = all(votes)
+        self._graph_safe = bool(ok)
+        return self._graph_safe
+
+    def allreduce_sum(self, flat):
+        """In place, asynchronous on the current henbun_amd stream (capturable)."""
+        from . import hip_ops
+
+        hip_ops.allreduce_sum(flat, self.handle)
+
+
 def gradient_scale(world_size, dp_reduce):
     """Factor applied to the summed gradient: 'mean' when every rank's objective
     already estimates the full ELBO from its own minibatch (the usual (N/n)*ll - KL

@@ -367,6 +367,30 @@ int hb_adam_step_f64(double* theta, const double* g, double* m, double* v, long 
                      double b1, double b2, double eps, double gscale, long* t, int tick,
                      const int* info, long n_info, const double* dpflag, long* fail, void* stream);
 
+/* ---- data-parallel exchange step (no reference counterpart: the reference is one tf.Session on one
+ *      device, model.py:57,255-269) --------------------------------------------------
+ * One process per GPU; the ranks exchange ONE all-reduce (sum) of the flat gradient buffer per Adam
+ * step, over RCCL (xGMI inside a node), issued on the caller's stream -- capturable into the step's
+ * hipGraph between the backward kernels and hb_adam_step.
+ *   hb_comm_available   1 when RCCL could be resolved in this process (it is looked up among the already
+ *                       loaded libraries first, then dlopen'ed: the library has no link-time dependency).
+ *   hb_comm_unique_id   (host) 128-byte rendezvous token, created on rank 0 and handed to the other ranks
+ *                       by the launcher's own channel (henbun_amd.parallel uses torch.distributed for that).
+ *   hb_comm_init        collective over all ranks; *comm_out is a (host) handle.
+ *   hb_allreduce_sum    in place over `n` elements, asynchronous on `stream`.
+ *   hb_dp_pack          tail[0] = objective[0] (nullable -> 0), tail[1] = any(info != 0): the two words that
+ *                       ride behind the gradient so that every rank sees the mean objective and a failed
+ *                       factorisation on ANY rank blocks the update on EVERY rank (hb_adam_step's dpflag). */
+#define HB_COMM_ID_BYTES 128
+int hb_comm_available(void);
+int hb_comm_unique_id(char* id128);
+int hb_comm_init(const char* id128, int rank, int world, void** comm_out);
+int hb_comm_destroy(void* comm);
+int hb_allreduce_sum_f32(float* buf, long n, void* comm, void* stream);
+int hb_allreduce_sum_f64(double* buf, long n, void* comm, void* stream);
+int hb_dp_pack_f32(float* tail, const float* objective, const int* info, long n_info, void* stream);
+int hb_dp_pack_f64(double* tail, const double* objective, const int* info, long n_info, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

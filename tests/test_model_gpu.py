@@ -268,8 +268,10 @@ def test_cholesky_failure_is_reported():
         Bad().obj().run()
 
 
-def test_cholesky_failure_inside_optimize_leaves_parameters_at_the_last_good_step():
-    """tf.cholesky raises inside session.run before apply_gradients (reference model.py:265-266): a failing step
+@pytest.mark.parametrize("dp", [False, True])
+def test_cholesky_failure_inside_optimize_leaves_parameters_at_the_last_good_step(dp):
+    """(dp: the same through the data-parallel step, where the failure flag rides behind the gradient in the
+    all-reduce and hb_adam_step reads it back as `dpflag`.)  tf.cholesky raises inside session.run before apply_gradients (reference model.py:265-266): a failing step
     must not touch theta / Adam slots / step count, also when it happens in the middle of a captured replay loop."""
     class Drift(hb.model.Model):
         def setUp(self):
@@ -282,12 +284,20 @@ def test_cholesky_failure_inside_optimize_leaves_parameters_at_the_last_good_ste
             K = tf.eye(2) + self.a * self.B
             return tf.reduce_sum(tf.cholesky(K)) * 1e-9 + tf.reduce_sum(self.a) * 100.0
 
+    cfg = hb.settings.get_settings()
+    cfg.runtime.force_dp = dp
+    with hb.settings.temp_settings(cfg):
+        _drift_body(Drift, dp)
+
+
+def _drift_body(Drift, dp):
     m = Drift(dtype="float64")
     m.a = np.array([0.9])
     opt = m.obj()
     opt.compile(optimizer=tf.train.AdamOptimizer(0.03))
     with pytest.raises(hb.CholeskyError) as e:
         opt.optimize(maxiter=12)        # a: 0.90 -> 0.93 -> 0.96 -> 0.99 -> 1.02 (fails in step 5)
+    assert opt.last_plan.dp_mode == ("rccl-in-graph" if dp else "none")
     assert "last good step" in str(e.value)
     a = float(m.a.value[0])
     assert np.isfinite(a) and abs(a - 1.02) < 1e-6, a      # the last applied update is step 4's
@@ -297,6 +307,46 @@ def test_cholesky_failure_inside_optimize_leaves_parameters_at_the_last_good_ste
     m.a = np.array([0.5])               # the caller may repair and continue
     opt.optimize(maxiter=2)
     assert abs(float(m.a.value[0]) - 0.56) < 2e-3
+
+
+def test_data_parallel_step_on_a_one_rank_rccl_group_is_bit_identical_to_the_single_process_step():
+    """The multi-rank step -- pack -> ONE RCCL all-reduce of the flat gradient (hb_allreduce_sum, on the plan's
+    stream, inside the captured graph) -> Adam with the all-reduced failure flag -- forced with a one-rank `nccl`
+    process group on the one GPU (settings.runtime.force_dp).  A one-rank sum is the identity and the mean's
+    1/R is 1, so ten steps must leave exactly the bits of the plain single-process path."""
+    import random
+
+    import torch.distributed as dist
+
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % random.randint(20000, 40000), rank=0,
+                                world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        out = {}
+        for dp in (False, True):
+            cfg = hb.settings.get_settings()
+            cfg.runtime.force_dp = dp
+            with hb.settings.temp_settings(cfg):
+                np.random.seed(11)
+                X, Y, Z = svgp_data(5000, 64, 1)
+                m = SVGP(X=X, Y=Y, Z=Z, dtype="float32", seed=5)
+                opt = m.ELBO()
+                opt.compile(optimizer=tf.train.AdamOptimizer(0.01))
+                opt.optimize(maxiter=10, minibatch_size=512)
+                plan = opt.last_plan
+                assert plan.is_captured
+                assert plan.dp_mode == ("rccl-in-graph" if dp else "none"), plan.dp_mode
+                torch.cuda.synchronize()
+                out[dp] = (m._session.theta.clone(), plan.gflat.clone(), opt.dp_objective())
+        assert torch.equal(out[False][0], out[True][0]), "parameters after 10 steps differ between the DP and plain step"
+        P = out[True][0].numel()
+        assert torch.equal(out[False][1][:P], out[True][1][:P])
+        assert out[False][2] is None and np.isfinite(out[True][2])
+        assert float(out[True][1][P + 1].item()) == 0.0          # no factorisation failed
+    finally:
+        if own_group:
+            dist.destroy_process_group()
 
 
 def test_injected_indices_last_for_one_call_and_the_plan_is_recaptured():
