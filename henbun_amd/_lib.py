@@ -59,8 +59,10 @@ _TYPED = {
     "hb_rng_normal": [P, L, P, L, P],
     "hb_diag_sample_kl_fwd": [P, P, P, P, L, P, P, P, L, L, L, L, P, P],
     "hb_diag_sample_kl_bwd": [P, P, P, P, P, P, P, L, L, L, L, P],
-    "hb_fullrank_sample_kl_fwd": [P, P, P, P, L, P, P, P, L, L, P, P],
-    "hb_fullrank_sample_kl_bwd": [P, P, P, P, P, P, P, L, L, P],
+    "hb_fullrank_sample_kl_fwd": [P, P, P, P, L, P, P, P, L, L, I, P, P],
+    "hb_fullrank_sample_kl_bwd": [P, P, P, P, P, P, P, L, L, I, P],
+    "hb_vec_to_tri": [P, P, L, L, P],
+    "hb_tri_to_vec": [P, P, L, L, P],
     "hb_gram_fwd": [I, P, L, P, L, P, L, L, P, L, L, L, L, D, P],
     "hb_gram_bwd": [I, P, L, P, L, P, L, L, P, P, P, P, L, L, L, L, P, P],
     "hb_matmul": [P, P, P, L, L, L, L, L, L, L, L, L, L, I, I, D, D, P, L, I, I, P, L, P],

@@ -188,10 +188,20 @@ __global__ void __launch_bounds__(256) rng_fill_kernel(uint64_t* state, long nla
 }
 
 // one wave per output (r,k): coalesced dot over j <= k.  Used for size > 64.
+// Row k of block r of S: dense [rows, size, size] storage, or the packed lower triangle [rows, size(size+1)/2]
+// in row-major order (row k holds its k+1 entries at offset k(k+1)/2: the order of numpy's tril_indices, which is
+// what the reference's disabled vec_to_tri / LowerTriangular hook uses, tf_wraps.py:50-71, transforms.py:182-269).
+// Packed storage halves the bytes the sampler reads (the full-rank q_sqrt of cfg 3 is 4.2 MB dense).
+template <typename T>
+__device__ __forceinline__ const T* fullrank_row(const T* S, long r, long k, long size, int packed) {
+  return packed ? S + r * (size * (size + 1) / 2) + k * (k + 1) / 2 : S + (r * size + k) * size;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) fullrank_fwd_wave_kernel(const T* __restrict__ mu, const T* __restrict__ S,
                                                                 const T* __restrict__ u, T* __restrict__ x,
-                                                                T* __restrict__ partial, long rows, long size) {
+                                                                T* __restrict__ partial, long rows, long size,
+                                                                int packed) {
   __shared__ T smem[16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long nout = rows * size;
@@ -199,7 +209,7 @@ __global__ void __launch_bounds__(256) fullrank_fwd_wave_kernel(const T* __restr
   T acc = T(0);
   for (long o = (long)blockIdx.x * 4 + w; o < nout; o += wstride) {
     const long r = o / size, k = o - r * size;
-    const T* Srow = S + (r * size + k) * size;
+    const T* Srow = fullrank_row(S, r, k, size, packed);
     const T* ur = u + r * size;
     // four row segments in flight per step (same summation order as the plain loop: deterministic)
     T dot = T(0);
@@ -229,14 +239,15 @@ __global__ void __launch_bounds__(256) fullrank_fwd_wave_kernel(const T* __restr
 template <typename T>
 __global__ void __launch_bounds__(256) fullrank_fwd_thread_kernel(const T* __restrict__ mu, const T* __restrict__ S,
                                                                   const T* __restrict__ u, T* __restrict__ x,
-                                                                  T* __restrict__ partial, long rows, long size) {
+                                                                  T* __restrict__ partial, long rows, long size,
+                                                                  int packed) {
   __shared__ T smem[16];
   const long nout = rows * size;
   const long stride = (long)gridDim.x * blockDim.x;
   T acc = T(0);
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < nout; o += stride) {
     const long r = o / size, k = o - r * size;
-    const T* Srow = S + (r * size + k) * size;
+    const T* Srow = fullrank_row(S, r, k, size, packed);
     const T* ur = u + r * size;
     T dot = T(0);
     for (long j = 0; j <= k; ++j) dot += Srow[j] * ur[j];
@@ -251,7 +262,7 @@ __global__ void __launch_bounds__(256) fullrank_fwd_thread_kernel(const T* __res
 
 template <typename T>
 static int fullrank_fwd(const T* mu, const T* S, const T* u_in, uint64_t* rng, long rng_lanes, T* u_out, T* x, T* kl,
-                        long rows, long size, T* ws, hipStream_t stream) {
+                        long rows, long size, int packed, T* ws, hipStream_t stream) {
   HB_REQUIRE(rows >= 0 && size >= 0, "hb_fullrank_sample_kl_fwd: negative extent");
   HB_REQUIRE(mu && S && x && kl && ws, "hb_fullrank_sample_kl_fwd: NULL pointer");
   HB_REQUIRE(u_in || (rng && rng_lanes > 0 && u_out), "hb_fullrank_sample_kl_fwd: need u_in, or rng and u_out");
@@ -272,10 +283,12 @@ static int fullrank_fwd(const T* mu, const T* S, const T* u_in, uint64_t* rng, l
     grid = (int)((n + 3) / 4);
     if (grid > HB_KL_MAX_PARTIALS) grid = HB_KL_MAX_PARTIALS;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(fullrank_fwd_wave_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, S, u, x, ws, rows, size);
+    hipLaunchKernelGGL(fullrank_fwd_wave_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, S, u, x, ws, rows, size,
+                       packed);
   } else {
     grid = hb_stream_grid(n, 256);
-    hipLaunchKernelGGL(fullrank_fwd_thread_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, S, u, x, ws, rows, size);
+    hipLaunchKernelGGL(fullrank_fwd_thread_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, S, u, x, ws, rows, size,
+                       packed);
   }
   HB_LAUNCH_CHECK();
   hipLaunchKernelGGL(kl_finish_kernel<T>, dim3(1), dim3(256), 0, stream, ws, grid, kl);
@@ -285,13 +298,13 @@ static int fullrank_fwd(const T* mu, const T* S, const T* u_in, uint64_t* rng, l
 
 extern "C" int hb_fullrank_sample_kl_fwd_f32(const float* mu, const float* S, const float* u_in, uint64_t* rng,
                                              long rng_lanes, float* u_out, float* x, float* kl, long rows, long size,
-                                             float* ws, void* stream) {
-  return fullrank_fwd<float>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, ws, (hipStream_t)stream);
+                                             int packed, float* ws, void* stream) {
+  return fullrank_fwd<float>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, packed, ws, (hipStream_t)stream);
 }
 extern "C" int hb_fullrank_sample_kl_fwd_f64(const double* mu, const double* S, const double* u_in, uint64_t* rng,
                                              long rng_lanes, double* u_out, double* x, double* kl, long rows,
-                                             long size, double* ws, void* stream) {
-  return fullrank_fwd<double>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, ws, (hipStream_t)stream);
+                                             long size, int packed, double* ws, void* stream) {
+  return fullrank_fwd<double>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, packed, ws, (hipStream_t)stream);
 }
 
 template <typename T>
@@ -318,25 +331,108 @@ __global__ void __launch_bounds__(256) fullrank_bwd_kernel(const T* __restrict__
   }
 }
 
+// index of the row that holds packed offset p (p = k(k+1)/2 + j, j <= k)
+__device__ __forceinline__ long tri_row_of(long p) {
+  long k = (long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+  while (k * (k + 1) / 2 > p) --k;
+  while ((k + 1) * (k + 2) / 2 <= p) ++k;
+  return k;
+}
+
+// the same gradient written as the packed lower triangle [rows, size(size+1)/2] (S is packed too)
+template <typename T>
+__global__ void __launch_bounds__(256) fullrank_bwd_packed_kernel(const T* __restrict__ S, const T* __restrict__ u,
+                                                                  const T* __restrict__ x, const T* __restrict__ xbar,
+                                                                  const T* __restrict__ klbar, T* __restrict__ mubar,
+                                                                  T* __restrict__ Sbar, long rows, long size) {
+  const T kb = klbar ? klbar[0] : T(0);
+  const long tri = size * (size + 1) / 2;
+  const long total = rows * tri;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long r = t / tri, p = t - r * tri;
+    const long k = tri_row_of(p), j = p - k * (k + 1) / 2;
+    const long rk = r * size + k;
+    const T mb = (xbar ? xbar[rk] : T(0)) + kb * x[rk];
+    if (j == 0) mubar[rk] = mb;
+    Sbar[t] = j < k ? mb * u[r * size + j] : mb * u[rk] - kb / S[t];
+  }
+}
+
 template <typename T>
 static int fullrank_bwd(const T* S, const T* u, const T* x, const T* xbar, const T* klbar, T* mubar, T* Sbar,
-                        long rows, long size, hipStream_t stream) {
+                        long rows, long size, int packed, hipStream_t stream) {
   HB_REQUIRE(rows >= 0 && size >= 0, "hb_fullrank_sample_kl_bwd: negative extent");
   HB_REQUIRE(S && u && x && mubar && Sbar, "hb_fullrank_sample_kl_bwd: NULL pointer");
-  const long total = rows * size * size;
+  const long total = packed ? rows * (size * (size + 1) / 2) : rows * size * size;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(fullrank_bwd_kernel<T>, dim3(hb_stream_grid(total, 256)), dim3(256), 0, stream, S, u, x, xbar,
-                     klbar, mubar, Sbar, rows, size);
+  if (packed)
+    hipLaunchKernelGGL(fullrank_bwd_packed_kernel<T>, dim3(hb_stream_grid(total, 256)), dim3(256), 0, stream, S, u, x,
+                       xbar, klbar, mubar, Sbar, rows, size);
+  else
+    hipLaunchKernelGGL(fullrank_bwd_kernel<T>, dim3(hb_stream_grid(total, 256)), dim3(256), 0, stream, S, u, x, xbar,
+                       klbar, mubar, Sbar, rows, size);
   HB_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int hb_fullrank_sample_kl_bwd_f32(const float* S, const float* u, const float* x, const float* xbar,
                                              const float* klbar, float* mubar, float* Sbar, long rows, long size,
-                                             void* stream) {
-  return fullrank_bwd<float>(S, u, x, xbar, klbar, mubar, Sbar, rows, size, (hipStream_t)stream);
+                                             int packed, void* stream) {
+  return fullrank_bwd<float>(S, u, x, xbar, klbar, mubar, Sbar, rows, size, packed, (hipStream_t)stream);
 }
 extern "C" int hb_fullrank_sample_kl_bwd_f64(const double* S, const double* u, const double* x, const double* xbar,
                                              const double* klbar, double* mubar, double* Sbar, long rows, long size,
-                                             void* stream) {
-  return fullrank_bwd<double>(S, u, x, xbar, klbar, mubar, Sbar, rows, size, (hipStream_t)stream);
+                                             int packed, void* stream) {
+  return fullrank_bwd<double>(S, u, x, xbar, klbar, mubar, Sbar, rows, size, packed, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// vec_to_tri / tri_to_vec: the reference's (disabled) native op pair, Henbun/tf_wraps.py:50-71 -- a [B, N(N+1)/2]
+// vector <-> [B, N, N] lower-triangular matrices, entries in numpy tril_indices order (transforms.py:225-244).
+// Each is the other's gradient (tf_wraps.py:56-58).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) vec_to_tri_kernel(const T* __restrict__ v, T* __restrict__ tri, long B, long N) {
+  const long total = B * N * N, tsz = N * (N + 1) / 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long b = t / (N * N), rem = t - b * N * N;
+    const long i = rem / N, j = rem - i * N;
+    tri[t] = j <= i ? v[b * tsz + i * (i + 1) / 2 + j] : T(0);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) tri_to_vec_kernel(const T* __restrict__ tri, T* __restrict__ v, long B, long N) {
+  const long tsz = N * (N + 1) / 2, total = B * tsz;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long b = t / tsz, p = t - b * tsz;
+    const long i = tri_row_of(p), j = p - i * (i + 1) / 2;
+    v[t] = tri[(b * N + i) * N + j];
+  }
+}
+template <typename T>
+static int tri_pack_launch(const T* src, T* dst, long B, long N, bool to_tri, hipStream_t stream) {
+  HB_REQUIRE(B >= 0 && N >= 0, "hb_vec_to_tri / hb_tri_to_vec: negative extent");
+  const long total = to_tri ? B * N * N : B * (N * (N + 1) / 2);
+  if (total == 0) return 0;
+  HB_REQUIRE(src && dst, "hb_vec_to_tri / hb_tri_to_vec: NULL pointer");
+  if (to_tri)
+    hipLaunchKernelGGL(vec_to_tri_kernel<T>, dim3(hb_stream_grid(total, 256)), dim3(256), 0, stream, src, dst, B, N);
+  else
+    hipLaunchKernelGGL(tri_to_vec_kernel<T>, dim3(hb_stream_grid(total, 256)), dim3(256), 0, stream, src, dst, B, N);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_vec_to_tri_f32(const float* v, float* tri, long B, long N, void* stream) {
+  return tri_pack_launch<float>(v, tri, B, N, true, (hipStream_t)stream);
+}
+extern "C" int hb_vec_to_tri_f64(const double* v, double* tri, long B, long N, void* stream) {
+  return tri_pack_launch<double>(v, tri, B, N, true, (hipStream_t)stream);
+}
+extern "C" int hb_tri_to_vec_f32(const float* tri, float* v, long B, long N, void* stream) {
+  return tri_pack_launch<float>(tri, v, B, N, false, (hipStream_t)stream);
+}
+extern "C" int hb_tri_to_vec_f64(const double* tri, double* v, long B, long N, void* stream) {
+  return tri_pack_launch<double>(tri, v, B, N, false, (hipStream_t)stream);
 }

@@ -1171,13 +1171,19 @@ defop("diag_sample_kl", _diag_skl_emit, _diag_skl_vjp)
 defop("diag_sample_kl_grad", _diag_skl_grad_emit, None)
 
 
-def fullrank_sample_kl(mu, S, u=None, stream="global") -> Tuple[Tensor, Tensor, Tensor]:
+def fullrank_sample_kl(mu, S, u=None, stream="global", packed=False) -> Tuple[Tensor, Tensor, Tensor]:
     """(x, kl, u):  x = mu + tril(S) u ; kl = -0.5 sum(log S_kk^2 + u^2 - x^2)
-    (reference variationals.py:144-146, :186, :225-230)."""
+    (reference variationals.py:144-146, :186, :225-230).  packed: S holds the lower triangle only,
+    [..., size(size+1)/2] in tril_indices order (half the bytes read; the gradient comes back packed)."""
     mu, S = as_tensor(mu), as_tensor(S)
-    assert S.shape == mu.shape + (mu.shape[-1],)
+    size = mu.shape[-1]
+    if packed:
+        assert S.shape == mu.shape[:-1] + (size * (size + 1) // 2,)
+    else:
+        assert S.shape == mu.shape + (size,)
     ins = (mu, S) if u is None else (mu, S, as_tensor(u))
-    n = make("fullrank_sample_kl", ins, {"stream": stream}, [mu.shape, (1,), mu.shape], unique=u is None)
+    n = make("fullrank_sample_kl", ins, {"stream": stream, "packed": bool(packed)}, [mu.shape, (1,), mu.shape],
+             unique=u is None)
     return n.outputs[0], n.outputs[1], n.outputs[2]
 
 
@@ -1187,7 +1193,8 @@ def _fr_skl_emit(plan, node):
     u_in = plan.buf(node.inputs[2]) if len(node.inputs) > 2 else None
     outs = tuple(plan.out(t) for t in node.outputs)
     rng = None if u_in is not None else plan.rng(node.attrs["stream"])
-    plan.steps.append(lambda: H.fullrank_sample_kl_fwd(mu, S, u_in=u_in, rng=rng, out=outs))
+    packed = bool(node.attrs.get("packed", False))
+    plan.steps.append(lambda: H.fullrank_sample_kl_fwd(mu, S, u_in=u_in, rng=rng, out=outs, packed=packed))
 
 
 def _fr_skl_vjp(node, gs):
@@ -1197,7 +1204,7 @@ def _fr_skl_vjp(node, gs):
     x, kl, u = node.outputs
     S = node.inputs[1]
     ins = [S, u, x]
-    flags = {"has_x": gx is not None, "has_kl": gkl is not None}
+    flags = {"has_x": gx is not None, "has_kl": gkl is not None, "packed": bool(node.attrs.get("packed", False))}
     if gx is not None:
         ins.append(gx)
     if gkl is not None:
@@ -1218,11 +1225,36 @@ def _fr_skl_grad_emit(plan, node):
     if node.attrs["has_kl"]:
         klbar = bufs[k]
     outs = tuple(plan.out(t) for t in node.outputs)
-    plan.steps.append(lambda: H.fullrank_sample_kl_bwd(S, u, x, xbar, klbar, out=outs))
+    packed = bool(node.attrs.get("packed", False))
+    plan.steps.append(lambda: H.fullrank_sample_kl_bwd(S, u, x, xbar, klbar, out=outs, packed=packed))
 
 
 defop("fullrank_sample_kl", _fr_skl_emit, _fr_skl_vjp)
 defop("fullrank_sample_kl_grad", _fr_skl_grad_emit, None)
+
+
+def vec_to_tri(v) -> Tensor:
+    """[..., N(N+1)/2] -> lower-triangular [..., N, N]: the reference's disabled native op (tf_wraps.py:50-71);
+    its gradient is tri_to_vec (tf_wraps.py:56-58)."""
+    v = as_tensor(v)
+    T = v.shape[-1]
+    N = int((8 * T + 1) ** 0.5 / 2.0 - 0.5 + 1e-9)
+    if N * (N + 1) // 2 != T:
+        raise ValueError("vec_to_tri: %d is not a triangular number" % T)
+    return make("vec_to_tri", (v,), {}, [v.shape[:-1] + (N, N)]).outputs[0]
+
+
+def tri_to_vec(t) -> Tensor:
+    t = as_tensor(t)
+    N = t.shape[-1]
+    assert t.shape[-2] == N
+    return make("tri_to_vec", (t,), {}, [t.shape[:-2] + (N * (N + 1) // 2,)]).outputs[0]
+
+
+defop("vec_to_tri", lambda plan, node: (lambda a, o: plan.steps.append(lambda: plan.H.vec_to_tri(a, out=o)))(
+    plan.buf(node.inputs[0]), plan.out(node.outputs[0])), lambda node, gs: [None if gs[0] is None else tri_to_vec(gs[0])])
+defop("tri_to_vec", lambda plan, node: (lambda a, o: plan.steps.append(lambda: plan.H.tri_to_vec(a, out=o)))(
+    plan.buf(node.inputs[0]), plan.out(node.outputs[0])), lambda node, gs: [None if gs[0] is None else vec_to_tri(gs[0])])
 
 KERN_KINDS = {"rbf": 0, "csym_rbf": 1, "sqdist": 2}
 

@@ -373,11 +373,13 @@ def diag_sample_kl_bwd(s, u, x, xbar, klbar, out=None, rows=None):
     return mubar, sbar
 
 
-def fullrank_sample_kl_fwd(mu, S, u_in=None, rng=None, out=None):
-    """x_r = mu_r + tril(S_r) u_r over rows; S [..., size, size]."""
+def fullrank_sample_kl_fwd(mu, S, u_in=None, rng=None, out=None, packed=False):
+    """x_r = mu_r + tril(S_r) u_r over rows; S [..., size, size], or packed [..., size(size+1)/2] (lower triangle,
+    tril_indices order)."""
     _chk(mu), _chk(S)
     size = mu.shape[-1]
     rows = mu.numel() // max(size, 1)
+    assert S.numel() == rows * (size * (size + 1) // 2 if packed else size * size)
     if out is None:
         x, kl, u = _empty_like(mu), _empty(1, dtype=mu.dtype, device=mu.device), _empty_like(mu)
     else:
@@ -385,11 +387,11 @@ def fullrank_sample_kl_fwd(mu, S, u_in=None, rng=None, out=None):
     ws = workspace(mu.dtype, mu.device)
     rp, rl = _rng_args(rng)
     _lib.lib().call("hb_fullrank_sample_kl_fwd" + _suf(mu), _p(mu), _p(S), _p(u_in), rp, rl, _p(u), _p(x), _p(kl),
-                    rows, size, _p(ws), stream())
+                    rows, size, int(bool(packed)), _p(ws), stream())
     return x, kl, u
 
 
-def fullrank_sample_kl_bwd(S, u, x, xbar, klbar, out=None):
+def fullrank_sample_kl_bwd(S, u, x, xbar, klbar, out=None, packed=False):
     size = u.shape[-1]
     rows = u.numel() // max(size, 1)
     if out is None:
@@ -397,8 +399,38 @@ def fullrank_sample_kl_bwd(S, u, x, xbar, klbar, out=None):
     else:
         mubar, Sbar = out
     _lib.lib().call("hb_fullrank_sample_kl_bwd" + _suf(S), _p(S), _p(u), _p(x), _p(xbar), _p(klbar), _p(mubar),
-                    _p(Sbar), rows, size, stream())
+                    _p(Sbar), rows, size, int(bool(packed)), stream())
     return mubar, Sbar
+
+
+def tri_size(n_packed):
+    """N with N(N+1)/2 == n_packed."""
+    N = int((8 * n_packed + 1) ** 0.5 / 2.0 - 0.5 + 1e-9)
+    if N * (N + 1) // 2 != n_packed:
+        raise ValueError("%d is not a triangular number" % n_packed)
+    return N
+
+
+def vec_to_tri(v, out=None):
+    """[..., N(N+1)/2] -> lower-triangular [..., N, N] (reference tf_wraps.py:50-71)."""
+    _chk(v)
+    N = tri_size(v.shape[-1])
+    B = v.numel() // max(v.shape[-1], 1)
+    if out is None:
+        out = _empty(tuple(v.shape[:-1]) + (N, N), dtype=v.dtype, device=v.device)
+    _lib.lib().call("hb_vec_to_tri" + _suf(v), _p(v), _p(out), B, N, stream())
+    return out
+
+
+def tri_to_vec(tri, out=None):
+    """Lower triangle of [..., N, N] -> [..., N(N+1)/2] (the gradient of vec_to_tri)."""
+    _chk(tri)
+    N = tri.shape[-1]
+    B = tri.numel() // max(N * N, 1)
+    if out is None:
+        out = _empty(tuple(tri.shape[:-2]) + (N * (N + 1) // 2,), dtype=tri.dtype, device=tri.device)
+    _lib.lib().call("hb_tri_to_vec" + _suf(tri), _p(tri), _p(out), B, N, stream())
+    return out
 
 
 # ---- K3 Gram ------------------------------------------------------------------

@@ -183,6 +183,50 @@ class Variable(Parentable):
         return {}
 
 
+def tri_pack(dense):
+    """Lower triangle of [..., N, N] as [..., N(N+1)/2] in numpy tril_indices (row-major) order -- the layout of
+    the reference's LowerTriangular transform (transforms.py:225-244)."""
+    dense = np.asarray(dense)
+    i, j = np.tril_indices(dense.shape[-1])
+    return dense[..., i, j]
+
+
+def tri_unpack(packed):
+    packed = np.asarray(packed)
+    T = packed.shape[-1]
+    N = int((8 * T + 1) ** 0.5 / 2.0 - 0.5 + 1e-9)
+    assert N * (N + 1) // 2 == T, "not a triangular number"
+    out = np.zeros(packed.shape[:-1] + (N, N), dtype=packed.dtype)
+    i, j = np.tril_indices(N)
+    out[..., i, j] = packed
+    return out
+
+
+class TriPackedVariable(Variable):
+    """A lower-triangular [size, size] matrix parameter stored as its packed lower triangle [size(size+1)/2]
+    (the storage the reference sketched with its disabled vec_to_tri hook, tf_wraps.py:50-71).  Reads (`.value`)
+    and deferred assignment speak dense [..., size, size] matrices -- entries above the diagonal do not exist:
+    they read as zero and are dropped on assignment (in the dense form they are stored, masked at use and get a
+    zero gradient, reference variationals.py:94-96,145).  The graph sees the packed vector (`dense_shape` tells
+    consumers the matrix shape): parameter bytes, gradient bytes and the data-parallel all-reduce are halved."""
+
+    def __init__(self, size, n_layers=[], mean=0.0, stddev=1.0, collections=[graph_key.VARIABLES]):
+        size = int(size)
+        self.dense_shape = [size, size]
+        Variable.__init__(self, [size * (size + 1) // 2], n_layers=n_layers, mean=mean, stddev=stddev,
+                          collections=collections)
+
+    def assign(self, value):
+        value = np.asarray(value, dtype=np.float64)
+        if value.shape[-2:] == tuple(self.dense_shape):
+            value = tri_pack(value)
+        Variable.assign(self, value)
+
+    @property
+    def value(self):
+        return tri_unpack(Variable.value.fget(self))
+
+
 class Parameterized(Parentable):
     """Holds Variables / other Parameterized as attributes (reference param.py:306-603)."""
 

@@ -26,3 +26,15 @@ def log_sum_exp(tensor, axis=-1):
     m = G.reduce_max(tensor, axis, keepdims=True)
     s = G.reduce_sum(G.unary("EXP", G.sub(tensor, m)), axis, keepdims=False)
     return G.add(G.squeeze(m, axis), G.unary("LOG", s))
+
+
+def vec_to_tri(vectors):
+    """[B, N(N+1)/2] -> [B, N, N] lower-triangular matrices, entries in numpy tril_indices order: the native op the
+    reference declares and leaves disabled (tf_wraps.py:50-71; `tf.load_op_library('tfops/matpackops.so')`), here
+    hb_vec_to_tri.  Gradient: tri_to_vec (tf_wraps.py:56-58)."""
+    return G.vec_to_tri(vectors)
+
+
+def tri_to_vec(matrices):
+    """Inverse packing (hb_tri_to_vec)."""
+    return G.tri_to_vec(matrices)

@@ -14,13 +14,14 @@ import numpy as np
 
 from . import graph as G
 from . import priors, transforms
-from .param import Parameterized, Variable, graph_key
+from ._settings import settings
+from .param import Parameterized, TriPackedVariable, Variable, graph_key
 from .tf_wraps import clip
 
 
 class Variational(Parameterized):
     def __init__(self, shape, n_layers=[], n_batch=None, q_shape="diagonal", mean=0.0, stddev=1.0,
-                 prior=None, transform=transforms.Identity(), collections=[graph_key.VARIABLES]):
+                 prior=None, transform=transforms.Identity(), collections=[graph_key.VARIABLES], tri_pack=None):
         Parameterized.__init__(self)
         self._shape = [int(shape)] if isinstance(shape, (int, np.integer)) else [int(s) for s in shape]
         self.n_layers = [int(n_layers)] if isinstance(n_layers, (int, np.integer)) else [int(s) for s in n_layers]
@@ -35,6 +36,10 @@ class Variational(Parameterized):
         if q_shape == "diagonal":
             self.q_sqrt = Variable(self.size, n_layers=self.n_layers, n_batch=n_batch, mean=math.log(stddev),
                                    stddev=0.1, collections=collections)
+        elif self._use_tri_pack(tri_pack, collections, n_batch):
+            # global full-rank q_sqrt kept as its packed lower triangle (tf_wraps.py:50-71)
+            self.q_sqrt = TriPackedVariable(self.size, n_layers=self.n_layers, mean=stddev, stddev=0.1 * stddev,
+                                            collections=collections)
         else:
             self.q_sqrt = Variable([self.size, self.size], n_layers=self.n_layers, n_batch=n_batch, mean=stddev,
                                    stddev=0.1 * stddev, collections=collections)
@@ -44,6 +49,22 @@ class Variational(Parameterized):
         self._injected_u = None
 
     # -- helpers
+    @staticmethod
+    def _use_tri_pack(tri_pack, collections, n_batch):
+        if collections == graph_key.LOCAL or n_batch is not None:
+            return False            # fed / batched q_sqrt stays dense: its columns come from an encoder output
+        if tri_pack is None:
+            tri_pack = bool(getattr(settings.numerics, "tri_pack", False))
+        return bool(tri_pack)
+
+    @property
+    def packed(self):
+        return isinstance(object.__getattribute__(self, "q_sqrt"), TriPackedVariable)
+
+    def _dense_sqrt(self, sq):
+        """q_sqrt as a dense [.., size, size] graph tensor (generic consumers: logdet, closed-form KL)."""
+        return G.vec_to_tri(sq) if self.packed else sq
+
     @property
     def is_local(self):
         return self.collections == graph_key.LOCAL
@@ -74,7 +95,7 @@ class Variational(Parameterized):
             u = G.reshape(G.as_tensor(u), mu.shape)
         if self.q_shape == "diagonal":
             return G.diag_sample_kl(mu, sq, u, stream=stream)
-        return G.fullrank_sample_kl(mu, sq, u, stream=stream)
+        return G.fullrank_sample_kl(mu, sq, u, stream=stream, packed=self.packed)
 
     def _current(self):
         tid = self._trace_id()
@@ -118,7 +139,7 @@ class Variational(Parameterized):
         mu, sq = self._raw_params()
         if self.q_shape == "diagonal":
             return G.affine(sq, 2.0)
-        return G.unary("LOG", G.square(G.diag_part(sq)))
+        return G.unary("LOG", G.square(G.diag_part(self._dense_sqrt(sq))))
 
     def KL(self, collection=None):
         if collection is None or collection in self.collections:
@@ -139,14 +160,41 @@ class Normal(Variational):
     """Standard-normal prior, identity transform (reference variationals.py:213-230)."""
 
     def __init__(self, shape, n_layers=[], n_batch=None, q_shape="diagonal", mean=0.0, stddev=1.0,
-                 collections=[graph_key.VARIABLES]):
+                 collections=[graph_key.VARIABLES], kl_form=None, tri_pack=None):
         Variational.__init__(self, shape, q_shape=q_shape, n_layers=n_layers, n_batch=n_batch, mean=mean,
                              stddev=stddev, prior=priors.Normal(), transform=transforms.Identity(),
-                             collections=collections)
+                             collections=collections, tri_pack=tri_pack)
+        if kl_form not in (None, "mc", "analytic"):
+            raise ValueError("kl_form must be 'mc' or 'analytic'")
+        self.kl_form = kl_form
 
     def _KL(self):
-        """-0.5*sum(logdet + u^2 - x^2): produced by the sampler kernel itself."""
+        """kl_form 'mc' (the reference's estimator, variationals.py:225-230): -0.5*sum(logdet + u^2 - x^2),
+        produced by the sampler kernel itself.  kl_form 'analytic' (this build's extra mode; `kl_form=None` reads
+        settings.numerics.kl_form): the closed form KL[N(mu, L L^T) || N(0, I)], see _KL_analytic."""
+        form = self.kl_form or str(getattr(settings.numerics, "kl_form", "mc"))
+        if form == "analytic":
+            return _KL_analytic(self)
         return G.reshape(self._current()[2], [])
+
+
+def _KL_analytic(v):
+    """Closed-form KL[q || N(0, I)] of a diagonal / full-covariance Gaussian q = N(mu, L L^T),
+        0.5 * sum( -logdet - 1 + trace + mu^2 ),
+    logdet = 2 s, trace = exp(2 s) (diagonal: s is the log-std) or logdet = log S_kk^2, trace = sum tril(S)^2
+    (full rank) -- the formula the reference uses as the expectation of its Monte-Carlo estimator
+    (testing/test_variationals.py:326-347, compared there at rtol 0.1 over 100 draws).  It has no sampling
+    noise, so its gradient w.r.t. (mu, s/S) is exact; the reparameterised sample itself is unchanged."""
+    mu, sq = v._raw_params()
+    half_mu2 = G.reduce_sum(G.square(mu))
+    if v.q_shape == "diagonal":
+        # sum(exp(2s) - 2s - 1)
+        rest = G.reduce_sum(G.sub(G.unary("EXP", G.affine(sq, 2.0)), G.affine(sq, 2.0, 1.0)))
+    else:
+        d = G.diag_part(v._dense_sqrt(sq))
+        rest = G.sub(G.reduce_sum(G.square(sq if v.packed else G.band_part(sq, -1, 0))),
+                     G.reduce_sum(G.affine(G.unary("LOG", G.square(d)), 1.0, 1.0)))
+    return G.reshape(G.affine(G.add(half_mu2, rest), 0.5), [])
 
 
 class Gaussian(Normal):
@@ -161,6 +209,7 @@ class Gaussian(Normal):
         Variational.__init__(self, shape, q_shape=q_shape, n_layers=n_layers, n_batch=n_batch, mean=q_mean,
                              stddev=q_std, prior=priors.Normal(), transform=transforms.Identity(),
                              collections=collections)
+        self.kl_form = None
         scale_shape = scale_shape or [1 for _ in self._shape]
         scale_layer = scale_n_layers or [1 for _ in self.n_layers]
         self.scale = Variable(scale_shape, n_layers=scale_layer, n_batch=n_batch, mean=scale_mean,

@@ -210,21 +210,31 @@ int hb_diag_sample_kl_bwd_f64(const double* s, const double* u, const double* x,
                               const double* klbar, double* mubar, double* sbar, long n, long L, long ld_s,
                               long ld_out, void* stream);
 /* full-rank q over `rows` independent blocks: x_r = mu_r + tril(S_r) u_r ;
- * kl = -0.5*sum(log S_kk^2 + u^2 - x^2).  S: [rows,size,size] (upper part
- * ignored), mu/u/x: [rows,size]. */
+ * kl = -0.5*sum(log S_kk^2 + u^2 - x^2).  mu/u/x: [rows,size].  S: packed == 0: dense
+ * [rows,size,size] (upper part ignored); packed != 0: the lower triangle only,
+ * [rows, size(size+1)/2] in numpy tril_indices (row-major) order -- half the bytes. */
 int hb_fullrank_sample_kl_fwd_f32(const float* mu, const float* S, const float* u_in, uint64_t* rng,
                                   long rng_lanes, float* u_out, float* x, float* kl, long rows,
-                                  long size, float* ws, void* stream);
+                                  long size, int packed, float* ws, void* stream);
 int hb_fullrank_sample_kl_fwd_f64(const double* mu, const double* S, const double* u_in,
                                   uint64_t* rng, long rng_lanes, double* u_out, double* x,
-                                  double* kl, long rows, long size, double* ws, void* stream);
-/* mubar = xbar + klbar*x ; Sbar = tril(mubar u^T) - klbar*diag(1/S_kk) ; strictly upper = 0 */
+                                  double* kl, long rows, long size, int packed, double* ws,
+                                  void* stream);
+/* mubar = xbar + klbar*x ; Sbar = tril(mubar u^T) - klbar*diag(1/S_kk) ; strictly upper = 0
+ * (dense) or absent (packed: Sbar has S's packed layout) */
 int hb_fullrank_sample_kl_bwd_f32(const float* S, const float* u, const float* x, const float* xbar,
                                   const float* klbar, float* mubar, float* Sbar, long rows,
-                                  long size, void* stream);
+                                  long size, int packed, void* stream);
 int hb_fullrank_sample_kl_bwd_f64(const double* S, const double* u, const double* x,
                                   const double* xbar, const double* klbar, double* mubar,
-                                  double* Sbar, long rows, long size, void* stream);
+                                  double* Sbar, long rows, long size, int packed, void* stream);
+/* The reference's one (disabled) native-op pair, Henbun/tf_wraps.py:50-71: v [B, N(N+1)/2] <-> lower-
+ * triangular tri [B,N,N] (zeros above the diagonal), entries in numpy tril_indices order
+ * (transforms.py:225-244); each is the other's gradient (tf_wraps.py:56-58). */
+int hb_vec_to_tri_f32(const float* v, float* tri, long B, long N, void* stream);
+int hb_vec_to_tri_f64(const double* v, double* tri, long B, long N, void* stream);
+int hb_tri_to_vec_f32(const float* tri, float* v, long B, long N, void* stream);
+int hb_tri_to_vec_f64(const double* tri, double* v, long B, long N, void* stream);
 
 /* ---- K3: stationary Gram matrices (reference gp/kernels.py:54-84
  *      square_dist, :110-111 UnitRBF.K, :122-131 UnitCsymRBF) -------------- */

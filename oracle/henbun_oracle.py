@@ -141,6 +141,23 @@ def sample_fullrank(q_mu, q_sqrt, u):
     return q_mu + torch.matmul(sqrt, u[..., None])[..., 0]
 
 
+def vec_to_tri(v):
+    """tf_wraps.py:50-71 (disabled native op) with the element order of transforms.py:225-244
+    (LowerTriangular.forward: numpy tril_indices): [..., N(N+1)/2] -> lower-triangular [..., N, N]."""
+    T_ = v.shape[-1]
+    N = int((8 * T_ + 1) ** 0.5 / 2.0 - 0.5 + 1e-9)
+    i, j = np.tril_indices(N)
+    out = torch.zeros(v.shape[:-1] + (N, N), dtype=v.dtype)
+    out[..., torch.as_tensor(i), torch.as_tensor(j)] = v
+    return out
+
+
+def tri_to_vec(t):
+    """transforms.py:246-256 (LowerTriangular.backward order)."""
+    i, j = np.tril_indices(t.shape[-1])
+    return t[..., torch.as_tensor(i), torch.as_tensor(j)]
+
+
 def logdet(q_sqrt, q_shape):
     """variationals.py:178-186."""
     if q_shape == "diagonal":
@@ -219,6 +236,26 @@ def csym_rbf_K(X, X2, lengthscales):
     if X2 is None:
         X2 = X
     return torch.exp(-square_dist(X, X2, lengthscales) / 2.0) + torch.exp(-square_dist(X, -X2, lengthscales) / 2.0)
+
+
+def euclid_dist(X, X2, lengthscales):
+    """gp/kernels.py:86-88  sqrt(r^2 + 1e-12)."""
+    return torch.sqrt(square_dist(X, X2, lengthscales) + 1e-12)
+
+
+def matern32_K(X, X2, lengthscales):
+    """Matern-3/2 on euclid_dist.  NOT in the reference (it defines the distance, gp/kernels.py:86-88, but no
+    Matern class): published formula (Rasmussen & Williams 2006, eq. 4.17), parity unpinned by the reference;
+    tests/test_oracle.py checks it against scikit-learn's Matern(nu=1.5)."""
+    a = math.sqrt(3.0) * euclid_dist(X, X2, lengthscales)
+    return (1.0 + a) * torch.exp(-a)
+
+
+def matern52_K(X, X2, lengthscales):
+    """Matern-5/2 (see matern32_K; scikit-learn Matern(nu=2.5))."""
+    r2 = square_dist(X, X2, lengthscales) + 1e-12
+    a = math.sqrt(5.0) * torch.sqrt(r2)
+    return (1.0 + a + (5.0 / 3.0) * r2) * torch.exp(-a)
 
 
 def rbf_Kdiag(X):

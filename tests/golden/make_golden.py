@@ -14,7 +14,8 @@ Executed from the reference (provenance list is also stored in the fixture):
   testing/test_kernels.py       RefStationary, RefRBF, RefCsymRBF  (:10-63), draws :66-88
   testing/test_variationals.py  gaussian_KL (:326-347), draws :30-52
   testing/test_densities.py     student_t_ref (:26-32), draws :13-16, :37-41
-  Henbun/transforms.py          Transform, Identity, Exp, Log1pe numpy forward/backward (:27-143)
+  Henbun/transforms.py          Transform, Identity, Exp, Log1pe numpy forward/backward (:27-143); LowerTriangular
+                                (numpy forward/backward, from the string literal the reference parked it in, :182-269)
 
 Restated inline here because the reference only has them inside TF test bodies
 (formula pinned, nothing to execute): projected samples / logdet
@@ -91,6 +92,16 @@ def load_reference_definitions():
         exec(code, ns)
         prov.append("%s sha256=%s %s" % (rel, hashlib.sha256(raw).hexdigest()[:16], ",".join(
             "%s:%d-%d" % (n.name, n.lineno, n.end_lineno) for n in picked)))
+        if rel == "Henbun/transforms.py":
+            # the reference keeps its LowerTriangular transform (the user of the disabled vec_to_tri native op,
+            # tf_wraps.py:50-71) inside a module-level string literal: parse THAT text and take the class from it
+            for node in tree.body:
+                if isinstance(node, ast.Expr) and isinstance(node.value, ast.Constant) and isinstance(node.value.value, str) \
+                        and "class LowerTriangular" in node.value.value:
+                    sub = ast.parse(node.value.value)
+                    cls = [n for n in sub.body if isinstance(n, ast.ClassDef) and n.name == "LowerTriangular"]
+                    exec(compile(ast.Module(body=cls, type_ignores=[]), path, "exec"), ns)
+                    prov.append("%s LowerTriangular (inside the string literal at :%d-%d)" % (rel, node.lineno, node.end_lineno))
     return ns, prov
 
 
@@ -263,6 +274,24 @@ def build():
         g["t_" + key + "_back"] = np.asarray(tr.backward(y), dtype=np.float64)
     checks += [(g["t_log1pe"], np.log(1.0 + np.exp(tx)) + 1e-6), (g["t_exp"], np.exp(tx) + 1e-6)]
 
+    # ---- tri-pack element order: the reference's LowerTriangular.forward / backward executed (numpy only) ----
+    if "LowerTriangular" in ns:
+        rng = np.random.RandomState(0)
+        lt = ns["LowerTriangular"](num_matrices=3)
+        lx = rng.randn(3 * 10)                       # three 4x4 lower-triangular matrices
+        ly = np.asarray(lt.forward(lx), dtype=np.float64)      # [4, 4, 3]
+        g["lt_vec"] = lx.reshape(3, 10)
+        g["lt_tri"] = np.ascontiguousarray(np.transpose(ly, (2, 0, 1)))   # [3, 4, 4] = vec_to_tri(lt_vec)
+        g["lt_back"] = np.asarray(lt.backward(ly), dtype=np.float64).reshape(3, 10)
+        ref_tri = np.zeros((3, 4, 4))
+        for b in range(3):
+            k = 0
+            for i in range(4):
+                for j in range(i + 1):
+                    ref_tri[b, i, j] = lx[b * 10 + k]
+                    k += 1
+        checks += [(g["lt_tri"], ref_tri), (g["lt_back"], g["lt_vec"])]
+
     # ---- MLP (test_nn.py:11-29 shape pattern; the reference compares TF with TF, weights drawn here) ----
     rng = np.random.RandomState(0)
     nx = rng.randn(5, 6, 3)
@@ -277,7 +306,7 @@ def build():
     for i, (got, want) in enumerate(checks):
         if not _same(got, want):
             raise AssertionError("reference-executed value #%d disagrees with its independent re-derivation" % i)
-    executed = sorted(k for k in g if k.startswith(("k_rbf", "k_csym", "k_sqdist", "v_kl", "c_kl", "d_logp1", "s_logp", "t_"))
+    executed = sorted(k for k in g if k.startswith(("k_rbf", "k_csym", "k_sqdist", "v_kl", "c_kl", "d_logp1", "s_logp", "t_", "lt_tri", "lt_back"))
                       and k != "t_x")
     g["_provenance"] = np.array(prov)
     g["_reference_executed_keys"] = np.array(executed)
