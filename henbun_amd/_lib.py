@@ -67,10 +67,10 @@ _TYPED = {
     "hb_gram_bwd": [I, P, L, P, L, P, L, L, P, P, P, P, L, L, L, L, P, P],
     "hb_matmul": [P, P, P, L, L, L, L, L, L, L, L, L, L, I, I, D, D, P, L, I, I, P, L, P],
     "hb_cholesky": [P, P, L, L, P, P],
-    "hb_cholesky_inverse": [P, P, P, L, L, P, P, P],
+    "hb_cholesky_inverse": [P, P, P, L, L, P, P, P, P],
     "hb_trinv": [P, P, L, L, P, P],
-    "hb_sgp_A": [I, P, L, P, P, L, P, P, L, L, L, L, P],
-    "hb_sgp_fwd": [I, I, P, L, P, P, L, P, P, P, P, L, P, P, P, P, L, L, L, L, L, P, P],
+    "hb_sgp_A": [I, P, L, P, P, L, P, P, P, L, L, L, L, P],
+    "hb_sgp_fwd": [I, I, P, L, P, P, L, P, P, P, P, P, L, P, P, P, P, L, L, L, L, L, P, P],
     "hb_sgp_bwd": [I, I, P, L, P, P, L, P, P, P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P],
     "hb_adam_step": [P, P, P, P, L, D, D, D, D, D, P, I, P, L, P, P, P],
     "hb_allreduce_sum": [P, L, P, P],

@@ -379,17 +379,38 @@ __device__ __forceinline__ void pivot_sqrt(double d, double& l, double& inv) {
   inv = 1.0 / l;
 }
 
+// Finishing pass of the factorisation: clears the strict upper triangles of L (and W = L^-1), and -- when `Wf` is
+// given (M % 32 == 0) -- also leaves two FRAGMENT-MAJOR copies of W for the M^2 n contractions (csrc/sgp.hip):
+//   Wf  [B][M/32 row tiles][M/32 k chunks][4][64 lanes][4]:  element (t, Q, v, lane = (li, h), s) = W [32t+li][32Q+16h+4v+s]
+//   WTf (B*M*M elements further on): the same with W^T,                                        = W [32Q+16h+4v+s][32t+li]
+// i.e. exactly the order in which the MFMA A-operand loads of a 32-row tile consume a 32-deep k chunk: load
+// instruction v of a wave reads 64 lanes x 16 B = ONE contiguous kilobyte (8 whole cache lines).  Read from the
+// row-major matrix the same instruction touches 32 different lines for 32 bytes each, and the CU's texture
+// addresser / L1 -- 64 B per clock -- was as busy as the matrix pipes (profiles/r01_strip_ablation.txt: loads alone
+// 12.4 us against MFMAs alone 16.3 us).
 template <typename T>
-__global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, T* __restrict__ W, long B, long M) {
+__global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, T* __restrict__ W, T* __restrict__ Wf,
+                                                           long B, long M) {
   const int Mi = (int)M;
-  const long total = B * M * M;
+  const long mm = M * M, total = B * mm;
   const long stride = (long)gridDim.x * blockDim.x;
+  const int nT = Mi / 32;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int rem = (int)(t % (M * M));
+    const long b = t / mm;
+    const int rem = (int)(t - b * mm);
     const int i = rem / Mi, j = rem - i * Mi;
     if (j > i) {
       L[t] = T(0);
       if (W) W[t] = T(0);
+    }
+    if (Wf) {
+      // output-major: this thread writes element `rem` of both fragment images of matrix b
+      const int s = rem & 3, lane = (rem >> 2) & 63, v = (rem >> 8) & 3, blk = rem >> 10;
+      const int Q = blk % nT, tt = blk / nT, li = lane & 31, h = lane >> 5;
+      const int r = 32 * tt + li, k = 32 * Q + 16 * h + 4 * v + s;
+      const T* Wb = W + b * mm;
+      Wf[t] = k <= r ? Wb[(long)r * Mi + k] : T(0);           // W  [r][k]   (lower triangular)
+      Wf[total + t] = r <= k ? Wb[(long)k * Mi + r] : T(0);   // W^T[r][k] = W[k][r]
     }
   }
 }
@@ -1115,7 +1136,8 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
 }
 
 template <typename T>
-static int cholesky_launch(const T* A, T* L, T* W, T* ws, long B, long M, int* info, hipStream_t stream) {
+static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, long B, long M, int* info, hipStream_t stream) {
+  HB_REQUIRE(!Wf || (W && M % 32 == 0), "hb_cholesky_inverse: the fragment-major copies need W and M %% 32 == 0");
   HB_REQUIRE(B >= 0 && M >= 0, "hb_cholesky: negative extent");
   HB_REQUIRE(A && L && info, "hb_cholesky: NULL pointer");
   HB_REQUIRE(!W || ws, "hb_cholesky_inverse: workspace of B*M*M elements required");
@@ -1140,7 +1162,7 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, long B, long M, int* i
                          inv ? (float*)ws : (float*)nullptr, (float*)W, (int)M, k, info);
       HB_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, B, M);
+    hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, B, M);
     HB_LAUNCH_CHECK();
     return 0;
   }
@@ -1154,26 +1176,26 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, long B, long M, int* i
                          k, info);
     HB_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, B, M);
+  hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, B, M);
   HB_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int hb_cholesky_f32(const float* A, float* L, long B, long M, int* info, void* stream) {
-  return cholesky_launch<float>(A, L, nullptr, nullptr, B, M, info, (hipStream_t)stream);
+  return cholesky_launch<float>(A, L, nullptr, nullptr, nullptr, B, M, info, (hipStream_t)stream);
 }
 extern "C" int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void* stream) {
-  return cholesky_launch<double>(A, L, nullptr, nullptr, B, M, info, (hipStream_t)stream);
+  return cholesky_launch<double>(A, L, nullptr, nullptr, nullptr, B, M, info, (hipStream_t)stream);
 }
 extern "C" int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long B, long M, int* info, float* ws,
-                                       void* stream) {
+                                       float* Wfrag, void* stream) {
   HB_REQUIRE(W, "hb_cholesky_inverse: NULL pointer");
-  return cholesky_launch<float>(A, L, W, ws, B, M, info, (hipStream_t)stream);
+  return cholesky_launch<float>(A, L, W, ws, Wfrag, B, M, info, (hipStream_t)stream);
 }
 extern "C" int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info, double* ws,
-                                       void* stream) {
+                                       double* Wfrag, void* stream) {
   HB_REQUIRE(W, "hb_cholesky_inverse: NULL pointer");
-  return cholesky_launch<double>(A, L, W, ws, B, M, info, (hipStream_t)stream);
+  return cholesky_launch<double>(A, L, W, ws, Wfrag, B, M, info, (hipStream_t)stream);
 }
 
 // ===========================================================================

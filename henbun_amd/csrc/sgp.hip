@@ -42,6 +42,7 @@ struct SgpArgs {
   const T* ell; // [E, dl]
   long dl;
   const T* W;   // [E, M, M]
+  const T* Wf;  // fragment-major copy of W written by hb_cholesky_inverse (see tril_inplace_kernel), or nullptr
   const T* u;   // [E, P, M]
   T* A;         // [E, M, n]
   long n, M, d, P;
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
 
 #define SGP_STRIP_THREADS 512  // 8 waves: two per SIMD, so one wave's W loads are in flight under the other's MFMAs
 
-template <int D>
+template <int D, bool FRAG>
 __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<float> a) {
   typedef float V4 __attribute__((ext_vector_type(4)));
   typedef Mma<float> MM;
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
   const float* __restrict__ x = a.x + e * a.sx;
   const float* __restrict__ z = a.z + e * a.M * D;
   const float* __restrict__ ell = a.ell + e * a.dl;
-  const float* __restrict__ W = a.W + e * a.M * a.M;
+  const float* __restrict__ W = (FRAG ? a.Wf : a.W) + e * a.M * a.M;
   float* __restrict__ A = a.A + e * a.M * a.n;
   const int M = (int)a.M, n = (int)a.n;
   const int col0 = bx * SGP_SN;
@@ -466,9 +467,16 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
     for (int j = P; j < 2; ++j) {
       int qq = Q < dep[j] ? Q : dep[j] - 1;  // finished tile: re-read its last step (never used)
       qq = qq < 0 ? 0 : qq;                   // empty slot (depth 0): stay inside W
-      const float* p = W + (32 * tile[j] + li) * M + 32 * qq + 16 * h;
+      if (FRAG) {
+        // fragment-major image: load instruction v of the wave reads one contiguous kilobyte
+        const float* p = W + ((long)(tile[j] * nT + qq) << 10) + 4 * lane;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) an[j][v] = *reinterpret_cast<const V4*>(p + 4 * v);
+        for (int v = 0; v < 4; ++v) an[j][v] = *reinterpret_cast<const V4*>(p + 256 * v);
+      } else {
+        const float* p = W + (32 * tile[j] + li) * M + 32 * qq + 16 * h;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) an[j][v] = *reinterpret_cast<const V4*>(p + 4 * v);
+      }
     }
   };
   auto step = [&](int Q, auto pc, auto mc) {
@@ -483,7 +491,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
     V4 bv[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) bv[v] = *reinterpret_cast<const V4*>(&Ks[li][32 * Q + 16 * h + 4 * v]);
-    if (MASK) {
+    if (MASK && !FRAG) {  // (the fragment image holds explicit zeros above the diagonal)
       // W is lower triangular: entries k > row are not part of it (only tile P crosses the diagonal here)
       const int r = 32 * tile[P] + li, kb = 32 * Q + 16 * h;
 #pragma unroll
@@ -584,14 +592,22 @@ static inline bool sgp_strip_ok(long E, long n, long M, long d, const void* W) {
 
 static int sgp_A_strip_launch(SgpArgs<float> a, long E, hipStream_t stream) {
   dim3 grid = sgp_grid(hb_cdiv(a.n, SGP_SN), 1, E, a.efast);
+#define HB_STRIP(D_)                                                                                          \
+  do {                                                                                                        \
+    if (a.Wf)                                                                                                 \
+      hipLaunchKernelGGL((sgp_A_strip_kernel<D_, true>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);        \
+    else                                                                                                      \
+      hipLaunchKernelGGL((sgp_A_strip_kernel<D_, false>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);       \
+  } while (0)
   if (a.d == 1)
-    hipLaunchKernelGGL(sgp_A_strip_kernel<1>, grid, dim3(SGP_STRIP_THREADS), 0, stream, a);
+    HB_STRIP(1);
   else if (a.d == 2)
-    hipLaunchKernelGGL(sgp_A_strip_kernel<2>, grid, dim3(SGP_STRIP_THREADS), 0, stream, a);
+    HB_STRIP(2);
   else if (a.d == 3)
-    hipLaunchKernelGGL(sgp_A_strip_kernel<3>, grid, dim3(SGP_STRIP_THREADS), 0, stream, a);
+    HB_STRIP(3);
   else
-    hipLaunchKernelGGL(sgp_A_strip_kernel<4>, grid, dim3(SGP_STRIP_THREADS), 0, stream, a);
+    HB_STRIP(4);
+#undef HB_STRIP
   HB_LAUNCH_CHECK();
   return 0;
 }
@@ -753,9 +769,9 @@ static inline int sgp_grid_y(long E, long n, int nRB) {
 }
 
 template <typename T>
-static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* u,
-                   const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* A, T* f, T* v, long E, long n,
-                   long M, long d, long P, T* ws, hipStream_t stream) {
+static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* Wf,
+                   const T* u, const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* A, T* f, T* v, long E,
+                   long n, long M, long d, long P, T* ws, hipStream_t stream) {
   HB_REQUIRE(kind == HB_KERN_RBF, "hb_sgp_fwd: only the UnitRBF kernel is fused (kind=%d)", kind);
   HB_REQUIRE(mode == HB_SGP_NEGLECTED || mode == HB_SGP_DIAGONAL, "hb_sgp_fwd: unknown mode %d", mode);
   HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1 && P >= 0, "hb_sgp_fwd: bad extents");
@@ -771,7 +787,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   // fused path: the contraction kernel leaves per-column partial sums, one small kernel finishes f, v (and draws eps)
   if (M > 0 && P <= 4 && ws) {
     SgpArgs<T> a;
-    a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = u; a.A = A;
+    a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.Wf = Wf; a.u = u; a.A = A;
     a.n = n; a.M = M; a.d = d; a.P = P;
     a.part = ws + E * n + E * M * d;
     const bool strip = sizeof(T) == 4 && sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip();
@@ -805,7 +821,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   }
   if (M > 0) {
     SgpArgs<T> a;
-    a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = u; a.A = A;
+    a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.Wf = nullptr; a.u = u; a.A = A;
     a.n = n; a.M = M; a.d = d; a.P = P;
     a.part = nullptr;
     dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), gy, E, a.efast);
@@ -821,8 +837,8 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
 // A = W K(z,x) alone (posterior-prediction callers need A without a draw; also
 // lets bench.py time the contraction kernel in isolation).
 template <typename T>
-static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, T* A, long E,
-                      long n, long M, long d, hipStream_t stream) {
+static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* Wf, T* A,
+                      long E, long n, long M, long d, hipStream_t stream) {
   HB_REQUIRE(kind == HB_KERN_RBF, "hb_sgp_A: only the UnitRBF kernel is fused (kind=%d)", kind);
   HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1, "hb_sgp_A: bad extents");
   HB_REQUIRE(dl == 1 || dl == d, "hb_sgp_A: lengthscales must have 1 or d entries");
@@ -831,7 +847,7 @@ static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, l
   HB_REQUIRE(M * n < 2147483647L && M * M < 2147483647L && n * d < 2147483647L, "hb_sgp_A: matrix too large");
   if (E * n * M == 0) return 0;
   SgpArgs<T> a;
-  a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.u = nullptr; a.A = A;
+  a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.Wf = Wf; a.u = nullptr; a.A = A;
   a.n = n; a.M = M; a.d = d; a.P = 0;
   a.part = nullptr;
   if (sizeof(T) == 4 && sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip()) return sgp_A_strip_launch(a, E, stream);
@@ -840,27 +856,29 @@ static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, l
   return sgp_A_launch<T>(a, grid, stream);
 }
 extern "C" int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
-                            const float* W, float* A, long E, long n, long M, long d, void* stream) {
-  return sgp_A_only<float>(kind, x, sx, z, ell, dl, W, A, E, n, M, d, (hipStream_t)stream);
+                            const float* W, const float* Wfrag, float* A, long E, long n, long M, long d,
+                            void* stream) {
+  return sgp_A_only<float>(kind, x, sx, z, ell, dl, W, Wfrag, A, E, n, M, d, (hipStream_t)stream);
 }
 extern "C" int hb_sgp_A_f64(int kind, const double* x, long sx, const double* z, const double* ell, long dl,
-                            const double* W, double* A, long E, long n, long M, long d, void* stream) {
-  return sgp_A_only<double>(kind, x, sx, z, ell, dl, W, A, E, n, M, d, (hipStream_t)stream);
+                            const double* W, const double* Wfrag, double* A, long E, long n, long M, long d,
+                            void* stream) {
+  return sgp_A_only<double>(kind, x, sx, z, ell, dl, W, Wfrag, A, E, n, M, d, (hipStream_t)stream);
 }
 
 extern "C" int hb_sgp_fwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell, long dl,
-                              const float* W, const float* u, const float* eps_in, uint64_t* rng, long rng_lanes,
-                              float* eps_out, float* A, float* f, float* v, long E, long n, long M, long d, long P,
-                              float* ws, void* stream) {
-  return sgp_fwd<float>(kind, mode, x, sx, z, ell, dl, W, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E, n, M, d, P,
-                        ws, (hipStream_t)stream);
+                              const float* W, const float* Wfrag, const float* u, const float* eps_in, uint64_t* rng,
+                              long rng_lanes, float* eps_out, float* A, float* f, float* v, long E, long n, long M,
+                              long d, long P, float* ws, void* stream) {
+  return sgp_fwd<float>(kind, mode, x, sx, z, ell, dl, W, Wfrag, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E, n, M,
+                        d, P, ws, (hipStream_t)stream);
 }
 extern "C" int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
-                              long dl, const double* W, const double* u, const double* eps_in, uint64_t* rng,
-                              long rng_lanes, double* eps_out, double* A, double* f, double* v, long E, long n, long M,
-                              long d, long P, double* ws, void* stream) {
-  return sgp_fwd<double>(kind, mode, x, sx, z, ell, dl, W, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E, n, M, d, P,
-                         ws, (hipStream_t)stream);
+                              long dl, const double* W, const double* Wfrag, const double* u, const double* eps_in,
+                              uint64_t* rng, long rng_lanes, double* eps_out, double* A, double* f, double* v, long E,
+                              long n, long M, long d, long P, double* ws, void* stream) {
+  return sgp_fwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E, n, M,
+                         d, P, ws, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

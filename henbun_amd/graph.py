@@ -1018,7 +1018,13 @@ def _cholesky_emit(plan, node):
         w = plan.out(inv_node.outputs[0])
         ws = plan.scratch((max(int(np.prod(node.outputs[0].shape)), 1),))
         plan._fused_trinv.add(inv_node.id)
-        plan.steps.append(lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws))
+        # fragment-major copies of W / W^T for the M^2 n contractions that consume this inverse (csrc/sgp.hip)
+        frag = None
+        M = node.outputs[0].shape[-1]
+        if plan.dtype == plan.torch.float32 and M % 32 == 0 and M >= 32 and any(c.op in ("sgp", "sgp_grad") for c in plan._consumers.get(inv_node.outputs[0], ())):
+            frag = plan.scratch((2 * max(int(np.prod(node.outputs[0].shape)), 1),))
+            plan._wfrag[inv_node.outputs[0]] = frag
+        plan.steps.append(lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws, frag=frag))
         return
     plan.steps.append(lambda: H.cholesky(a, out=out, info=info))
 
@@ -1382,7 +1388,8 @@ def _sgp_emit(plan, node):
     outs = tuple(plan.out(t) for t in node.outputs)
     mode = SGP_MODES[node.attrs["mode"]]
     rng = plan.rng("local") if (eps_in is None and mode == 1) else None
-    plan.steps.append(lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs))
+    wfrag = plan._wfrag.get(node.inputs[4])
+    plan.steps.append(lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag))
 
 
 def _sgp_vjp(node, gs):
@@ -1689,6 +1696,7 @@ class Plan:
             self._needed.add(t)
         self._extra_copies = []
         self._fused_trinv = set()
+        self._wfrag: Dict[Tensor, object] = {}   # W tensor -> fragment-major copies written by the fused factorisation
         self._fused_matutil = set()
         self._fused_concat = set()
         self._lazy_cols: Dict[Tensor, object] = {}

@@ -302,11 +302,15 @@ int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void*
  * eliminated alongside A: the inverse costs extra width per launch, no extra
  * depth).  ws: B*M*M elements.  Replaces the tf.cholesky +
  * tf.matrix_triangular_solve(Lm, .) pair of SparseGP.samples (reference
- * gp/gp.py:135,162,169).  A, L, W must not alias. */
+ * gp/gp.py:135,162,169).  A, L, W must not alias.
+ * Wfrag (nullable; 2*B*M*M elements, needs M % 32 == 0): fragment-major copies of W and of W^T --
+ * [B][M/32 row tiles t][M/32 k chunks Q][4 v][64 lanes (li + 32 h)][4 s] = W[32t+li][32Q+16h+4v+s] (then the
+ * same for W^T) -- the order in which the MFMA operand loads of hb_sgp_fwd / hb_sgp_bwd consume them, so that
+ * every load instruction reads one contiguous kilobyte. */
 int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long B, long M, int* info, float* ws,
-                            void* stream);
+                            float* Wfrag, void* stream);
 int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info,
-                            double* ws, void* stream);
+                            double* ws, double* Wfrag, void* stream);
 /* W = L^{-1} (lower triangular inverse), batched.  Used in place of
  * tf.matrix_triangular_solve(Lm, .) (reference gp/gp.py:162,169): the
  * reference's own batched branch forms the explicit inverse the same way.
@@ -325,21 +329,24 @@ enum { HB_SGP_NEGLECTED = 0, HB_SGP_DIAGONAL = 1 };
  *   f   = mean + sqrt(|v|) * eps      (DIAGONAL; eps [n] shared by the P rows,
  *                                      reference gp/gp.py:131-132)  or mean (NEGLECTED)
  * eps_in nullable -> drawn from rng; eps_out [E,n] receives the noise used.
+ * Wfrag (nullable): the fragment-major copies hb_cholesky_inverse wrote for this W (faster operand loads).
  * ws >= hb_sgp_ws_elems(...) elements. */
 long hb_sgp_ws_elems(long E, long n, long M, long d, long P);
 int hb_sgp_fwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell,
-                   long dl, const float* W, const float* u, const float* eps_in, uint64_t* rng,
-                   long rng_lanes, float* eps_out, float* A, float* f, float* v, long E, long n,
-                   long M, long d, long P, float* ws, void* stream);
+                   long dl, const float* W, const float* Wfrag, const float* u, const float* eps_in,
+                   uint64_t* rng, long rng_lanes, float* eps_out, float* A, float* f, float* v, long E,
+                   long n, long M, long d, long P, float* ws, void* stream);
 int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
-                   long dl, const double* W, const double* u, const double* eps_in, uint64_t* rng,
-                   long rng_lanes, double* eps_out, double* A, double* f, double* v, long E, long n,
-                   long M, long d, long P, double* ws, void* stream);
+                   long dl, const double* W, const double* Wfrag, const double* u, const double* eps_in,
+                   uint64_t* rng, long rng_lanes, double* eps_out, double* A, double* f, double* v,
+                   long E, long n, long M, long d, long P, double* ws, void* stream);
 /* The contraction alone, A = W k(z,x) (posterior-prediction callers; isolated timing). */
 int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
-                 const float* W, float* A, long E, long n, long M, long d, void* stream);
+                 const float* W, const float* Wfrag, float* A, long E, long n, long M, long d,
+                 void* stream);
 int hb_sgp_A_f64(int kind, const double* x, long sx, const double* z, const double* ell, long dl,
-                 const double* W, double* A, long E, long n, long M, long d, void* stream);
+                 const double* W, const double* Wfrag, double* A, long E, long n, long M, long d,
+                 void* stream);
 /* VJP given fbar [E,P,n]:
  *   Abar = u^T fbar + A diag(c),  c = -eps sign(v)/sqrt|v| * sum_p fbar_p
  *   Kbar = W^T Abar            [E,M,n]  (scratch output, kept for Lbar)

@@ -574,6 +574,42 @@ def test_sgp_experts_batched_and_rng(H):
     assert_close(f2, ref, dict(rtol=1e-6, atol=1e-6))
 
 
+def test_fragment_major_copies_of_the_inverse(H):
+    """hb_cholesky_inverse's optional Wfrag output (fragment-major W and W^T, include/henbun_hip.h) has the
+    documented element order, and the column-strip contraction gives the same BITS from it as from row-major W."""
+    rng = np.random.RandomState(5)
+    for B, M in ((1, 64), (2, 96), (1, 512)):
+        z = np.sort(rng.uniform(0, M / 2.0, (B, M, 1)), axis=1)
+        K = H.gram_fwd(dev(z, torch.float32), dev(z, torch.float32), dev(np.ones(1), torch.float32), diag_add=1e-3)
+        K = K.reshape(B, M, M)
+        frag = torch.full((2 * B * M * M,), float("nan"), dtype=torch.float32, device="cuda")
+        L, W, info = H.cholesky_inverse(K, frag=frag)
+        L2, W2, _ = H.cholesky_inverse(K)
+        assert not info.cpu().numpy().any() and torch.equal(W, W2) and torch.equal(L, L2)
+        Wh = W.cpu().numpy()
+        nT = M // 32
+        t, Q, v, lane, s = np.meshgrid(np.arange(nT), np.arange(nT), np.arange(4), np.arange(64), np.arange(4), indexing="ij")
+        r, k = 32 * t + (lane & 31), 32 * Q + 16 * (lane >> 5) + 4 * v + s
+        fr = frag.cpu().numpy().reshape(2, B, nT, nT, 4, 64, 4)
+        for b in range(B):
+            assert np.array_equal(fr[0, b], Wh[b][r, k])
+            assert np.array_equal(fr[1, b], Wh[b].T[r, k])
+        x = dev(rng.uniform(0, M / 2.0, (700, 1)), torch.float32)
+        u = dev(rng.randn(B, 1, M), torch.float32)
+        eps = dev(rng.randn(B, 700), torch.float32)
+        zz, ell = dev(z, torch.float32), dev(np.ones((B, 1)), torch.float32)
+        if B == 1:
+            zz, ell, u, eps = zz[0], ell[0], u[0], eps[0]
+            Wd = W.reshape(M, M)
+        else:
+            Wd = W
+        a = H.sgp_fwd(x, zz, ell, Wd, u, eps_in=eps)
+        b_ = H.sgp_fwd(x, zz, ell, Wd, u, eps_in=eps, wfrag=frag)
+        for p_, q_ in zip(a, b_):
+            assert torch.equal(p_, q_)
+        assert torch.equal(H.sgp_A(x, zz, ell, Wd), H.sgp_A(x, zz, ell, Wd, wfrag=frag))
+
+
 # ------------------------------------------------------------------ Adam + graphs
 @pytest.mark.parametrize("p", ["f32", "f64"])
 def test_adam_matches_tf_formula(H, p):
