@@ -67,10 +67,10 @@ _TYPED = {
     "hb_gram_bwd": [I, P, L, P, L, P, L, L, P, P, P, P, L, L, L, L, P, P],
     "hb_matmul": [P, P, P, L, L, L, L, L, L, L, L, L, L, I, I, D, D, P, L, I, I, P, L, P],
     "hb_cholesky": [P, P, L, L, P, P],
-    "hb_cholesky_inverse": [P, P, P, L, L, P, P, P, P],
+    "hb_cholesky_inverse": [P, P, P, L, L, P, P, P, I, P],
     "hb_trinv": [P, P, L, L, P, P],
-    "hb_sgp_A": [I, P, L, P, P, L, P, P, P, L, L, L, L, P],
-    "hb_sgp_fwd": [I, I, P, L, P, P, L, P, P, P, P, P, L, P, P, P, P, L, L, L, L, L, P, P],
+    "hb_sgp_A": [I, P, L, P, P, L, P, P, I, P, L, L, L, L, P],
+    "hb_sgp_fwd": [I, I, P, L, P, P, L, P, P, I, P, P, P, L, P, P, P, P, L, L, L, L, L, P, P],
     "hb_sgp_bwd": [I, I, P, L, P, P, L, P, P, P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P],
     "hb_adam_step": [P, P, P, P, L, D, D, D, D, D, P, I, P, L, P, P, P],
     "hb_allreduce_sum": [P, L, P, P],
@@ -93,6 +93,11 @@ class _Lib:
                 "henbun_amd: %s is missing.  Build it with `python -m henbun_amd._build` "
                 "(hipcc, gfx950).  There is no CPU fallback." % path
             )
+        # PyTorch (device memory / streams) ships its own libamdhip64.so: it must be the HIP runtime of the process.
+        # Loading this library first would pull in /opt/rocm's copy, and kernels launched through that second runtime
+        # see no device ("no ROCm-capable device is detected" when henbun_amd was imported before torch).
+        import torch  # noqa: F401
+
         self._dll = ctypes.CDLL(path)
         self._fns = {}
         for name, args in _SIGS.items():

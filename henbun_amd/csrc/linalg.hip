@@ -230,6 +230,201 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
   }
 }
 
+// ===========================================================================
+// Small GEMMs (the three M^3 products of the Cholesky VJP, 512^3 at cfg 2): split-K INSIDE the workgroup.
+//
+// A 512x512 result is 64 tiles of 64x64: to fill 256 CUs the tile engine above splits the contraction over
+// workgroups, writes S slabs and needs a second launch to fold them (8-10 us + 5.9 us per product).  Here one
+// 256-thread workgroup owns ONE 32x32 output tile (256 of them: one per CU) and its four waves each contract a
+// quarter of K into a private accumulator; the four partial tiles meet in LDS (16 KB) and every thread finishes
+// four output elements -- epilogues (alpha, bias, activation, beta, tril / Phi / symmetrise) included, no slabs in
+// HBM, no finish launch.  Operands go straight from L2 into MFMA fragments, two register sets used alternately
+// (see sgp_A_strip2_kernel for why the loop is written that way): a "k-major" operand (stored [K][M]) loads whole
+// 128-byte rows (lane (li, h) takes k = k0 + 16 h + j, j = 0..15), an "m-major" one 64 contiguous bytes per lane.
+// SYM_OUT: the workgroup of tile (i, j >= ... i >= j) carries a second accumulator for the mirrored tile (j, i) and
+// writes both halves of (X + X^T)/2.
+// ===========================================================================
+#define WGK_LD 33
+template <bool TA, bool TB, bool SYM>
+__global__ void __launch_bounds__(256) matmul_wgk_kernel(MmArgs<float> a) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef Mma<float> MM;
+  __shared__ float red[SYM ? 8 : 4][32][WGK_LD];
+  const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
+  const int lda = (int)a.lda, ldb = (int)a.ldb;
+  const int tiles_n = N / 32;
+  const long b = blockIdx.y;
+  int ti, tj;
+  if (SYM) {
+    // lower tiles only, linear index -> (ti >= tj)
+    int t = blockIdx.x;
+    ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while (ti * (ti + 1) / 2 > t) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    tj = t - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.x / tiles_n;
+    tj = blockIdx.x - ti * tiles_n;
+  }
+  const int row0 = ti * 32, col0 = tj * 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  float* Cb = a.C + b * a.sC;
+  const bool lower_only = (a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) != 0;
+  if (!SYM && lower_only && col0 > row0 + 31) {
+    if (a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) {
+      for (int idx = tid; idx < 1024; idx += 256) Cb[(long)(row0 + (idx >> 5)) * a.ldc + col0 + (idx & 31)] = 0.f;
+    }
+    return;
+  }
+  const float* __restrict__ Ab = a.A + b * a.sA;
+  const float* __restrict__ Bb = a.B + b * a.sB;
+  const int Kw = K / 4, kbeg = w * Kw, nch = Kw / 32;
+  typename MM::Acc acc, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f, acc2[r] = 0.f;
+
+  // CH chunks of 32 per operand register set: a whole wave-slice of K = 512 (4 chunks) is in flight at once -- these
+  // products are a single dependent round trip to L2 / the Infinity Cache plus ~2 us of MFMAs, so the loads of every
+  // chunk are issued before the first MFMA (1 wave per SIMD: 512 registers to spend); deeper contractions
+  // alternate two such sets.
+  constexpr int CH = SYM ? 2 : 4;
+  struct Frag {
+    float a[CH][16], b[CH][16], a2[SYM ? CH : 1][16], b2[SYM ? CH : 1][16];
+  };
+  // operand element (m, k): A_op[m][k] = TA ? A[k][m] : A[m][k];  B_op[k][n] = TB ? B[n][k] : B[k][n]
+  auto load_side = [&](float (&f)[16], const float* __restrict__ base, int ld, bool kmajor, int idx0, int k0) {
+    if (kmajor) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) f[j] = base[(long)(k0 + 16 * h + j) * ld + idx0 + li];
+    } else {
+      const float* p = base + (long)(idx0 + li) * ld + k0 + 16 * h;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const V4 q = *reinterpret_cast<const V4*>(p + 4 * v);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) f[4 * v + s2] = q[s2];
+      }
+    }
+  };
+  auto load = [&](Frag& f, int c0) {
+    if (c0 >= nch) return;  // (uniform) nothing left for this set
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int cc = c0 + q < nch ? c0 + q : nch - 1;   // a ragged last set re-reads its last chunk (never used)
+      const int k0 = kbeg + 32 * cc;
+      load_side(f.a[q], Ab, lda, TA, row0, k0);
+      load_side(f.b[q], Bb, ldb, !TB, col0, k0);
+      if (SYM) {
+        load_side(f.a2[q], Ab, lda, TA, col0, k0);   // mirrored tile (tj, ti): rows of tile tj ...
+        load_side(f.b2[q], Bb, ldb, !TB, row0, k0);  // ... against the columns of tile ti
+      }
+    }
+  };
+  auto compute = [&](const Frag& f, int c0) {
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      if (c0 + q >= nch) break;  // uniform
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        acc = MM::mma(f.a[q][j], f.b[q][j], acc);
+        if (SYM) acc2 = MM::mma(f.a2[q][j], f.b2[q][j], acc2);
+      }
+    }
+  };
+  {
+    Frag fa, fb;
+    load(fa, 0);
+#pragma nounroll
+    for (int c = 0; c < nch; c += 2 * CH) {
+      load(fb, c + CH);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fa, c);
+      __builtin_amdgcn_sched_barrier(0);
+      load(fa, c + 2 * CH);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fb, c + CH);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- the four partial tiles meet in LDS
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    red[w][MM::acc_row(lane, r)][li] = acc[r];
+    if (SYM) red[4 + w][MM::acc_row(lane, r)][li] = acc2[r];
+  }
+  __syncthreads();
+  const float* biasb = a.bias ? a.bias + b * a.sBias : nullptr;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + 256 * e, r = idx >> 5, c = idx & 31;
+    float v = ((red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c])) * a.alpha;
+    const long gr = row0 + r, gcn = col0 + c;
+    if (SYM) {
+      // (X + X^T)/2: element (r, c) of tile (ti, tj) pairs with element (c, r) of the mirrored tile (tj, ti)
+      const float vm = ((red[4][c][r] + red[5][c][r]) + (red[6][c][r] + red[7][c][r])) * a.alpha;
+      const float sy = 0.5f * (v + vm);
+      Cb[gr * a.ldc + gcn] = sy;
+      continue;
+    }
+    if (biasb) v += biasb[gcn];
+    v = apply_act<float>(a.act, v);
+    if (a.beta != 0.f) v += a.beta * Cb[gr * a.ldc + gcn];
+    if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && gcn > gr) v = 0.f;
+    if ((a.flags & HB_MM_PHI_OUT) && gcn == gr) v *= 0.5f;
+    Cb[gr * a.ldc + gcn] = v;
+  }
+  if (SYM && ti != tj) {
+    // the mirrored tile (tj, ti): element (r, c) there = the symmetrised element (c, r) here
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * e, r = idx >> 5, c = idx & 31;
+      const float v = ((red[0][c][r] + red[1][c][r]) + (red[2][c][r] + red[3][c][r])) * a.alpha;
+      const float vm = ((red[4][r][c] + red[5][r][c]) + (red[6][r][c] + red[7][r][c])) * a.alpha;
+      Cb[(long)(col0 + r) * a.ldc + row0 + c] = 0.5f * (v + vm);
+    }
+  }
+}
+
+// eligibility of the in-workgroup split-K kernel (fp32 only)
+template <typename T>
+static bool matmul_wgk_ok(const MmArgs<T>&, long, long, long, long, int, bool) { return false; }
+template <>
+bool matmul_wgk_ok<float>(const MmArgs<float>& a, long M, long N, long K, long batch, int flags, bool aligned) {
+  static const bool off = getenv("HB_MM_NO_WGK") != nullptr;  // diagnostic A/B switch
+  if (off || !aligned) return false;
+  if (M % 32 || N % 32 || K % 128 || K < 128 || K > 4096) return false;
+  if (flags & HB_MM_ACTGRAD) return false;
+  if ((flags & HB_MM_SYM_OUT) && M != N) return false;
+  const long tiles = (M / 32) * (N / 32) * batch;
+  return tiles <= 1024 && batch <= 65535;
+}
+template <typename T>
+static int matmul_wgk_launch(const MmArgs<T>&, int, int, hipStream_t) { return -1; }
+template <>
+int matmul_wgk_launch<float>(const MmArgs<float>& a, int transA, int transB, hipStream_t stream) {
+  const bool sym = (a.flags & HB_MM_SYM_OUT) != 0;
+  const long nt = a.M / 32;
+  dim3 grid((unsigned)(sym ? nt * (nt + 1) / 2 : (a.M / 32) * (a.N / 32)), (unsigned)a.batch, 1);
+#define HB_WGK(TA_, TB_)                                                                         \
+  do {                                                                                           \
+    if (sym)                                                                                     \
+      hipLaunchKernelGGL((matmul_wgk_kernel<TA_, TB_, true>), grid, dim3(256), 0, stream, a);    \
+    else                                                                                         \
+      hipLaunchKernelGGL((matmul_wgk_kernel<TA_, TB_, false>), grid, dim3(256), 0, stream, a);   \
+  } while (0)
+  if (!transA && !transB)
+    HB_WGK(false, false);
+  else if (!transA && transB)
+    HB_WGK(false, true);
+  else if (transA && !transB)
+    HB_WGK(true, false);
+  else
+    HB_WGK(true, true);
+#undef HB_WGK
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T>
 static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long N, long K, long lda, long ldb,
                          long ldc, long sA, long sB, long sC, int transA, int transB, double alpha, double beta,
@@ -312,6 +507,14 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   if (S > 8) S -= S % 8;  // slab <-> XCD affinity (see matmul_kernel)
   a.S = S;
   a.to_ws = (S > 1 || (flags & HB_MM_SYM_OUT)) ? 1 : 0;
+  {
+    // results that would go through slabs + a finish launch: one 32x32 tile per workgroup with the contraction
+    // split over its four waves instead (matmul_wgk_kernel)
+    constexpr long VEC0 = 16 / sizeof(T);
+    const bool aligned0 = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % VEC0 == 0 && ldb % VEC0 == 0 &&
+                          sA % VEC0 == 0 && sB % VEC0 == 0;
+    if (a.to_ws && matmul_wgk_ok<T>(a, M, N, K, batch, flags, aligned0)) return matmul_wgk_launch<T>(a, transA, transB, stream);
+  }
   const long tiles_final = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
   HB_REQUIRE(tiles_final * S * batch < 2147483647L, "hb_matmul: grid too large");
   a.bfast = (batch > 1 && batch % 8 == 0) ? 1 : 0;
@@ -388,9 +591,19 @@ __device__ __forceinline__ void pivot_sqrt(double d, double& l, double& inv) {
 // row-major matrix the same instruction touches 32 different lines for 32 bytes each, and the CU's texture
 // addresser / L1 -- 64 B per clock -- was as busy as the matrix pipes (profiles/r01_strip_ablation.txt: loads alone
 // 12.4 us against MFMAs alone 16.3 us).
+// fp32 -> three bf16 terms hi + mid + lo (each rounded to nearest even of what is left): the operand form of the
+// "bf16x3" contractions, whose six significant cross products reproduce the fp32-operand result to fp32 accuracy
+// (profiles/r01_bf16_split_study.txt) at the bf16 MFMA rate.
+__device__ __forceinline__ void hb_split_bf16x3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = (__bf16)x;
+  const float r1 = x - (float)hi;
+  mid = (__bf16)r1;
+  lo = (__bf16)(r1 - (float)mid);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, T* __restrict__ W, T* __restrict__ Wf,
-                                                           long B, long M) {
+                                                           int bf16x3, long B, long M) {
   const int Mi = (int)M;
   const long mm = M * M, total = B * mm;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -405,12 +618,29 @@ __global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, T*
     }
     if (Wf) {
       // output-major: this thread writes element `rem` of both fragment images of matrix b
-      const int s = rem & 3, lane = (rem >> 2) & 63, v = (rem >> 8) & 3, blk = rem >> 10;
-      const int Q = blk % nT, tt = blk / nT, li = lane & 31, h = lane >> 5;
-      const int r = 32 * tt + li, k = 32 * Q + 16 * h + 4 * v + s;
       const T* Wb = W + b * mm;
-      Wf[t] = k <= r ? Wb[(long)r * Mi + k] : T(0);           // W  [r][k]   (lower triangular)
-      Wf[total + t] = r <= k ? Wb[(long)k * Mi + r] : T(0);   // W^T[r][k] = W[k][r]
+      {
+        const int s = rem & 3, lane = (rem >> 2) & 63, v = (rem >> 8) & 3, blk = rem >> 10;
+        const int Q = blk % nT, tt = blk / nT, li = lane & 31, h = lane >> 5;
+        const int r = 32 * tt + li, k = 32 * Q + 16 * h + 4 * v + s;
+        Wf[t] = k <= r ? Wb[(long)r * Mi + k] : T(0);           // W  [r][k]   (lower triangular)
+        Wf[total + t] = r <= k ? Wb[(long)k * Mi + r] : T(0);   // W^T[r][k] = W[k][r]
+      }
+      if (bf16x3) {
+        // bf16 images, one per split term p: [p][B][t][Q][q = 0..1][64 lanes][8] with the element
+        // X[32t + li][32Q + 16q + 8h + j] -- the A-operand fragment of v_mfma_f32_32x32x16_bf16 for k16-step q
+        const int jj = rem & 7, lane = (rem >> 3) & 63, q = (rem >> 9) & 1, blk = rem >> 10;
+        const int Q = blk % nT, tt = blk / nT, li = lane & 31, h = lane >> 5;
+        const int r = 32 * tt + li, k = 32 * Q + 16 * q + 8 * h + jj;
+        __bf16* W3 = reinterpret_cast<__bf16*>(Wf + 2 * total);   // 3 planes of W, then 3 planes of W^T
+        const float x = k <= r ? (float)Wb[(long)r * Mi + k] : 0.f;
+        const float xt = r <= k ? (float)Wb[(long)k * Mi + r] : 0.f;
+        __bf16 a0, a1, a2;
+        hb_split_bf16x3(x, a0, a1, a2);
+        W3[t] = a0, W3[total + t] = a1, W3[2 * total + t] = a2;
+        hb_split_bf16x3(xt, a0, a1, a2);
+        W3[3 * total + t] = a0, W3[4 * total + t] = a1, W3[5 * total + t] = a2;
+      }
     }
   }
 }
@@ -1136,8 +1366,10 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
 }
 
 template <typename T>
-static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, long B, long M, int* info, hipStream_t stream) {
+static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, long B, long M, int* info,
+                           hipStream_t stream) {
   HB_REQUIRE(!Wf || (W && M % 32 == 0), "hb_cholesky_inverse: the fragment-major copies need W and M %% 32 == 0");
+  HB_REQUIRE(!bf16x3 || (Wf && sizeof(T) == 4), "hb_cholesky_inverse: bf16x3 images need Wfrag and fp32");
   HB_REQUIRE(B >= 0 && M >= 0, "hb_cholesky: negative extent");
   HB_REQUIRE(A && L && info, "hb_cholesky: NULL pointer");
   HB_REQUIRE(!W || ws, "hb_cholesky_inverse: workspace of B*M*M elements required");
@@ -1162,7 +1394,7 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, long B, long M,
                          inv ? (float*)ws : (float*)nullptr, (float*)W, (int)M, k, info);
       HB_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, B, M);
+    hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, bf16x3, B, M);
     HB_LAUNCH_CHECK();
     return 0;
   }
@@ -1176,26 +1408,26 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, long B, long M,
                          k, info);
     HB_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, B, M);
+  hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, bf16x3, B, M);
   HB_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int hb_cholesky_f32(const float* A, float* L, long B, long M, int* info, void* stream) {
-  return cholesky_launch<float>(A, L, nullptr, nullptr, nullptr, B, M, info, (hipStream_t)stream);
+  return cholesky_launch<float>(A, L, nullptr, nullptr, nullptr, 0, B, M, info, (hipStream_t)stream);
 }
 extern "C" int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void* stream) {
-  return cholesky_launch<double>(A, L, nullptr, nullptr, nullptr, B, M, info, (hipStream_t)stream);
+  return cholesky_launch<double>(A, L, nullptr, nullptr, nullptr, 0, B, M, info, (hipStream_t)stream);
 }
 extern "C" int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long B, long M, int* info, float* ws,
-                                       float* Wfrag, void* stream) {
+                                       float* Wfrag, int frag_bf16x3, void* stream) {
   HB_REQUIRE(W, "hb_cholesky_inverse: NULL pointer");
-  return cholesky_launch<float>(A, L, W, ws, Wfrag, B, M, info, (hipStream_t)stream);
+  return cholesky_launch<float>(A, L, W, ws, Wfrag, frag_bf16x3, B, M, info, (hipStream_t)stream);
 }
 extern "C" int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info, double* ws,
-                                       double* Wfrag, void* stream) {
+                                       double* Wfrag, int frag_bf16x3, void* stream) {
   HB_REQUIRE(W, "hb_cholesky_inverse: NULL pointer");
-  return cholesky_launch<double>(A, L, W, ws, Wfrag, B, M, info, (hipStream_t)stream);
+  return cholesky_launch<double>(A, L, W, ws, Wfrag, frag_bf16x3, B, M, info, (hipStream_t)stream);
 }
 
 // ===========================================================================

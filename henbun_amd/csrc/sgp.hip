@@ -43,6 +43,8 @@ struct SgpArgs {
   long dl;
   const T* W;   // [E, M, M]
   const T* Wf;  // fragment-major copy of W written by hb_cholesky_inverse (see tril_inplace_kernel), or nullptr
+  const void* W3;  // bf16x3 fragment images of W (3 planes of E*M*M bf16), or nullptr
+  long plane3;     // elements per bf16 plane (E*M*M)
   const T* u;   // [E, P, M]
   T* A;         // [E, M, n]
   long n, M, d, P;
@@ -483,10 +485,17 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
     constexpr int P = decltype(pc)::value;
     constexpr bool MASK = decltype(mc)::value;
     V4 ac[2][4];
+    // The copy out of the prefetch registers is where the compiler waits for the loads issued one step ago.  Left to
+    // itself the scheduler rotates it into the PREVIOUS step, in between that step's MFMAs (as soon as the operand
+    // registers die), i.e. a few hundred cycles after the loads were issued: the wave then sits on s_waitcnt vmcnt
+    // with its matrix pipe idle (48 % issue-wait + 30 % parked in profiles/r01_pmc_cfg2_kernels.txt).  Pinned here,
+    // the loads have the whole previous step (32 MFMAs, >= 2048 cycles) to land.
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = P; j < 2; ++j)
 #pragma unroll
       for (int v = 0; v < 4; ++v) ac[j][v] = an[j][v];
+    __builtin_amdgcn_sched_barrier(0);
     if (!(HB_STRIP_ABLATE & 2) && Q + 1 < dep[1]) load_a(Q + 1, pc);  // prefetch (a tile that finishes now re-reads its last step: harmless)
     V4 bv[4];
 #pragma unroll
@@ -576,6 +585,385 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
   HB_SSTAMP(6);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Column-strip contraction, second form: used when the fragment-major image of W is available (hb_cholesky_inverse's
+// Wfrag).  Same decomposition (one workgroup = 32 data columns x all M rows, 8 waves, wave w owns the row tiles
+// w and nT-1-w), but the wave walks its nT+1 "tile-steps" (16 MFMAs each: one 32-row tile x one 32-deep chunk of the
+// contraction) as ONE flat sequence -- first all of the shallow tile, then all of the deep one -- with a single
+// accumulator and two operand register sets used alternately (the loop is unrolled by two):
+//     load B-set (step t+1) ; 16 MFMAs from A-set (step t) ; load A-set (step t+2) ; 16 MFMAs from B-set (step t+1)
+// Every load has a whole step of MFMAs (>= 1024 cycles) between issue and first use, and no register copy carries
+// an operand set around the loop.  In the first form the copy out of the prefetch registers was rotated by the
+// compiler into the middle of the previous step, so the wave waited (s_waitcnt vmcnt) ~450 cycles after issuing the
+// loads with its matrix pipe idle: loads and MFMAs did not overlap (profiles/r01_strip_ablation.txt: 16.3 + 12.4 us
+// of work took 21.7 us).
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs<float> a) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef Mma<float> MM;
+  __shared__ __attribute__((aligned(16))) float Ks[SGP_SN][SGP_SLD];
+  __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
+  __shared__ float us[4][SGP_SM_MAX];
+  long e;
+  int bx;
+  sgp_block(a.efast, e, bx);
+  const float* __restrict__ x = a.x + e * a.sx;
+  const float* __restrict__ z = a.z + e * a.M * D;
+  const float* __restrict__ ell = a.ell + e * a.dl;
+  const float* __restrict__ Wf = a.Wf + e * a.M * a.M;
+  float* __restrict__ A = a.A + e * a.M * a.n;
+  const int M = (int)a.M, n = (int)a.n;
+  const int col0 = bx * SGP_SN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+
+  HB_SSTAMP(0);
+  // ---- K(z, x[strip]) -> LDS (as in the first form)
+  {
+    const int c = tid & 31, kq = tid >> 5;
+    const int cc = col0 + c < n ? col0 + c : n - 1;
+    float sc[D], xs[D];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
+      xs[dd] = x[cc * D + dd] * sc[dd];
+    }
+    constexpr int NTH = SGP_STRIP_THREADS;
+    constexpr int ZIT = (SGP_SM_MAX * D) / NTH, UIT = SGP_SM_MAX / NTH;
+    float zt[ZIT], ut[4][UIT];
+    const int npu = a.part ? ((int)a.P < 4 ? (int)a.P : 4) : 0;
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + NTH * it;
+      zt[it] = z[i < M * D ? i : 0];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int it = 0; it < UIT; ++it) {
+        const int i = tid + NTH * it;
+        ut[p][it] = p < npu ? a.u[e * a.P * a.M + (long)p * M + (i < M ? i : 0)] : 0.f;
+      }
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + NTH * it;
+      if (i < M * D) zs[i] = zt[it] * sc[i % D];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int it = 0; it < UIT; ++it) {
+        const int i = tid + NTH * it;
+        if (p < npu && i < M) us[p][i] = ut[p][it];
+      }
+    __syncthreads();
+#pragma unroll 4
+    for (int k4 = kq * 4; k4 < M; k4 += NTH / 8) {
+      float zq[4 * D];
+#pragma unroll
+      for (int q = 0; q < 4 * D; q += 4) {
+        const V4 zz = *reinterpret_cast<const V4*>(&zs[k4 * D + q]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) zq[q + s] = zz[s];
+      }
+      V4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float r2 = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          const float tt = zq[q * D + dd] - xs[dd];
+          r2 += tt * tt;
+        }
+        v[q] = hb_exp2_neg<float>(r2);
+      }
+      *reinterpret_cast<V4*>(&Ks[c][k4]) = v;
+    }
+  }
+  __syncthreads();
+  HB_SSTAMP(1);
+
+  // ---- this wave's tile-steps: [tile t0 = w: chunks 0..w] then [tile t1 = nT-1-w: chunks 0..t1]
+  const int nT = M / 32;
+  const int t1 = nT - 1 - w, t0 = w;
+  const int d0 = w < t1 ? w + 1 : 0;      // the middle tile of an odd count is taken once, as t1
+  const int d1 = w <= t1 ? t1 + 1 : 0;
+  const int nts = d0 + d1;
+  const int npart = a.part ? (int)a.P : 0;
+  float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int gc = col0 + li;
+  typename MM::Acc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  auto load = [&](V4 (&f)[4], int ts) {
+    const int tc = ts < nts ? ts : nts - 1;            // past the end: re-read the last step (never used)
+    const int tile = tc < d0 ? t0 : t1, Q = tc < d0 ? tc : tc - d0;
+    const float* p = Wf + ((long)(tile * nT + Q) << 10) + 4 * lane;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) f[v] = *reinterpret_cast<const V4*>(p + 256 * v);
+  };
+  auto compute = [&](const V4 (&f)[4], int ts) {
+    if (ts >= nts) return;                               // (uniform) the odd tail of the two-step loop
+    const int tile = ts < d0 ? t0 : t1, Q = ts < d0 ? ts : ts - d0;
+    V4 bv[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bv[v] = *reinterpret_cast<const V4*>(&Ks[li][32 * Q + 16 * h + 4 * v]);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = MM::mma(f[v][s], bv[v][s], acc);
+    if (ts == d0 - 1 || ts == nts - 1) {
+      // the tile is complete (its last chunk holds the diagonal block; the image has explicit zeros above it):
+      // store it and fold it into the column statistics; the stores drain under the next tile's MFMAs
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * tile + MM::acc_row(lane, r);
+        const float v = acc[r];
+        if (gc < n) A[(long)row * n + gc] = v;
+        if (a.part) {
+          cs[0] += v * v;
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            if (p < npart) cs[1 + p] += us[p][row] * v;
+        }
+        acc[r] = 0.f;
+      }
+    }
+  };
+  if (nts > 0) {
+    V4 fa[4], fb[4];
+    load(fa, 0);
+    // sched_barrier(0): nothing crosses.  Without them the scheduler hoists a set's reload above the last MFMAs
+    // that still read it (renaming the registers), which turns the loop-carried set into a copy at the back edge
+    // and moves the vmcnt wait to a few hundred cycles after the load.
+#pragma nounroll
+    for (int ts = 0; ts < nts; ts += 2) {
+      load(fb, ts + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fa, ts);
+      __builtin_amdgcn_sched_barrier(0);
+      load(fa, ts + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fb, ts + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  HB_SSTAMP(2);
+
+  // ---- epilogue: column statistics across lanes and waves
+  if (a.part) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) cs[q] += __shfl_xor(cs[q], 32);
+    __syncthreads();  // every wave is done reading the K block
+    float* red = &Ks[0][0];  // [8 waves][5][32]
+    if (lane < 32) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) red[(w * 5 + q) * 32 + lane] = cs[q];
+    }
+    __syncthreads();
+    if (tid < 32 && col0 + tid < n) {
+      float* pp = a.part + e * 5 * a.n + col0 + tid;  // gy = 1
+      for (int q = 0; q < 1 + npart; ++q) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SGP_STRIP_THREADS / 64; ++ww) sum += red[(ww * 5 + q) * 32 + tid];  // fixed order
+        pp[(long)q * n] = sum;
+      }
+    }
+  }
+  HB_SSTAMP(3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Column-strip contraction with bf16x3 operands ("fp16-in / fp32-accumulate" variant of BASELINE cfg 5, made usable).
+// Plain 16-bit operands are NOT usable for the whitened solve: entries of W = L^-1 reach +-30 and cancel, a single
+// bf16 rounding of W and K leaves a 27 % error in A = W K (profiles/r01_bf16_split_study.txt).  Each fp32 operand
+// is therefore split into three bf16 terms x = hi + mid + lo (W once per step by hb_cholesky_inverse, the RBF block
+// as it is synthesised); the six products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi carry all but O(2^-24) of
+// the fp32 product and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 12 MFMAs of 32 cycles per tile-step
+// instead of 16 of 64.  Same decomposition and loop shape as sgp_A_strip2_kernel; the operand images are
+// fragment-major so every load is one contiguous kilobyte per wave.
+// ---------------------------------------------------------------------------------------------------------------
+#define SGP_S3LD (SGP_SM_MAX + 8)  // bf16 row stride of the K planes: 1040 B, lanes of a column group hit distinct banks
+template <int D>
+__global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip3_kernel(SgpArgs<float> a) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 B8 __attribute__((ext_vector_type(8)));
+  typedef Mma<float> MM;
+  __shared__ __attribute__((aligned(16))) __bf16 K3[3][SGP_SN][SGP_S3LD];
+  __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
+  __shared__ float us[4][SGP_SM_MAX];
+  long e;
+  int bx;
+  sgp_block(a.efast, e, bx);
+  const float* __restrict__ x = a.x + e * a.sx;
+  const float* __restrict__ z = a.z + e * a.M * D;
+  const float* __restrict__ ell = a.ell + e * a.dl;
+  const __bf16* __restrict__ W3 = reinterpret_cast<const __bf16*>(a.W3) + e * a.M * a.M;
+  float* __restrict__ A = a.A + e * a.M * a.n;
+  const int M = (int)a.M, n = (int)a.n;
+  const int col0 = bx * SGP_SN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+
+  // ---- K(z, x[strip]) -> LDS as three bf16 planes [term][column][k]
+  {
+    const int c = tid & 31, kq = tid >> 5;
+    const int cc = col0 + c < n ? col0 + c : n - 1;
+    float sc[D], xs[D];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
+      xs[dd] = x[cc * D + dd] * sc[dd];
+    }
+    constexpr int NTH = SGP_STRIP_THREADS;
+    constexpr int ZIT = (SGP_SM_MAX * D) / NTH, UIT = SGP_SM_MAX / NTH;
+    float zt[ZIT], ut[4][UIT];
+    const int npu = a.part ? ((int)a.P < 4 ? (int)a.P : 4) : 0;
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + NTH * it;
+      zt[it] = z[i < M * D ? i : 0];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int it = 0; it < UIT; ++it) {
+        const int i = tid + NTH * it;
+        ut[p][it] = p < npu ? a.u[e * a.P * a.M + (long)p * M + (i < M ? i : 0)] : 0.f;
+      }
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + NTH * it;
+      if (i < M * D) zs[i] = zt[it] * sc[i % D];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int it = 0; it < UIT; ++it) {
+        const int i = tid + NTH * it;
+        if (p < npu && i < M) us[p][i] = ut[p][it];
+      }
+    __syncthreads();
+    // thread (c, kq) takes the groups of 8 consecutive k: kq*8, kq*8 + 128, ...
+#pragma unroll 2
+    for (int k8 = kq * 8; k8 < M; k8 += NTH / 4) {
+      B8 p0, p1, p2;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float r2 = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          const float tt = zs[(k8 + q) * D + dd] - xs[dd];
+          r2 += tt * tt;
+        }
+        const float kv = hb_exp2_neg<float>(r2);
+        const __bf16 b0 = (__bf16)kv;
+        const float r1 = kv - (float)b0;
+        const __bf16 b1 = (__bf16)r1;
+        p0[q] = b0, p1[q] = b1, p2[q] = (__bf16)(r1 - (float)b1);
+      }
+      *reinterpret_cast<B8*>(&K3[0][c][k8]) = p0;
+      *reinterpret_cast<B8*>(&K3[1][c][k8]) = p1;
+      *reinterpret_cast<B8*>(&K3[2][c][k8]) = p2;
+    }
+  }
+  __syncthreads();
+
+  const int nT = M / 32;
+  const int t1 = nT - 1 - w, t0 = w;
+  const int d0 = w < t1 ? w + 1 : 0;
+  const int d1 = w <= t1 ? t1 + 1 : 0;
+  const int nts = d0 + d1;
+  const int npart = a.part ? (int)a.P : 0;
+  float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int gc = col0 + li;
+  typename MM::Acc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  struct Frag {
+    B8 f[3][2];  // [term][k16-step]
+  };
+  auto load = [&](Frag& fr, int ts) {
+    const int tc = ts < nts ? ts : nts - 1;
+    const int tile = tc < d0 ? t0 : t1, Q = tc < d0 ? tc : tc - d0;
+    const __bf16* p = W3 + ((long)(tile * nT + Q) << 10) + 8 * lane;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) fr.f[t][q] = *reinterpret_cast<const B8*>(p + (long)t * a.plane3 + 512 * q);
+  };
+  auto compute = [&](const Frag& fr, int ts) {
+    if (ts >= nts) return;
+    const int tile = ts < d0 ? t0 : t1, Q = ts < d0 ? ts : ts - d0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      B8 b[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const B8*>(&K3[t][li][32 * Q + 16 * q + 8 * h]);
+      // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[2][q], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[1][q], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[1][q], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[0], acc, 0, 0, 0);
+    }
+    if (ts == d0 - 1 || ts == nts - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * tile + MM::acc_row(lane, r);
+        const float v = acc[r];
+        if (gc < n) A[(long)row * n + gc] = v;
+        if (a.part) {
+          cs[0] += v * v;
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            if (p < npart) cs[1 + p] += us[p][row] * v;
+        }
+        acc[r] = 0.f;
+      }
+    }
+  };
+  if (nts > 0) {
+    Frag fa, fb;
+    load(fa, 0);
+#pragma nounroll
+    for (int ts = 0; ts < nts; ts += 2) {
+      load(fb, ts + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fa, ts);
+      __builtin_amdgcn_sched_barrier(0);
+      load(fa, ts + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fb, ts + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  if (a.part) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) cs[q] += __shfl_xor(cs[q], 32);
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&K3[0][0][0]);  // [8 waves][5][32]
+    if (lane < 32) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) red[(w * 5 + q) * 32 + lane] = cs[q];
+    }
+    __syncthreads();
+    if (tid < 32 && col0 + tid < n) {
+      float* pp = a.part + e * 5 * a.n + col0 + tid;
+      for (int q = 0; q < 1 + npart; ++q) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SGP_STRIP_THREADS / 64; ++ww) sum += red[(ww * 5 + q) * 32 + tid];
+        pp[(long)q * n] = sum;
+      }
+    }
+  }
+}
+
 // diagnostic switch: HB_SGP_NO_STRIP=1 forces the tiled kernels (A/B timing)
 static inline bool hb_sgp_no_strip() {
   static const bool v = getenv("HB_SGP_NO_STRIP") != nullptr;
@@ -594,8 +982,10 @@ static int sgp_A_strip_launch(SgpArgs<float> a, long E, hipStream_t stream) {
   dim3 grid = sgp_grid(hb_cdiv(a.n, SGP_SN), 1, E, a.efast);
 #define HB_STRIP(D_)                                                                                          \
   do {                                                                                                        \
-    if (a.Wf)                                                                                                 \
-      hipLaunchKernelGGL((sgp_A_strip_kernel<D_, true>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);        \
+    if (a.W3)                                                                                                 \
+      hipLaunchKernelGGL((sgp_A_strip3_kernel<D_>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);             \
+    else if (a.Wf)                                                                                            \
+      hipLaunchKernelGGL((sgp_A_strip2_kernel<D_>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);             \
     else                                                                                                      \
       hipLaunchKernelGGL((sgp_A_strip_kernel<D_, false>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);       \
   } while (0)
@@ -770,8 +1160,11 @@ static inline int sgp_grid_y(long E, long n, int nRB) {
 
 template <typename T>
 static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* Wf,
-                   const T* u, const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* A, T* f, T* v, long E,
-                   long n, long M, long d, long P, T* ws, hipStream_t stream) {
+                   int prec, const T* u, const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* A, T* f, T* v,
+                   long E, long n, long M, long d, long P, T* ws, hipStream_t stream) {
+  HB_REQUIRE(prec == HB_PREC_NATIVE || prec == HB_PREC_BF16X3, "hb_sgp_fwd: unknown precision %d", prec);
+  HB_REQUIRE(prec == HB_PREC_NATIVE || (sizeof(T) == 4 && Wf && M % 32 == 0 && M <= SGP_SM_MAX && d <= SGP_DREG && P <= 4 && ws),
+             "hb_sgp_fwd: bf16x3 needs fp32, the bf16 images in Wfrag, M %% 32 == 0, M <= %d, d <= %d, P <= 4", SGP_SM_MAX, SGP_DREG);
   HB_REQUIRE(kind == HB_KERN_RBF, "hb_sgp_fwd: only the UnitRBF kernel is fused (kind=%d)", kind);
   HB_REQUIRE(mode == HB_SGP_NEGLECTED || mode == HB_SGP_DIAGONAL, "hb_sgp_fwd: unknown mode %d", mode);
   HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1 && P >= 0, "hb_sgp_fwd: bad extents");
@@ -789,8 +1182,10 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     SgpArgs<T> a;
     a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.Wf = Wf; a.u = u; a.A = A;
     a.n = n; a.M = M; a.d = d; a.P = P;
+    a.W3 = prec == HB_PREC_BF16X3 ? (const void*)(Wf + 2 * E * M * M) : nullptr;
+    a.plane3 = E * M * M;
     a.part = ws + E * n + E * M * d;
-    const bool strip = sizeof(T) == 4 && sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip();
+    const bool strip = sizeof(T) == 4 && ((sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip()) || prec == HB_PREC_BF16X3);
     const int gyp = strip ? 1 : gy;  // partial rows of the column statistics
     int rc;
     if (strip) {
@@ -823,6 +1218,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     SgpArgs<T> a;
     a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.Wf = nullptr; a.u = u; a.A = A;
     a.n = n; a.M = M; a.d = d; a.P = P;
+    a.W3 = nullptr; a.plane3 = 0;
     a.part = nullptr;
     dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), gy, E, a.efast);
     int rc = sgp_A_launch<T>(a, grid, stream);
@@ -837,8 +1233,11 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
 // A = W K(z,x) alone (posterior-prediction callers need A without a draw; also
 // lets bench.py time the contraction kernel in isolation).
 template <typename T>
-static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* Wf, T* A,
-                      long E, long n, long M, long d, hipStream_t stream) {
+static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* Wf, int prec,
+                      T* A, long E, long n, long M, long d, hipStream_t stream) {
+  HB_REQUIRE(prec == HB_PREC_NATIVE || prec == HB_PREC_BF16X3, "hb_sgp_A: unknown precision %d", prec);
+  HB_REQUIRE(prec == HB_PREC_NATIVE || (sizeof(T) == 4 && Wf && M % 32 == 0 && M <= SGP_SM_MAX && d <= SGP_DREG),
+             "hb_sgp_A: bf16x3 needs fp32, the bf16 images in Wfrag, M %% 32 == 0, M <= %d, d <= %d", SGP_SM_MAX, SGP_DREG);
   HB_REQUIRE(kind == HB_KERN_RBF, "hb_sgp_A: only the UnitRBF kernel is fused (kind=%d)", kind);
   HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1, "hb_sgp_A: bad extents");
   HB_REQUIRE(dl == 1 || dl == d, "hb_sgp_A: lengthscales must have 1 or d entries");
@@ -849,36 +1248,39 @@ static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, l
   SgpArgs<T> a;
   a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.Wf = Wf; a.u = nullptr; a.A = A;
   a.n = n; a.M = M; a.d = d; a.P = 0;
+  a.W3 = prec == HB_PREC_BF16X3 ? (const void*)(Wf + 2 * E * M * M) : nullptr;
+  a.plane3 = E * M * M;
   a.part = nullptr;
-  if (sizeof(T) == 4 && sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip()) return sgp_A_strip_launch(a, E, stream);
+  if (sizeof(T) == 4 && ((sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip()) || prec == HB_PREC_BF16X3))
+    return sgp_A_strip_launch(a, E, stream);
   const int nRB = hb_cdiv(M, SGP_BM);
   dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), sgp_grid_y(E, n, nRB), E, a.efast);
   return sgp_A_launch<T>(a, grid, stream);
 }
 extern "C" int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
-                            const float* W, const float* Wfrag, float* A, long E, long n, long M, long d,
+                            const float* W, const float* Wfrag, int prec, float* A, long E, long n, long M, long d,
                             void* stream) {
-  return sgp_A_only<float>(kind, x, sx, z, ell, dl, W, Wfrag, A, E, n, M, d, (hipStream_t)stream);
+  return sgp_A_only<float>(kind, x, sx, z, ell, dl, W, Wfrag, prec, A, E, n, M, d, (hipStream_t)stream);
 }
 extern "C" int hb_sgp_A_f64(int kind, const double* x, long sx, const double* z, const double* ell, long dl,
-                            const double* W, const double* Wfrag, double* A, long E, long n, long M, long d,
+                            const double* W, const double* Wfrag, int prec, double* A, long E, long n, long M, long d,
                             void* stream) {
-  return sgp_A_only<double>(kind, x, sx, z, ell, dl, W, Wfrag, A, E, n, M, d, (hipStream_t)stream);
+  return sgp_A_only<double>(kind, x, sx, z, ell, dl, W, Wfrag, prec, A, E, n, M, d, (hipStream_t)stream);
 }
 
 extern "C" int hb_sgp_fwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell, long dl,
-                              const float* W, const float* Wfrag, const float* u, const float* eps_in, uint64_t* rng,
-                              long rng_lanes, float* eps_out, float* A, float* f, float* v, long E, long n, long M,
-                              long d, long P, float* ws, void* stream) {
-  return sgp_fwd<float>(kind, mode, x, sx, z, ell, dl, W, Wfrag, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E, n, M,
-                        d, P, ws, (hipStream_t)stream);
+                              const float* W, const float* Wfrag, int prec, const float* u, const float* eps_in,
+                              uint64_t* rng, long rng_lanes, float* eps_out, float* A, float* f, float* v, long E,
+                              long n, long M, long d, long P, float* ws, void* stream) {
+  return sgp_fwd<float>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E,
+                        n, M, d, P, ws, (hipStream_t)stream);
 }
 extern "C" int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
-                              long dl, const double* W, const double* Wfrag, const double* u, const double* eps_in,
-                              uint64_t* rng, long rng_lanes, double* eps_out, double* A, double* f, double* v, long E,
-                              long n, long M, long d, long P, double* ws, void* stream) {
-  return sgp_fwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E, n, M,
-                         d, P, ws, (hipStream_t)stream);
+                              long dl, const double* W, const double* Wfrag, int prec, const double* u,
+                              const double* eps_in, uint64_t* rng, long rng_lanes, double* eps_out, double* A, double* f,
+                              double* v, long E, long n, long M, long d, long P, double* ws, void* stream) {
+  return sgp_fwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E,
+                         n, M, d, P, ws, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

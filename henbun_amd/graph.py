@@ -1021,10 +1021,18 @@ def _cholesky_emit(plan, node):
         # fragment-major copies of W / W^T for the M^2 n contractions that consume this inverse (csrc/sgp.hip)
         frag = None
         M = node.outputs[0].shape[-1]
-        if plan.dtype == plan.torch.float32 and M % 32 == 0 and M >= 32 and any(c.op in ("sgp", "sgp_grad") for c in plan._consumers.get(inv_node.outputs[0], ())):
-            frag = plan.scratch((2 * max(int(np.prod(node.outputs[0].shape)), 1),))
-            plan._wfrag[inv_node.outputs[0]] = frag
-        plan.steps.append(lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws, frag=frag))
+        users = list(plan._consumers.get(inv_node.outputs[0], ()))
+        users += [c2 for c in users if c.op == "stop_gradient" for c2 in plan._consumers.get(c.outputs[0], ())]
+        bf3 = False
+        if plan.dtype == plan.torch.float32 and M % 32 == 0 and M >= 32 and any(c.op in ("sgp", "sgp_grad") for c in users):
+            from ._settings import settings as _st
+
+            # settings.numerics.contraction = bf16x3: the M^2 n contractions take three-term bf16 operands
+            # (fp32-level accuracy at the bf16 MFMA rate, include/henbun_hip.h HB_PREC_BF16X3); M <= 512 only
+            bf3 = str(getattr(_st.numerics, "contraction", "native")) == "bf16x3" and M <= 512
+            frag = plan.scratch(((5 if bf3 else 2) * max(int(np.prod(node.outputs[0].shape)), 1),))
+            plan._wfrag[inv_node.outputs[0]] = (frag, bf3)
+        plan.steps.append(lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws, frag=frag, frag_bf16x3=bf3))
         return
     plan.steps.append(lambda: H.cholesky(a, out=out, info=info))
 
@@ -1381,6 +1389,12 @@ def sgp_samples(x, z, ell, L, u, mode="diagonal", eps=None) -> Tuple[Tensor, Ten
     return tuple(nd.outputs)
 
 
+def _through_stop_gradient(t):
+    while t.node.op == "stop_gradient":
+        t = t.node.inputs[0]
+    return t
+
+
 def _sgp_emit(plan, node):
     H = plan.H
     x, z, ell, L, W, u = (plan.buf(t) for t in node.inputs[:6])
@@ -1388,8 +1402,12 @@ def _sgp_emit(plan, node):
     outs = tuple(plan.out(t) for t in node.outputs)
     mode = SGP_MODES[node.attrs["mode"]]
     rng = plan.rng("local") if (eps_in is None and mode == 1) else None
-    wfrag = plan._wfrag.get(node.inputs[4])
-    plan.steps.append(lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag))
+    wfrag, bf3 = plan._wfrag.get(_through_stop_gradient(node.inputs[4]), (None, False))
+    # bf16x3 operands (settings.numerics.contraction): column-strip kernel only (d <= 4, at most 4 latent functions)
+    bf3 = bf3 and node.inputs[0].shape[-1] <= 4 and node.inputs[5].shape[-2] <= 4
+    prec = H.PREC_BF16X3 if bf3 else H.PREC_NATIVE
+    plan.steps.append(lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag,
+                                        prec=prec))
 
 
 def _sgp_vjp(node, gs):

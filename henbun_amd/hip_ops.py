@@ -572,7 +572,10 @@ def cholesky(A, out=None, info=None):
     return out, info
 
 
-def cholesky_inverse(A, out=None, inv=None, info=None, ws=None, frag=None):
+PREC_NATIVE, PREC_BF16X3 = 0, 1
+
+
+def cholesky_inverse(A, out=None, inv=None, info=None, ws=None, frag=None, frag_bf16x3=False):
     """(L, W, info): L = chol(A) and W = L^-1 from one fused launch sequence (batched over leading dims).
     `frag` (2*B*M*M elements, M % 32 == 0): receives the fragment-major copies of W and W^T (see the header)."""
     _chk(A)
@@ -588,8 +591,9 @@ def cholesky_inverse(A, out=None, inv=None, info=None, ws=None, frag=None):
     if ws is None:
         ws = workspace(A.dtype, A.device, max(B * M * M, 1))
     if frag is not None:
-        assert frag.numel() >= 2 * B * M * M and M % 32 == 0 and frag.dtype == A.dtype
-    _lib.lib().call("hb_cholesky_inverse" + _suf(A), _p(A), _p(out), _p(inv), B, M, _p(info), _p(ws), _p(frag), stream())
+        assert frag.numel() >= (5 if frag_bf16x3 else 2) * B * M * M and M % 32 == 0 and frag.dtype == A.dtype
+    _lib.lib().call("hb_cholesky_inverse" + _suf(A), _p(A), _p(out), _p(inv), B, M, _p(info), _p(ws), _p(frag),
+                    int(bool(frag_bf16x3 and frag is not None)), stream())
     return out, inv, info
 
 
@@ -615,7 +619,7 @@ def _sgp_dims(x, z, u):
     return E, n, M, d, P, sx
 
 
-def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None, wfrag=None):
+def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None, wfrag=None, prec=PREC_NATIVE):
     """Returns (f[E?,P,n], A[E?,M,n], v[E?,n], eps[E?,n]).  `wfrag`: cholesky_inverse's fragment-major copies of W."""
     for t in (x, z, ell, W, u):
         _chk(t)
@@ -632,12 +636,12 @@ def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None,
     dl = ell.numel() // E
     rp, rl = _rng_args(rng)
     ws = workspace(dt, dev, int(_lib.lib().raw("hb_sgp_ws_elems")(E, n, M, d, P)))
-    _lib.lib().call("hb_sgp_fwd" + _suf(x), KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(wfrag), _p(u), _p(eps_in),
+    _lib.lib().call("hb_sgp_fwd" + _suf(x), KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(wfrag), int(prec), _p(u), _p(eps_in),
                     rp, rl, _p(eps), _p(A), _p(f), _p(v), E, n, M, d, P, _p(ws), stream())
     return f, A, v, eps
 
 
-def sgp_A(x, z, ell, W, out=None, wfrag=None):
+def sgp_A(x, z, ell, W, out=None, wfrag=None, prec=PREC_NATIVE):
     """A = W K(z,x): the M^2 n contraction alone (hb_sgp_A)."""
     E = z.shape[0] if z.dim() == 3 else 1
     M, d = z.shape[-2], z.shape[-1]
@@ -645,8 +649,8 @@ def sgp_A(x, z, ell, W, out=None, wfrag=None):
     sx = n * d if (x.dim() == 3 and x.shape[0] == E and E > 1) else 0
     if out is None:
         out = _empty(((E,) if z.dim() == 3 else ()) + (M, n), dtype=x.dtype, device=x.device)
-    _lib.lib().call("hb_sgp_A" + _suf(x), KERN_RBF, _p(x), sx, _p(z), _p(ell), ell.numel() // E, _p(W), _p(wfrag), _p(out),
-                    E, n, M, d, stream())
+    _lib.lib().call("hb_sgp_A" + _suf(x), KERN_RBF, _p(x), sx, _p(z), _p(ell), ell.numel() // E, _p(W), _p(wfrag), int(prec),
+                    _p(out), E, n, M, d, stream())
     return out
 
 

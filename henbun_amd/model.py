@@ -185,7 +185,7 @@ class Optimizer:
     # ------------------------------------------------------------------ plans
     def _settings_key(self):
         n = settings.numerics
-        return (n.jitter_level, n.clip_by_value, n.clip_value_min, n.clip_value_max, str(getattr(n, "kl_form", "mc")),
+        return (n.jitter_level, n.clip_by_value, n.clip_value_min, n.clip_value_max, str(getattr(n, "kl_form", "mc")), str(getattr(n, "contraction", "native")),
                 str(settings.runtime.index_source), bool(settings.runtime.fuse_elementwise),
                 bool(getattr(settings.runtime, "force_dp", False)))
 

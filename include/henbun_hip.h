@@ -306,11 +306,14 @@ int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void*
  * Wfrag (nullable; 2*B*M*M elements, needs M % 32 == 0): fragment-major copies of W and of W^T --
  * [B][M/32 row tiles t][M/32 k chunks Q][4 v][64 lanes (li + 32 h)][4 s] = W[32t+li][32Q+16h+4v+s] (then the
  * same for W^T) -- the order in which the MFMA operand loads of hb_sgp_fwd / hb_sgp_bwd consume them, so that
- * every load instruction reads one contiguous kilobyte. */
+ * every load instruction reads one contiguous kilobyte.
+ * frag_bf16x3 != 0 (fp32 only): Wfrag has 5*B*M*M elements and, behind the two fp32 images, receives the bf16x3
+ * operand images of W and W^T (3 + 3 planes of B*M*M bf16: each fp32 entry split into hi + mid + lo bf16 terms;
+ * [term][B][t][Q][k16-step q][64 lanes][8] = X[32t+li][32Q+16q+8h+j]) for the HB_PREC_BF16X3 contractions. */
 int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long B, long M, int* info, float* ws,
-                            float* Wfrag, void* stream);
+                            float* Wfrag, int frag_bf16x3, void* stream);
 int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info,
-                            double* ws, double* Wfrag, void* stream);
+                            double* ws, double* Wfrag, int frag_bf16x3, void* stream);
 /* W = L^{-1} (lower triangular inverse), batched.  Used in place of
  * tf.matrix_triangular_solve(Lm, .) (reference gp/gp.py:162,169): the
  * reference's own batched branch forms the explicit inverse the same way.
@@ -321,6 +324,12 @@ int hb_trinv_f64(const double* L, double* W, long B, long M, double* ws, void* s
 /* ---- K5/K6: fused sparse-GP conditional (reference gp/gp.py:99-143 samples,
  *      :146-162 _effective_LT, :177-189 _additional_cov 'diagonal') -------- */
 enum { HB_SGP_NEGLECTED = 0, HB_SGP_DIAGONAL = 1 };
+/* Operand precision of the M^2 n contraction.  NATIVE: the arithmetic type (fp32 / fp64 MFMA).  BF16X3 (fp32
+ * only; BASELINE cfg 5's "fp16-with-fp32-accum" variant in a usable form): every fp32 operand is split into three
+ * bf16 terms and the six significant cross products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation --
+ * fp32-level accuracy (plain 16-bit operands leave a 27 % error in L^-1 K) at the bf16 matrix rate.  Needs the
+ * bf16 images of hb_cholesky_inverse(frag_bf16x3 = 1) in Wfrag. */
+enum { HB_PREC_NATIVE = 0, HB_PREC_BF16X3 = 1 };
 /* Per expert e < E (all arrays carry a leading E; x may be shared: sx = 0):
  *   Kmn = k(z, x)            [M,n]   (never written to memory)
  *   A   = W Kmn              [M,n]   W = chol(Kmm + jitter I)^{-1}
@@ -333,20 +342,21 @@ enum { HB_SGP_NEGLECTED = 0, HB_SGP_DIAGONAL = 1 };
  * ws >= hb_sgp_ws_elems(...) elements. */
 long hb_sgp_ws_elems(long E, long n, long M, long d, long P);
 int hb_sgp_fwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell,
-                   long dl, const float* W, const float* Wfrag, const float* u, const float* eps_in,
-                   uint64_t* rng, long rng_lanes, float* eps_out, float* A, float* f, float* v, long E,
-                   long n, long M, long d, long P, float* ws, void* stream);
+                   long dl, const float* W, const float* Wfrag, int prec, const float* u,
+                   const float* eps_in, uint64_t* rng, long rng_lanes, float* eps_out, float* A, float* f,
+                   float* v, long E, long n, long M, long d, long P, float* ws, void* stream);
 int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
-                   long dl, const double* W, const double* Wfrag, const double* u, const double* eps_in,
-                   uint64_t* rng, long rng_lanes, double* eps_out, double* A, double* f, double* v,
-                   long E, long n, long M, long d, long P, double* ws, void* stream);
+                   long dl, const double* W, const double* Wfrag, int prec, const double* u,
+                   const double* eps_in, uint64_t* rng, long rng_lanes, double* eps_out, double* A,
+                   double* f, double* v, long E, long n, long M, long d, long P, double* ws,
+                   void* stream);
 /* The contraction alone, A = W k(z,x) (posterior-prediction callers; isolated timing). */
 int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
-                 const float* W, const float* Wfrag, float* A, long E, long n, long M, long d,
+                 const float* W, const float* Wfrag, int prec, float* A, long E, long n, long M, long d,
                  void* stream);
 int hb_sgp_A_f64(int kind, const double* x, long sx, const double* z, const double* ell, long dl,
-                 const double* W, const double* Wfrag, double* A, long E, long n, long M, long d,
-                 void* stream);
+                 const double* W, const double* Wfrag, int prec, double* A, long E, long n, long M,
+                 long d, void* stream);
 /* VJP given fbar [E,P,n]:
  *   Abar = u^T fbar + A diag(c),  c = -eps sign(v)/sqrt|v| * sum_p fbar_p
  *   Kbar = W^T Abar            [E,M,n]  (scratch output, kept for Lbar)

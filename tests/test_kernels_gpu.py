@@ -323,6 +323,47 @@ def test_matmul_activation_gradient_epilogue(H, p):
         H.matmul(dev(g, dt), dev(w, dt), act="tanh", actgrad=dev(y, dt), bias=dev(rng.randn(50), dt))
 
 
+@pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])
+def test_matmul_in_workgroup_split_k_small_gemms(H, tA, tB):
+    """fp32 products with few output tiles (the M^3 GEMMs of the Cholesky VJP: 512^3 at cfg 2, 8 x 512^3 at cfg 5)
+    run as one 32x32 tile per workgroup with the contraction split over its four waves and every epilogue applied in
+    the workgroup (matmul_wgk_kernel): all transposes, batch, bias + activation, beta, tril / Phi / symmetrise."""
+    dt = torch.float32
+    rng = np.random.RandomState(7)
+    for batch, m, n, k in ((1, 512, 512, 512), (3, 64, 96, 128), (1, 128, 32, 256), (8, 128, 128, 384)):
+        a = rng.randn(batch, *((k, m) if tA else (m, k)))
+        b = rng.randn(batch, *((n, k) if tB else (k, n)))
+        full = np.einsum("bij,bjk->bik", np.transpose(a, (0, 2, 1)) if tA else a, np.transpose(b, (0, 2, 1)) if tB else b)
+        A_, B_ = dev(a if batch > 1 else a[0], dt), dev(b if batch > 1 else b[0], dt)
+        sq = (lambda x: x if batch > 1 else x[0])
+        tol = dict(rtol=1e-4, atol=2e-4 * np.sqrt(k))
+        assert_close(H.matmul(A_, B_, transA=tA, transB=tB, alpha=-0.5), sq(-0.5 * full), tol)
+        bias = rng.randn(n)
+        assert_close(H.matmul(A_, B_, transA=tA, transB=tB, bias=dev(bias, dt), act="tanh", alpha=0.01),
+                     sq(np.tanh(0.01 * full + bias)), dict(rtol=1e-4, atol=1e-5))
+        c0 = rng.randn(*full.shape)
+        out = dev(sq(c0), dt)
+        H.matmul(A_, B_, transA=tA, transB=tB, out=out, beta=2.0)
+        assert_close(out, sq(full + 2.0 * c0), tol)
+        if m == n:
+            got = host(H.matmul(A_, B_, transA=tA, transB=tB, tril_out=True))
+            assert np.all(np.triu(got, 1) == 0) and np.allclose(got, sq(np.tril(full)), **tol)
+            phi = np.tril(full, -1) + 0.5 * np.einsum("bii->bi", full)[:, :, None] * np.eye(m)
+            got = host(H.matmul(A_, B_, transA=tA, transB=tB, epilogue=H.MM_PHI_OUT))
+            assert np.all(np.triu(got, 1) == 0) and np.allclose(got, sq(phi), **tol)
+            got = host(H.matmul(A_, B_, transA=tA, transB=tB, epilogue=H.MM_SYM_OUT))
+            assert np.allclose(got, sq(0.5 * (full + np.transpose(full, (0, 2, 1)))), **tol)
+            assert np.array_equal(got, np.swapaxes(got, -1, -2)), "symmetrised output must be exactly symmetric"
+            got = host(H.matmul(A_, B_, transA=tA, transB=tB, lower_out=True))
+            il = np.tril_indices(m)
+            assert np.allclose(got[..., il[0], il[1]], sq(full)[..., il[0], il[1]], **tol)
+    # A = I with an asymmetric B through this kernel (accumulator row/column map, k mapping of both operand forms)
+    bb = np.arange(128 * 128, dtype=np.float64).reshape(128, 128) % 251
+    eye = np.eye(128)
+    assert np.array_equal(host(H.matmul(dev(eye, dt), dev(bb if not tB else bb.T.copy(), dt), transA=tA, transB=tB)), bb)
+    assert np.array_equal(host(H.matmul(dev(bb if not tA else bb.T.copy(), dt), dev(eye, dt), transA=tA, transB=tB)), bb)
+
+
 def test_matmul_asymmetric_identity(H):
     # A = I with an ASYMMETRIC B catches a swapped accumulator row/col map
     for dt in (torch.float32, torch.float64):
@@ -608,6 +649,42 @@ def test_fragment_major_copies_of_the_inverse(H):
         for p_, q_ in zip(a, b_):
             assert torch.equal(p_, q_)
         assert torch.equal(H.sgp_A(x, zz, ell, Wd), H.sgp_A(x, zz, ell, Wd, wfrag=frag))
+
+
+def test_bf16x3_contraction_has_fp32_accuracy(H):
+    """HB_PREC_BF16X3 (BASELINE cfg 5's "fp16-with-fp32-accum" variant in a usable form): A = L^-1 K(z,x) with every
+    operand split into three bf16 terms on v_mfma_f32_32x32x16_bf16 is as close to the fp64 result as the fp32-operand
+    kernel is (cfg-2-like Kmm, cond ~ 1e5: entries of L^-1 reach +-30 and cancel), and the column statistics /
+    draw built on it agree; plain 16-bit operands would be off by ~27 % (profiles/r01_bf16_split_study.txt)."""
+    rng = np.random.RandomState(11)
+    for E, M, n in ((1, 512, 4096), (2, 256, 1000), (1, 96, 333)):
+        z = np.broadcast_to(np.linspace(0, M / 2.0, M)[None, :, None], (E, M, 1)).copy()
+        ellv = np.ones((E, 1))
+        x = rng.uniform(0, M / 2.0, (n, 1))
+        zz, ell, xx = dev(z, torch.float32), dev(ellv, torch.float32), dev(x, torch.float32)
+        K = H.gram_fwd(zz, zz, ell, diag_add=1e-4).reshape(E, M, M)
+        frag = torch.zeros(5 * E * M * M, dtype=torch.float32, device="cuda")
+        L, W, info = H.cholesky_inverse(K, frag=frag, frag_bf16x3=True)
+        assert not info.cpu().numpy().any()
+        u = dev(rng.randn(E, 1, M), torch.float32)
+        eps = dev(rng.randn(E, n), torch.float32)
+        if E == 1:
+            zz, ell, u, eps, Wd = zz[0], ell[0], u[0], eps[0], W.reshape(M, M)
+        else:
+            Wd = W
+        f32 = H.sgp_fwd(xx, zz, ell, Wd, u, eps_in=eps, wfrag=frag)
+        fb3 = H.sgp_fwd(xx, zz, ell, Wd, u, eps_in=eps, wfrag=frag, prec=H.PREC_BF16X3)
+        # fp64 reference from the SAME fp32 factor (the comparison is about the contraction, not the factorisation)
+        Wh = W.double().cpu().numpy().reshape(E, M, M)
+        Kzx = np.exp(-0.5 * (z[:, :, None, 0] - x[None, None, :, 0]) ** 2)
+        Aref = Wh @ Kzx
+        A32, Ab3 = f32[1].double().cpu().numpy().reshape(E, M, n), fb3[1].double().cpu().numpy().reshape(E, M, n)
+        e32, eb3 = np.abs(A32 - Aref).max(), np.abs(Ab3 - Aref).max()
+        assert eb3 <= 2.0 * e32 + 1e-6, (E, M, n, e32, eb3)
+        assert np.abs(Ab3 - A32).max() <= 4.0 * e32 + 1e-6
+        for a_, b_ in ((f32[0], fb3[0]), (f32[2], fb3[2])):      # f and v from the column statistics
+            assert np.abs(a_.double().cpu().numpy() - b_.double().cpu().numpy()).max() < 5e-4
+        assert torch.equal(H.sgp_A(xx, zz, ell, Wd, wfrag=frag, prec=H.PREC_BF16X3), fb3[1])
 
 
 # ------------------------------------------------------------------ Adam + graphs

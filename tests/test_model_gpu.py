@@ -468,6 +468,36 @@ def test_cfg2_full_size_properties_fp32():
     assert np.abs(f.double().cpu().numpy() - fd).max() < 2e-3
 
 
+def test_bf16x3_contraction_mode_tracks_the_fp32_step():
+    """settings.numerics.contraction = bf16x3: the forward M^2 n contraction on three-term bf16 operands gives the
+    fp32 step's ELBO and gradients to fp32 accuracy (both measured against the fp64 oracle), and trains."""
+    res = {}
+    for mode in ("native", "bf16x3"):
+        cfg = hb.settings.get_settings()
+        cfg.numerics.jitter_level = 1e-4
+        cfg.numerics.contraction = mode
+        with hb.settings.temp_settings(cfg):
+            m, data = make_svgp(20000, 512, 4096, "diagonal", "float32")
+            opt = m.ELBO()
+            opt.compile()
+            res[mode] = opt.gradients(minibatch_size=4096, indices=data[5])
+            if mode == "bf16x3":
+                fn, params = oracle_svgp(m, data, 1e-4, "diagonal")
+                ref_val, ref = O.grads_of(fn, params)
+                m.u.inject_noise(None)
+                m.eps = None
+                o2 = m.ELBO()
+                o2.compile(optimizer=tf.train.AdamOptimizer(1e-3))
+                o2.optimize(maxiter=5, minibatch_size=4096)
+                assert np.isfinite(o2.run(minibatch_size=4096))
+    (v0, g0), (v1, g1) = res["native"], res["bf16x3"]
+    e0, e1 = abs(v0 - ref_val.item()), abs(v1 - ref_val.item())
+    assert e1 <= 2.0 * e0 + 1e-4 * abs(ref_val.item()), (e0, e1)
+    for mine, theirs in NAMES:
+        r0, r1 = rel_err(g0[mine], ref[theirs].numpy()), rel_err(g1[mine], ref[theirs].numpy())
+        assert r1 <= 2.0 * r0 + 1e-3, (mine, r0, r1)
+
+
 def test_injected_indices_out_of_range_raise():
     """A caller-supplied minibatch index outside the data set is an error, not silently zero-filled rows
     (the reference would fail inside tf.gather / numpy indexing, param.py:733-739)."""

@@ -1,41 +1,61 @@
-// Diagnostic build of the column-strip contraction with in-kernel phase stamps (not part of the product).
+// Diagnostic build of the column-strip contraction (second form, fragment-major W) with in-kernel phase stamps for
+// EVERY workgroup and wave (not part of the product): hipcc -O3 --offload-arch=gfx950 tools/strip_stamps.hip -o /tmp/ss
 #include <hip/hip_runtime.h>
-__device__ long long hb_sstamps[8 * 8];
-#define HB_SSTAMP(i)                                                                              \
-  do {                                                                                            \
-    if (blockIdx.x == 7 && (threadIdx.x & 63) == 0) hb_sstamps[(threadIdx.x >> 6) * 8 + (i)] = clock64(); \
+__device__ long long hb_sstamps[256 * 8 * 4];
+__device__ long long hb_srt[256 * 2];
+#define HB_SSTAMP(i)                                                                                         \
+  do {                                                                                                       \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {                                                       \
+      hb_sstamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + (i)] = clock64();                               \
+      if (threadIdx.x == 0 && ((i) == 0 || (i) == 3)) hb_srt[blockIdx.x * 2 + ((i) == 3)] = wall_clock64(); \
+    }                                                                                                        \
   } while (0)
 #include "../henbun_amd/csrc/runtime.hip"
 #include "../henbun_amd/csrc/elementwise.hip"
+#include "../henbun_amd/csrc/gram.hip"
 #include "../henbun_amd/csrc/linalg.hip"
 #include "../henbun_amd/csrc/sgp.hip"
+#include <algorithm>
 #include <stdio.h>
 #include <vector>
 int main() {
   const int M = 512, n = 8192;
-  float *W, *z, *x, *A, *ell;
-  (void)hipMalloc(&W, M * M * 4); (void)hipMalloc(&z, M * 4); (void)hipMalloc(&x, n * 4); (void)hipMalloc(&A, (size_t)M * n * 4); (void)hipMalloc(&ell, 4);
-  std::vector<float> h(M * M, 0.01f), hz(M), hx(n);
+  float *K, *L, *W, *ws, *Wf, *z, *x, *A, *ell;
+  int* info;
+  (void)hipMalloc(&K, M * M * 4); (void)hipMalloc(&L, M * M * 4); (void)hipMalloc(&W, M * M * 4); (void)hipMalloc(&ws, M * M * 4);
+  (void)hipMalloc(&Wf, 2 * M * M * 4); (void)hipMalloc(&info, 4);
+  (void)hipMalloc(&z, M * 4); (void)hipMalloc(&x, n * 4); (void)hipMalloc(&A, (size_t)M * n * 4); (void)hipMalloc(&ell, 4);
+  std::vector<float> hz(M), hx(n);
   for (int i = 0; i < M; ++i) hz[i] = i * 0.5f;
   for (int i = 0; i < n; ++i) hx[i] = (i % 997) * 0.25f;
   float one = 1.f;
-  (void)hipMemcpy(W, h.data(), M * M * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(z, hz.data(), M * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(ell, &one, 4, hipMemcpyHostToDevice);
+  if (hb_gram_fwd_f32(0, z, 0, z, 0, ell, 0, 1, K, 1, M, M, 1, 1e-3, 0)) { printf("gram: %s\n", hb_last_error_string()); return 1; }
+  if (hb_cholesky_inverse_f32(K, L, W, 1, M, info, ws, Wf, 0)) { printf("chol: %s\n", hb_last_error_string()); return 1; }
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) hb_sgp_A_f32(0, x, 0, z, ell, 1, W, A, 1, n, M, 1, 0);
+  for (int i = 0; i < 5; ++i) hb_sgp_A_f32(0, x, 0, z, ell, 1, W, Wf, A, 1, n, M, 1, 0);
   (void)hipEventRecord(e0);
-  for (int i = 0; i < 50; ++i) hb_sgp_A_f32(0, x, 0, z, ell, 1, W, A, 1, n, M, 1, 0);
+  for (int i = 0; i < 50; ++i) hb_sgp_A_f32(0, x, 0, z, ell, 1, W, Wf, A, 1, n, M, 1, 0);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-  printf("hb_sgp_A_f32 (strip): %.2f us per launch (back-to-back stream launches)\n", ms * 1e3 / 50);
-  long long st[64];
-  (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(hb_sstamps), sizeof(st));
-  for (int w = 0; w < 8; ++w) {
-    long long* s = st + w * 8;
-    printf("wave %d: synth %6lld  phase0 (both tiles) %6lld  phase1 (deep tile) %6lld  epilogue %6lld   total %6lld cycles = %.2f us\n", w,
-           s[1] - s[0], s[2] - s[1], s[3] - s[2], s[6] - s[5], s[6] - s[0], (s[6] - s[0]) / 2400.0);
-  }
+  printf("hb_sgp_A_f32 (strip2, fragment-major W): %.2f us per launch (back-to-back stream launches)\n", ms * 1e3 / 50);
+  std::vector<long long> st(256 * 8 * 4), rt(512);
+  (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(hb_sstamps), st.size() * 8);
+  (void)hipMemcpyFromSymbol(rt.data(), HIP_SYMBOL(hb_srt), rt.size() * 8);
+  long long t0 = rt[0], t1 = rt[1];
+  for (int b = 0; b < 256; ++b) { t0 = std::min(t0, rt[2 * b]); t1 = std::max(t1, rt[2 * b + 1]); }
+  printf("last launch: first workgroup start -> last workgroup end %.2f us (100 MHz wall clock)\n", (t1 - t0) / 100.0);
+  std::vector<double> starts, durs;
+  for (int b = 0; b < 256; ++b) { starts.push_back((rt[2 * b] - t0) / 100.0); durs.push_back((rt[2 * b + 1] - rt[2 * b]) / 100.0); }
+  std::sort(starts.begin(), starts.end()); std::sort(durs.begin(), durs.end());
+  printf("workgroup start offsets (us): min %.2f median %.2f p90 %.2f max %.2f ; durations: min %.2f median %.2f p90 %.2f max %.2f\n",
+         starts[0], starts[128], starts[230], starts[255], durs[0], durs[128], durs[230], durs[255]);
+  for (int b : {0, 7, 128, 255})
+    for (int w = 0; w < 8; ++w) {
+      long long* s = &st[(b * 8 + w) * 4];
+      printf("wg %3d wave %d: synth %6lld  loop %6lld  epilogue %6lld  total %6lld cycles\n", b, w, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[3] - s[0]);
+    }
   return 0;
 }
