@@ -71,7 +71,7 @@ _TYPED = {
     "hb_trinv": [P, P, L, L, P, P],
     "hb_sgp_A": [I, P, L, P, P, L, P, P, I, P, L, L, L, L, P],
     "hb_sgp_fwd": [I, I, P, L, P, P, L, P, P, I, P, P, P, L, P, P, P, P, L, L, L, L, L, P, P],
-    "hb_sgp_bwd": [I, I, P, L, P, P, L, P, P, P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P],
+    "hb_sgp_bwd": [I, I, P, L, P, P, L, P, P, I, P, P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P],
     "hb_adam_step": [P, P, P, P, L, D, D, D, D, D, P, I, P, L, P, P, P],
     "hb_allreduce_sum": [P, L, P, P],
     "hb_dp_pack": [P, P, P, L, P],

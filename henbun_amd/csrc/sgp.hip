@@ -1314,6 +1314,16 @@ struct SgpBwdArgs {
   long n, M, P;
   int mode;
   long efast;     // expert-fastest grid (see sgp_block)
+  // column-strip form (sgp_kbar_strip_kernel)
+  const T* x;     // [E?, n, d]
+  long sx;
+  const T* z;     // [E, M, d]
+  const T* ell;   // [E, dl]
+  long dl, d;
+  const T* WTf;   // fragment-major fp32 image of W^T
+  const void* WT3;  // bf16x3 images of W^T (3 planes) or nullptr
+  long plane3;
+  T* part;        // [E, nS, 2d + P, M] strip partials of zbar, ell, ubar
 };
 
 template <typename T>
@@ -1427,6 +1437,406 @@ __global__ void __launch_bounds__(256) sgp_kbar_kernel(SgpBwdArgs<T> a) {
       const int r = row0 + row, cc = col0 + col;
       if (r < M && cc < n) Kbar[(long)r * n + cc] = v;
     });
+  }
+}
+
+// Sum over each 32-lane half of the wave with DPP adds (VALU only): afterwards every lane of rows 1 and 3 (lanes
+// 16..31 and 48..63) holds the total of its half-wave.
+__device__ __forceinline__ float hb_half_wave_sum_dpp(float v) {
+  auto dpp = [](float x, int ctrl_unused) { return x; };
+  (void)dpp;
+  int vi;
+#define HB_DPP_ADD(CTRL, ROWMASK)                                                                        \
+  vi = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, true);             \
+  v += __builtin_bit_cast(float, vi);
+  HB_DPP_ADD(0xB1, 0xF)   // quad_perm [1,0,3,2]
+  HB_DPP_ADD(0x4E, 0xF)   // quad_perm [2,3,0,1]
+  HB_DPP_ADD(0x141, 0xF)  // row_half_mirror
+  HB_DPP_ADD(0x140, 0xF)  // row_mirror: every lane of a 16-lane row now holds the row total
+  HB_DPP_ADD(0x142, 0xA)  // row_bcast:15 -> rows 1 and 3 add the total of the row before
+#undef HB_DPP_ADD
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward in column-strip form (fp32, fragment-major W^T from hb_cholesky_inverse; BF3: bf16x3 operands).
+//
+// One workgroup owns 32 data columns and all M rows, like the forward strip kernel: it builds
+//   Abar[:, strip] = u^T fbar + A diag(c)            (into LDS, from the A columns of the strip)
+//   Kbar[:, strip] = W^T Abar[:, strip]              (W^T is upper triangular: row tile t contracts chunks t .. nT-1)
+// and, as each 32 x 32 tile of Kbar completes, folds it into the row gradients of the strip
+//   zbar_m += sum_j Kbar_mj dK_mj/dz_m ,  ell_m += sum_j Kbar_mj dK_mj/dell ,  ubar_pm += sum_j fbar_pj A_mj
+// (K re-synthesised from the staged coordinates; the tile is turned row-per-lane through a per-wave LDS transpose so
+// a lane sums its 16 columns in registers).  That replaces sgp_kbar_kernel + sgp_rowgrad_vec_kernel, i.e. the second
+// full read of Kbar and A (33.5 MB) disappears; the strips' partial sums are folded by sgp_strip_finish_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+#define SGP_TLD 36
+template <int D, bool BF3>
+__global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBwdArgs<float> a) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 B8 __attribute__((ext_vector_type(8)));
+  typedef Mma<float> MM;
+  constexpr int KS_BYTES = BF3 ? 3 * SGP_SN * SGP_S3LD * 2 : SGP_SN * SGP_SLD * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char ks_raw[KS_BYTES];
+  __shared__ __attribute__((aligned(16))) float Tw[SGP_STRIP_THREADS / 64][32][SGP_TLD];
+  __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
+  __shared__ __attribute__((aligned(16))) float xss[SGP_SN * D];
+  __shared__ float us[4][SGP_SM_MAX];
+  __shared__ float cjs[SGP_SN], fbs[4][SGP_SN];
+  float (*Ks)[SGP_SLD] = reinterpret_cast<float (*)[SGP_SLD]>(ks_raw);
+  __bf16 (*K3)[SGP_SN][SGP_S3LD] = reinterpret_cast<__bf16 (*)[SGP_SN][SGP_S3LD]>(ks_raw);
+  long e;
+  int bx;
+  sgp_block(a.efast, e, bx);
+  const float* __restrict__ x = a.x + e * a.sx;
+  const float* __restrict__ z = a.z + e * a.M * D;
+  const float* __restrict__ ell = a.ell + e * a.dl;
+  const float* __restrict__ A = a.A + e * a.M * a.n;
+  const float* __restrict__ fbar = a.fbar + e * a.P * a.n;
+  float* __restrict__ Kbar = a.Kbar + e * a.M * a.n;
+  const int M = (int)a.M, n = (int)a.n, P = (int)a.P;
+  const int col0 = bx * SGP_SN, nS = (n + SGP_SN - 1) / SGP_SN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int nq = 2 * D + P;
+  float* __restrict__ part = a.part + ((e * nS + bx) * (long)nq) * M;   // [2D + P][M] of this strip
+
+  // ---- stage z (scaled), the strip's x (scaled), u, the per-column residual coefficient and fbar
+  float sc[D];
+#pragma unroll
+  for (int dd = 0; dd < D; ++dd) sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
+  {
+    constexpr int NTH = SGP_STRIP_THREADS;
+    constexpr int ZIT = (SGP_SM_MAX * D) / NTH, UIT = SGP_SM_MAX / NTH;
+    float zt[ZIT], ut[4][UIT];
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + NTH * it;
+      zt[it] = z[i < M * D ? i : 0];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int it = 0; it < UIT; ++it) {
+        const int i = tid + NTH * it;
+        ut[p][it] = p < P ? a.u[e * a.P * a.M + (long)p * M + (i < M ? i : 0)] : 0.f;
+      }
+    if (tid < SGP_SN) {
+      const int cc = col0 + tid;
+      const bool ok = cc < n;
+      const int cj = ok ? cc : n - 1;
+      cjs[tid] = ok ? sgp_resid_coef<float>(a.eps ? a.eps + e * a.n : nullptr, a.v + e * a.n, fbar, a.n, a.P, a.mode, cj) : 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) fbs[p][tid] = (ok && p < P) ? fbar[(long)p * n + cj] : 0.f;
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) xss[tid * D + dd] = x[cj * D + dd] * sc[dd];
+    }
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + NTH * it;
+      if (i < M * D) zs[i] = zt[it] * sc[i % D];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int it = 0; it < UIT; ++it) {
+        const int i = tid + NTH * it;
+        if (p < P && i < M) us[p][i] = ut[p][it];
+      }
+  }
+  __syncthreads();
+
+  // ---- Abar[:, strip] -> LDS ([column][k]); ubar partials of the strip on the way.
+  // Thread (c, kq) takes groups of G consecutive rows k for its column c: the global loads of a wave cover two
+  // 128-byte row segments, the LDS store is one conflict-free 16-byte vector per group.
+  {
+    constexpr int G = BF3 ? 8 : 4;
+    const int c = tid & 31, kq = tid >> 5;           // 16 row-group lanes
+    const bool cok = col0 + c < n;
+    const int cc = cok ? col0 + c : n - 1;
+    const float cj = cjs[c];
+    float fb[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) fb[p] = fbs[p][c];
+    constexpr int NG = SGP_SM_MAX / (16 * G);         // groups per thread (M = 512: 8 of 4, or 4 of 8)
+    float av[NG][G];
+#pragma unroll
+    for (int it = 0; it < NG; ++it)
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int k = G * (kq + 16 * it) + i;
+        av[it][i] = (k < M && cok) ? A[(long)k * n + cc] : 0.f;
+      }
+#pragma unroll
+    for (int it = 0; it < NG; ++it) {
+      const int kb = G * (kq + 16 * it);
+      if (kb < M) {                                   // (M % 32 == 0: a group is wholly inside or outside)
+        float val[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          val[i] = av[it][i] * cj;
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            if (p < P) val[i] += us[p][kb + i] * fb[p];
+        }
+        if (BF3) {
+          B8 p0, p1, p2;
+#pragma unroll
+          for (int i = 0; i < G; ++i) {
+            const __bf16 b0 = (__bf16)val[i];
+            const float r1 = val[i] - (float)b0;
+            const __bf16 b1 = (__bf16)r1;
+            p0[i & 7] = b0, p1[i & 7] = b1, p2[i & 7] = (__bf16)(r1 - (float)b1);
+          }
+          *reinterpret_cast<B8*>(&K3[0][c][kb]) = p0;
+          *reinterpret_cast<B8*>(&K3[1][c][kb]) = p1;
+          *reinterpret_cast<B8*>(&K3[2][c][kb]) = p2;
+        } else {
+          V4 q;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) q[i] = val[i & 3];
+          *reinterpret_cast<V4*>(&Ks[c][kb]) = q;
+        }
+        // ubar_pk (strip) = sum over the strip's 32 columns of fbar_pc A_kc: the 32 lanes of a half-wave hold one k;
+        // reduced with DPP adds (no LDS traffic); lanes 31 / 63 end up with the two half-wave totals
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (p < P) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+              const float t = hb_half_wave_sum_dpp(fb[p] * av[it][i]);
+              if (c == 31) part[(long)(2 * D + p) * M + kb + i] = t;
+            }
+          }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- tile-steps: W^T is upper triangular: row tile t contracts chunks Q = t .. nT-1
+  const int nT = M / 32;
+  const int ta = nT - 1 - w, tb = w;                 // shallow tile first (w + 1 chunks), then the deep one (nT - w)
+  const int d0 = ta > tb ? w + 1 : 0;                // the middle tile of an odd count is taken once, as tb
+  const int d1 = tb <= ta ? nT - w : 0;
+  const int nts = d0 + d1;
+  typename MM::Acc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int gc = col0 + li;
+
+  auto tile_of = [&](int ts) { return ts < d0 ? ta : tb; };
+  auto chunk_of = [&](int ts) { return ts < d0 ? ta + ts : tb + (ts - d0); };
+  float lwave[D];
+#pragma unroll
+  for (int dd = 0; dd < D; ++dd) lwave[dd] = 0.f;
+
+  // fold a finished tile (in `acc`, column-per-lane) into the outputs
+  auto retire = [&](int tile) {
+    // Kbar, row-major (accumulator layout: two 128-byte row segments per store)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * tile + MM::acc_row(lane, r);
+      if (gc < n) Kbar[(long)row * n + gc] = acc[r];
+      Tw[w][MM::acc_row(lane, r)][li] = acc[r];
+    }
+    // row-per-lane view: lane (li, h) takes row li, columns 16h .. 16h+15 of the tile
+    float kb[16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const V4 q = *reinterpret_cast<const V4*>(&Tw[w][li][16 * h + 4 * v]);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) kb[4 * v + s2] = q[s2];
+    }
+    const int row = 32 * tile + li;
+    float zr[D], zacc[D], lacc[D];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) zr[dd] = zs[row * D + dd], zacc[dd] = 0.f, lacc[dd] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = 16 * h + i;
+      float tt[D], r2 = 0.f;
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) {
+        tt[dd] = zr[dd] - xss[c * D + dd];
+        r2 += tt[dd] * tt[dd];
+      }
+      const float gk = (col0 + c < n) ? kb[i] * hb_exp2_neg<float>(r2) : 0.f;
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) {
+        zacc[dd] -= gk * tt[dd];
+        lacc[dd] += gk * tt[dd] * tt[dd];
+      }
+    }
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      zacc[dd] += __shfl_xor(zacc[dd], 32);
+      // tt is in exp2-scaled units (t' = t * S, S = SGP_EXP2_SCALE): zbar = -(1/ell) sum g t, ell = (1/ell) sum g t^2
+      if (h == 0) part[(long)dd * M + row] = zacc[dd] * sc[dd] * float(1.0 / (SGP_EXP2_SCALE * SGP_EXP2_SCALE));
+      lwave[dd] += lacc[dd];   // the lengthscale gradient is summed over the rows too: per lane, folded at the end
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  };
+
+  if (!BF3) {
+    const float* __restrict__ Wf = a.WTf + e * a.M * a.M;
+    auto load = [&](V4 (&f)[4], int ts) {
+      const int tc = ts < nts ? ts : nts - 1;
+      const float* p = Wf + ((long)(tile_of(tc) * nT + chunk_of(tc)) << 10) + 4 * lane;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) f[v] = *reinterpret_cast<const V4*>(p + 256 * v);
+    };
+    auto compute = [&](const V4 (&f)[4], int ts) {
+      if (ts >= nts) return;
+      const int Q = chunk_of(ts);
+      V4 bv[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) bv[v] = *reinterpret_cast<const V4*>(&Ks[li][32 * Q + 16 * h + 4 * v]);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc = MM::mma(f[v][s2], bv[v][s2], acc);
+      if (ts == d0 - 1 || ts == nts - 1) retire(tile_of(ts));
+    };
+    if (nts > 0) {
+      V4 fa[4], fb2[4];
+      load(fa, 0);
+#pragma nounroll
+      for (int ts = 0; ts < nts; ts += 2) {
+        load(fb2, ts + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(fa, ts);
+        __builtin_amdgcn_sched_barrier(0);
+        load(fa, ts + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(fb2, ts + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+    const __bf16* __restrict__ W3 = reinterpret_cast<const __bf16*>(a.WT3) + e * a.M * a.M;
+    struct Frag {
+      B8 f[3][2];
+    };
+    auto load = [&](Frag& fr, int ts) {
+      const int tc = ts < nts ? ts : nts - 1;
+      const __bf16* p = W3 + ((long)(tile_of(tc) * nT + chunk_of(tc)) << 10) + 8 * lane;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) fr.f[t][q] = *reinterpret_cast<const B8*>(p + (long)t * a.plane3 + 512 * q);
+    };
+    auto compute = [&](const Frag& fr, int ts) {
+      if (ts >= nts) return;
+      const int Q = chunk_of(ts);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        B8 b[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const B8*>(&K3[t][li][32 * Q + 16 * q + 8 * h]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[2][q], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[1][q], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[1][q], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[0], acc, 0, 0, 0);
+      }
+      if (ts == d0 - 1 || ts == nts - 1) retire(tile_of(ts));
+    };
+    if (nts > 0) {
+      Frag fa, fb2;
+      load(fa, 0);
+#pragma nounroll
+      for (int ts = 0; ts < nts; ts += 2) {
+        load(fb2, ts + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(fa, ts);
+        __builtin_amdgcn_sched_barrier(0);
+        load(fa, ts + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(fb2, ts + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // ---- the strip's lengthscale partial: sum over all rows (lanes, waves) in a fixed order
+  __syncthreads();
+  float* red = &Tw[0][0][0];
+#pragma unroll
+  for (int dd = 0; dd < D; ++dd) {
+    const float t = wave_sum(lwave[dd]);
+    if (lane == 0) red[w * D + dd] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int dd = 0; dd < D; ++dd)
+    if (tid == dd) {
+      float t = 0.f;
+      for (int ww = 0; ww < SGP_STRIP_THREADS / 64; ++ww) t += red[ww * D + dd];
+      part[(long)(D + dd) * M] = t * sc[dd] * float(1.0 / (SGP_EXP2_SCALE * SGP_EXP2_SCALE * SGP_EXP2_SCALE));
+    }
+}
+
+// Fold the strips' partial sums (sgp_kbar_strip_kernel):  zbar[e, m, q] = sum_s part[e, s, q, m];
+// ubar[e, p, m] = sum_s part[e, s, 2D + p, m];  ellbar[e, q | 0] = sum_s lstrip[e, s, q] (already summed over the rows
+// by the strip kernel).  Block (x = 64-row block, y = quantity q, z = expert): 256 threads = 64 rows x 4 strip groups,
+// 16 loads in flight per thread; the extra block row y = 2D + P - D... (see launch) sums the ell partials.  Fixed
+// summation order: deterministic.
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_strip_finish_kernel(const T* __restrict__ part, int nS, long M, long d, long dl,
+                                                               long P, T* __restrict__ zbar, T* __restrict__ ellbar,
+                                                               T* __restrict__ ubar) {
+  __shared__ T red[4][64];
+  __shared__ T smem[16];
+  const long e = blockIdx.z;
+  const int nq = (int)(2 * d + P);
+  part += e * nS * (long)nq * M;
+  const int q = blockIdx.y;
+  if (q >= (int)d && q < 2 * (int)d) {
+    // ell: per-strip totals were left in row 0 of this quantity's rows ([s][D + q][0]) by the strip kernel
+    if (blockIdx.x != 0) return;
+    T acc = T(0);
+    for (int s = threadIdx.x; s < nS; s += 256) acc += part[((long)s * nq + q) * M];
+    acc = block_sum(acc, smem);
+    // dl == 1: every dimension adds into the one lengthscale -- one block per dimension would race; dimension 0's
+    // block therefore takes all of them
+    if (dl == 1) {
+      if (q != (int)d) return;
+      T tot = acc;
+      for (int qq = (int)d + 1; qq < 2 * (int)d; ++qq) {
+        T a2 = T(0);
+        for (int s = threadIdx.x; s < nS; s += 256) a2 += part[((long)s * nq + qq) * M];
+        tot += block_sum(a2, smem);
+      }
+      if (threadIdx.x == 0) ellbar[e] = tot;
+    } else if (threadIdx.x == 0) {
+      ellbar[e * dl + (q - d)] = acc;
+    }
+    return;
+  }
+  const int ml = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const long m = (long)blockIdx.x * 64 + ml;
+  T acc = T(0);
+  if (m < M) {
+    const T* base = part + (long)q * M + m;
+    const long sstride = (long)nq * M;
+    int s = sg;
+    for (; s + 4 * 15 < nS; s += 4 * 16) {
+      T v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = base[(long)(s + 4 * i) * sstride];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc += v[i];
+    }
+    for (; s < nS; s += 4) acc += base[(long)s * sstride];
+  }
+  red[sg][ml] = acc;
+  __syncthreads();
+  if (sg == 0 && m < M) {
+    const T tot = (red[0][ml] + red[1][ml]) + (red[2][ml] + red[3][ml]);
+    if (q < (int)d)
+      zbar[(e * M + m) * d + q] = tot;
+    else
+      ubar[(e * P + (q - 2 * d)) * M + m] = tot;
   }
 }
 
@@ -1662,10 +2072,35 @@ static inline int sgp_matmul(const double* A, const double* B, double* C, long b
                        flags, ws, wse, stream);
 }
 
+static int sgp_bwd_strip_launch(SgpBwdArgs<float> a, long E, long nS, hipStream_t stream) {
+  dim3 grid = sgp_grid(nS, 1, E, a.efast);
+#define HB_KBS(D_)                                                                                               \
+  do {                                                                                                           \
+    if (a.WT3)                                                                                                   \
+      hipLaunchKernelGGL((sgp_kbar_strip_kernel<D_, true>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);        \
+    else                                                                                                         \
+      hipLaunchKernelGGL((sgp_kbar_strip_kernel<D_, false>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);       \
+  } while (0)
+  if (a.d == 1)
+    HB_KBS(1);
+  else if (a.d == 2)
+    HB_KBS(2);
+  else if (a.d == 3)
+    HB_KBS(3);
+  else
+    HB_KBS(4);
+#undef HB_KBS
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+static int sgp_bwd_strip_launch(SgpBwdArgs<double>, long, long, hipStream_t) { return -1; }  // fp32 only
+
 template <typename T>
-static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* u,
-                   const T* eps, const T* A, const T* v, const T* fbar, T* Kbar, T* Lbar, T* ubar, T* zbar, T* ellbar,
-                   T* xbar, long E, long n, long M, long d, long P, T* ws, hipStream_t stream) {
+static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W,
+                   const T* Wfrag, int prec, const T* u, const T* eps, const T* A, const T* v, const T* fbar, T* Kbar,
+                   T* Lbar, T* ubar, T* zbar, T* ellbar, T* xbar, long E, long n, long M, long d, long P, T* ws,
+                   hipStream_t stream) {
+  HB_REQUIRE(prec == HB_PREC_NATIVE || prec == HB_PREC_BF16X3, "hb_sgp_bwd: unknown precision %d", prec);
   HB_REQUIRE(kind == HB_KERN_RBF, "hb_sgp_bwd: only the UnitRBF kernel is fused (kind=%d)", kind);
   HB_REQUIRE(mode == HB_SGP_NEGLECTED || mode == HB_SGP_DIAGONAL, "hb_sgp_bwd: unknown mode %d", mode);
   HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1 && P >= 0, "hb_sgp_bwd: bad extents");
@@ -1679,10 +2114,38 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   T* ellpart = ws + E * n;  // (the first E*n elements of ws are unused since the residual coefficient is computed in-kernel)
   T* mmws = ellpart + E * M * d;
   const long mmws_elems = 32 * E * M * M;
+  // column-strip form: fp32, fragment-major W^T available, M a multiple of 32 up to SGP_SM_MAX, small d and P, no xbar
+  const long nS = hb_cdiv(n, SGP_SN);
+  const bool strip = sizeof(T) == 4 && Wfrag && n > 0 && M % 32 == 0 && M >= 32 && M <= SGP_SM_MAX && d <= SGP_DREG &&
+                     P <= 4 && !xbar && nS * (2 * d + P) * M * E <= mmws_elems && !hb_sgp_no_strip() &&
+                     (E * nS <= 4096 || prec == HB_PREC_BF16X3);
+  HB_REQUIRE(prec == HB_PREC_NATIVE || strip, "hb_sgp_bwd: bf16x3 needs the column-strip form (fp32, Wfrag, M %% 32 == 0, M <= %d, "
+             "d <= %d, P <= 4, no xbar)", SGP_SM_MAX, SGP_DREG);
+  if (strip) {
+    SgpBwdArgs<T> a;
+    a.W = W; a.u = u; a.A = A; a.fbar = fbar; a.eps = eps; a.v = v; a.Kbar = Kbar;
+    a.n = n; a.M = M; a.P = P; a.mode = mode;
+    a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.d = d;
+    a.WTf = Wfrag + E * M * M;
+    a.WT3 = prec == HB_PREC_BF16X3 ? (const void*)(reinterpret_cast<const unsigned short*>(Wfrag + 2 * E * M * M) + 3 * E * M * M)
+                                   : nullptr;
+    a.plane3 = E * M * M;
+    a.part = mmws;   // consumed by the finish kernel before the Lbar contraction reuses the space
+    int rc = sgp_bwd_strip_launch(a, E, nS, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sgp_strip_finish_kernel<T>, dim3((unsigned)hb_cdiv(M, 64), (unsigned)(2 * d + P), (unsigned)E), dim3(256), 0,
+                       stream, mmws, (int)nS, M, d, dl, P, zbar, ellbar, ubar);
+    HB_LAUNCH_CHECK();
+    int rc2 = sgp_matmul(Kbar, A, Lbar, E, M, M, n, n, n, M, M * n, M * n, M * M, 0, 1, -1.0, HB_MM_TRIL_OUT, mmws, mmws_elems,
+                         (void*)stream);
+    return rc2;
+  }
   if (n > 0) {
     SgpBwdArgs<T> a;
     a.W = W; a.u = u; a.A = A; a.fbar = fbar; a.eps = eps; a.v = v; a.Kbar = Kbar;
     a.n = n; a.M = M; a.P = P; a.mode = mode;
+    a.x = nullptr; a.sx = 0; a.z = nullptr; a.ell = nullptr; a.dl = 0; a.d = d; a.WTf = nullptr; a.WT3 = nullptr;
+    a.plane3 = 0; a.part = nullptr;
     const int nRB = hb_cdiv(M, SGP_BM);
     dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), sgp_grid_y(E, n, nRB), E, a.efast);
     constexpr long VECH = 16 / sizeof(T);
@@ -1736,17 +2199,18 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
 }
 
 extern "C" int hb_sgp_bwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell, long dl,
-                              const float* W, const float* u, const float* eps, const float* A, const float* v,
-                              const float* fbar, float* Kbar, float* Lbar, float* ubar, float* zbar, float* ellbar,
-                              float* xbar, long E, long n, long M, long d, long P, float* ws, void* stream) {
-  return sgp_bwd<float>(kind, mode, x, sx, z, ell, dl, W, u, eps, A, v, fbar, Kbar, Lbar, ubar, zbar, ellbar, xbar, E,
-                        n, M, d, P, ws, (hipStream_t)stream);
+                              const float* W, const float* Wfrag, int prec, const float* u, const float* eps,
+                              const float* A, const float* v, const float* fbar, float* Kbar, float* Lbar, float* ubar,
+                              float* zbar, float* ellbar, float* xbar, long E, long n, long M, long d, long P, float* ws,
+                              void* stream) {
+  return sgp_bwd<float>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps, A, v, fbar, Kbar, Lbar, ubar, zbar, ellbar,
+                        xbar, E, n, M, d, P, ws, (hipStream_t)stream);
 }
 extern "C" int hb_sgp_bwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
-                              long dl, const double* W, const double* u, const double* eps, const double* A,
-                              const double* v, const double* fbar, double* Kbar, double* Lbar, double* ubar,
-                              double* zbar, double* ellbar, double* xbar, long E, long n, long M, long d, long P,
-                              double* ws, void* stream) {
-  return sgp_bwd<double>(kind, mode, x, sx, z, ell, dl, W, u, eps, A, v, fbar, Kbar, Lbar, ubar, zbar, ellbar, xbar, E,
-                         n, M, d, P, ws, (hipStream_t)stream);
+                              long dl, const double* W, const double* Wfrag, int prec, const double* u, const double* eps,
+                              const double* A, const double* v, const double* fbar, double* Kbar, double* Lbar,
+                              double* ubar, double* zbar, double* ellbar, double* xbar, long E, long n, long M, long d,
+                              long P, double* ws, void* stream) {
+  return sgp_bwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps, A, v, fbar, Kbar, Lbar, ubar, zbar,
+                         ellbar, xbar, E, n, M, d, P, ws, (hipStream_t)stream);
 }

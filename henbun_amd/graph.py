@@ -1434,8 +1434,11 @@ def _sgp_grad_emit(plan, node):
     if need_x and len(node.inputs[1].shape) > 2 and len(node.inputs[0].shape) == 2:
         raise NotImplementedError("gradient w.r.t. an x shared by several experts")
     xbuf = xb.reshape((-1,) + tuple(xb.shape[-2:])) if need_x else None
+    wfrag, bf3 = plan._wfrag.get(_through_stop_gradient(node.inputs[3]), (None, False))
+    bf3 = bf3 and not need_x and node.inputs[0].shape[-1] <= 4 and node.inputs[4].shape[-2] <= 4
+    prec = H.PREC_BF16X3 if bf3 else H.PREC_NATIVE
     plan.steps.append(lambda: H.sgp_bwd(x, z, ell, W, u, eps, A, v, gf, mode=mode, need_xbar=need_x,
-                                        out=(Kbar, Lb, ub, zb, lb, xbuf)))
+                                        out=(Kbar, Lb, ub, zb, lb, xbuf), wfrag=wfrag, prec=prec))
 
 
 defop("sgp", _sgp_emit, _sgp_vjp)

@@ -654,7 +654,8 @@ def sgp_A(x, z, ell, W, out=None, wfrag=None, prec=PREC_NATIVE):
     return out
 
 
-def sgp_bwd(x, z, ell, W, u, eps, A, v, fbar, mode=SGP_DIAGONAL, need_xbar=False, out=None):
+def sgp_bwd(x, z, ell, W, u, eps, A, v, fbar, mode=SGP_DIAGONAL, need_xbar=False, out=None, wfrag=None,
+            prec=PREC_NATIVE):
     """Returns (Lbar, ubar, zbar, ellbar, xbar|None)."""
     E, n, M, d, P, sx = _sgp_dims(x, z, u)
     dev, dt = x.device, x.dtype
@@ -670,7 +671,7 @@ def sgp_bwd(x, z, ell, W, u, eps, A, v, fbar, mode=SGP_DIAGONAL, need_xbar=False
         Kbar, Lbar, ubar, zbar, ellbar, xbar = out
     wse = _lib.lib().raw("hb_sgp_ws_elems")(E, n, M, d, P)
     ws = workspace(dt, dev, wse)
-    _lib.lib().call("hb_sgp_bwd" + _suf(x), KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(u), _p(eps),
+    _lib.lib().call("hb_sgp_bwd" + _suf(x), KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(wfrag), int(prec), _p(u), _p(eps),
                     _p(A), _p(v), _p(fbar), _p(Kbar), _p(Lbar), _p(ubar), _p(zbar), _p(ellbar), _p(xbar), E, n, M, d,
                     P, _p(ws), stream())
     return Lbar, ubar, zbar, ellbar, xbar

@@ -328,7 +328,7 @@ enum { HB_SGP_NEGLECTED = 0, HB_SGP_DIAGONAL = 1 };
  * only; BASELINE cfg 5's "fp16-with-fp32-accum" variant in a usable form): every fp32 operand is split into three
  * bf16 terms and the six significant cross products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation --
  * fp32-level accuracy (plain 16-bit operands leave a 27 % error in L^-1 K) at the bf16 matrix rate.  Needs the
- * bf16 images of hb_cholesky_inverse(frag_bf16x3 = 1) in Wfrag. */
+ * bf16 images of hb_cholesky_inverse_f32 (frag_bf16x3 = 1) in Wfrag. */
 enum { HB_PREC_NATIVE = 0, HB_PREC_BF16X3 = 1 };
 /* Per expert e < E (all arrays carry a leading E; x may be shared: sx = 0):
  *   Kmn = k(z, x)            [M,n]   (never written to memory)
@@ -362,17 +362,19 @@ int hb_sgp_A_f64(int kind, const double* x, long sx, const double* z, const doub
  *   Kbar = W^T Abar            [E,M,n]  (scratch output, kept for Lbar)
  *   Lbar = -tril(Kbar A^T)     [E,M,M]
  *   ubar = fbar A^T            [E,P,M]
+ * Wfrag (nullable) / prec: as for hb_sgp_fwd; with Wfrag (fp32, M %% 32 == 0, M <= 512, d <= 4, P <= 4, no xbar) Kbar
+ * and the row gradients come from ONE column-strip kernel (no second pass over Kbar and A).
  *   zbar, ellbar (and xbar, nullable) through Kmn = k(z,x). */
 int hb_sgp_bwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell,
-                   long dl, const float* W, const float* u, const float* eps, const float* A,
-                   const float* v, const float* fbar, float* Kbar, float* Lbar, float* ubar,
-                   float* zbar, float* ellbar, float* xbar, long E, long n, long M, long d, long P,
-                   float* ws, void* stream);
+                   long dl, const float* W, const float* Wfrag, int prec, const float* u, const float* eps,
+                   const float* A, const float* v, const float* fbar, float* Kbar, float* Lbar,
+                   float* ubar, float* zbar, float* ellbar, float* xbar, long E, long n, long M, long d,
+                   long P, float* ws, void* stream);
 int hb_sgp_bwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
-                   long dl, const double* W, const double* u, const double* eps, const double* A,
-                   const double* v, const double* fbar, double* Kbar, double* Lbar, double* ubar,
-                   double* zbar, double* ellbar, double* xbar, long E, long n, long M, long d,
-                   long P, double* ws, void* stream);
+                   long dl, const double* W, const double* Wfrag, int prec, const double* u,
+                   const double* eps, const double* A, const double* v, const double* fbar, double* Kbar,
+                   double* Lbar, double* ubar, double* zbar, double* ellbar, double* xbar, long E, long n,
+                   long M, long d, long P, double* ws, void* stream);
 
 /* ---- K9: flat-buffer Adam, TensorFlow-1 formula (reference model.py:206,220
  *      tf.train.AdamOptimizer via optimizer.minimize) --------

@@ -651,6 +651,51 @@ def test_fragment_major_copies_of_the_inverse(H):
         assert torch.equal(H.sgp_A(x, zz, ell, Wd), H.sgp_A(x, zz, ell, Wd, wfrag=frag))
 
 
+@pytest.mark.parametrize("E,M,n,d,P,mode", [(1, 512, 3000, 1, 1, "diagonal"), (2, 96, 257, 2, 3, "diagonal"),
+                                             (1, 64, 64, 3, 1, "neglected"), (3, 160, 1000, 1, 2, "diagonal")])
+def test_sgp_backward_column_strip_form(H, E, M, n, d, P, mode):
+    """hb_sgp_bwd with the fragment-major W^T (one column-strip kernel: Kbar + the row gradients zbar / ellbar / ubar
+    folded as each 32 x 32 tile completes, no second pass over Kbar and A) against torch autograd in fp64 -- at fp32
+    tolerances, for the native and the bf16x3 operand forms -- and against the generic fp32 kernels."""
+    dt = torch.float32
+    rng = np.random.RandomState(5)
+    z = np.stack([np.sort(rng.uniform(0, M / 2.0, (M, d)), axis=0) for _ in range(E)])
+    ellv = np.exp(0.1 * rng.randn(E, d)) if d > 1 else np.exp(0.1 * rng.randn(E, 1))
+    x = rng.uniform(0, M / 2.0, (n, d))
+    u, eps, fbar = rng.randn(E, P, M), rng.randn(E, n), rng.randn(E, P, n)
+    K = H.gram_fwd(dev(z, dt), dev(z, dt), dev(ellv, dt), diag_add=1e-2).reshape(E, M, M)
+    frag = torch.zeros(5 * E * M * M, dtype=dt, device="cuda")
+    L, W, info = H.cholesky_inverse(K, frag=frag, frag_bf16x3=True)
+    assert not info.cpu().numpy().any()
+    m = H.SGP_DIAGONAL if mode == "diagonal" else H.SGP_NEGLECTED
+    sq = (lambda a: a if E > 1 else a[0])
+    args = (dev(x, dt), dev(sq(z), dt), dev(sq(ellv), dt), W if E > 1 else W[0], dev(sq(u), dt))
+    f, A, v, _ = H.sgp_fwd(*args, eps_in=dev(sq(eps), dt), mode=m, wfrag=frag)
+    # fp64 reference of the same contract (L an independent leaf, built from the fp32 factor)
+    refs = []
+    for e in range(E):
+        Lt = L[e].double().cpu().clone().requires_grad_(True)
+        tz, tl, tu = [torch.as_tensor(t).requires_grad_(True) for t in (z[e], ellv[e], u[e])]
+        Ar = torch.linalg.solve_triangular(Lt, O.rbf_K(tz, torch.as_tensor(x), tl), upper=False)
+        vr = 1.0 - (Ar * Ar).sum(0)
+        fr = tu @ Ar + (torch.sqrt(torch.abs(vr)) * torch.as_tensor(eps[e]) if mode == "diagonal" else 0.0)
+        refs.append(torch.autograd.grad((fr * torch.as_tensor(fbar[e])).sum(), [Lt, tu, tz, tl]))
+    ref = [np.stack([r[i].numpy() for r in refs]) for i in range(4)]
+    ref[0] = np.tril(ref[0])
+    bargs = args + (dev(sq(eps), dt), A, v, dev(sq(fbar), dt))
+    old = H.sgp_bwd(*bargs, mode=m)                                          # generic fp32 kernels
+    new = H.sgp_bwd(*bargs, mode=m, wfrag=frag)                              # column-strip form
+    bf3 = H.sgp_bwd(*bargs, mode=m, wfrag=frag, prec=H.PREC_BF16X3)          # ... with bf16x3 operands
+    names = ("Lbar", "ubar", "zbar", "ellbar")
+    for i, nm in enumerate(names):
+        r = ref[i].reshape(host(old[i]).shape)
+        scale = max(1.0, np.abs(r).max())
+        e_old = np.abs(host(old[i]) - r).max() / scale
+        for tag, got in (("strip", new), ("bf16x3", bf3)):
+            e_new = np.abs(host(got[i]) - r).max() / scale
+            assert e_new <= 3.0 * e_old + 2e-5, (nm, tag, e_old, e_new)
+
+
 def test_bf16x3_contraction_has_fp32_accuracy(H):
     """HB_PREC_BF16X3 (BASELINE cfg 5's "fp16-with-fp32-accum" variant in a usable form): A = L^-1 K(z,x) with every
     operand split into three bf16 terms on v_mfma_f32_32x32x16_bf16 is as close to the fp64 result as the fp32-operand
