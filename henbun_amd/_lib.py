@@ -34,6 +34,7 @@ _SIGS = {
     "hb_rng_init": [P, L, U64, U64, P],
     "hb_rng_randint": [P, L, P, L, L, L, P],
     "hb_sgp_ws_elems": [L, L, L, L, L],
+    "hb_sgp_strip_path": [L, L, L, L, L, I],
     "hb_ewise_prog_image_bytes": [],
     "hb_ewise_prog_build": [I, P, P, I, P, P, I, P, P, P, I, P, P, P, P],
     "hb_comm_available": [],
@@ -70,8 +71,8 @@ _TYPED = {
     "hb_cholesky_inverse": [P, P, P, L, L, P, P, P, I, P],
     "hb_trinv": [P, P, L, L, P, P],
     "hb_sgp_A": [I, P, L, P, P, L, P, P, I, P, L, L, L, L, P],
-    "hb_sgp_fwd": [I, I, P, L, P, P, L, P, P, I, P, P, P, L, P, P, P, P, L, L, L, L, L, P, P],
-    "hb_sgp_bwd": [I, I, P, L, P, P, L, P, P, I, P, P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P],
+    "hb_sgp_fwd": [I, I, P, L, P, P, L, P, P, I, P, P, P, L, P, P, P, P, P, L, L, L, L, L, P, P],
+    "hb_sgp_bwd": [I, I, P, L, P, P, L, P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P],
     "hb_adam_step": [P, P, P, P, L, D, D, D, D, D, P, I, P, L, P, P, P],
     "hb_allreduce_sum": [P, L, P, P],
     "hb_dp_pack": [P, P, P, L, P],

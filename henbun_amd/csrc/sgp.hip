@@ -45,6 +45,7 @@ struct SgpArgs {
   const T* Wf;  // fragment-major copy of W written by hb_cholesky_inverse (see tril_inplace_kernel), or nullptr
   const void* W3;  // bf16x3 fragment images of W (3 planes of E*M*M bf16), or nullptr
   long plane3;     // elements per bf16 plane (E*M*M)
+  T* Af;           // fragment-major A: [E][M/32 row tiles][nS strips][4 v][64 lanes][4] (see hb_sgp_fwd), or nullptr
   const T* u;   // [E, P, M]
   T* A;         // [E, M, n]
   long n, M, d, P;
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
   const float* __restrict__ z = a.z + e * a.M * D;
   const float* __restrict__ ell = a.ell + e * a.dl;
   const float* __restrict__ W = (FRAG ? a.Wf : a.W) + e * a.M * a.M;
-  float* __restrict__ A = a.A + e * a.M * a.n;
+  float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
   const int M = (int)a.M, n = (int)a.n;
   const int col0 = bx * SGP_SN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
@@ -585,6 +586,31 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
   HB_SSTAMP(6);
 }
 
+// Fragment-major copy of a finished 32 x 32 tile (accumulator layout: column on the lane, rows in the registers) of
+// an [M, n] operand of the Lbar contraction: block (row tile t, strip s) holds, for v = 0..3, lane (li, h), s' = 0..3,
+//     X[32 t + li][32 s + 16 h + 4 v + s']
+// i.e. the MFMA operand fragments of a contraction over the DATA axis, in load order: each of the four stores of a
+// wave -- and each of the consumer's loads -- is one contiguous kilobyte.  The tile is turned row-per-lane through the
+// wave's own LDS buffer (no barrier: a wave's LDS operations execute in order).  Columns past n are written as zeros.
+#define SGP_TLD 36
+__device__ __forceinline__ void sgp_store_frag_tile(float* __restrict__ Xf, float (*T)[SGP_TLD],
+                                                    const Mma<float>::Acc& acc, long e, int nT, int nS, int tile, int strip,
+                                                    int col0, int n, int lane) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  const int li = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) T[Mma<float>::acc_row(lane, r)][li] = acc[r];
+  float* blk = Xf + ((((long)e * nT + tile) * nS + strip) << 10) + 4 * lane;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    V4 q = *reinterpret_cast<const V4*>(&T[li][16 * h + 4 * v]);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+      if (col0 + 16 * h + 4 * v + s2 >= n) q[s2] = 0.f;
+    *reinterpret_cast<V4*>(blk + 256 * v) = q;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Column-strip contraction, second form: used when the fragment-major image of W is available (hb_cholesky_inverse's
 // Wfrag).  Same decomposition (one workgroup = 32 data columns x all M rows, 8 waves, wave w owns the row tiles
@@ -605,6 +631,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs
   __shared__ __attribute__((aligned(16))) float Ks[SGP_SN][SGP_SLD];
   __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
   __shared__ float us[4][SGP_SM_MAX];
+  __shared__ __attribute__((aligned(16))) float Tw[SGP_STRIP_THREADS / 64][32][SGP_TLD];  // per-wave tile transpose (Af)
   long e;
   int bx;
   sgp_block(a.efast, e, bx);
@@ -612,7 +639,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs
   const float* __restrict__ z = a.z + e * a.M * D;
   const float* __restrict__ ell = a.ell + e * a.dl;
   const float* __restrict__ Wf = a.Wf + e * a.M * a.M;
-  float* __restrict__ A = a.A + e * a.M * a.n;
+  float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
   const int M = (int)a.M, n = (int)a.n;
   const int col0 = bx * SGP_SN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
@@ -716,11 +743,12 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs
     if (ts == d0 - 1 || ts == nts - 1) {
       // the tile is complete (its last chunk holds the diagonal block; the image has explicit zeros above it):
       // store it and fold it into the column statistics; the stores drain under the next tile's MFMAs
+      if (a.Af) sgp_store_frag_tile(a.Af, Tw[w], acc, e, nT, (n + SGP_SN - 1) / SGP_SN, tile, bx, col0, n, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * tile + MM::acc_row(lane, r);
         const float v = acc[r];
-        if (gc < n) A[(long)row * n + gc] = v;
+        if (a.A && gc < n) A[(long)row * n + gc] = v;
         if (a.part) {
           cs[0] += v * v;
 #pragma unroll
@@ -794,6 +822,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip3_kernel(SgpArgs
   __shared__ __attribute__((aligned(16))) __bf16 K3[3][SGP_SN][SGP_S3LD];
   __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
   __shared__ float us[4][SGP_SM_MAX];
+  __shared__ __attribute__((aligned(16))) float Tw[SGP_STRIP_THREADS / 64][32][SGP_TLD];
   long e;
   int bx;
   sgp_block(a.efast, e, bx);
@@ -801,7 +830,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip3_kernel(SgpArgs
   const float* __restrict__ z = a.z + e * a.M * D;
   const float* __restrict__ ell = a.ell + e * a.dl;
   const __bf16* __restrict__ W3 = reinterpret_cast<const __bf16*>(a.W3) + e * a.M * a.M;
-  float* __restrict__ A = a.A + e * a.M * a.n;
+  float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
   const int M = (int)a.M, n = (int)a.n;
   const int col0 = bx * SGP_SN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
@@ -911,11 +940,12 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip3_kernel(SgpArgs
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[0], acc, 0, 0, 0);
     }
     if (ts == d0 - 1 || ts == nts - 1) {
+      if (a.Af) sgp_store_frag_tile(a.Af, Tw[w], acc, e, nT, (n + SGP_SN - 1) / SGP_SN, tile, bx, col0, n, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * tile + MM::acc_row(lane, r);
         const float v = acc[r];
-        if (gc < n) A[(long)row * n + gc] = v;
+        if (a.A && gc < n) A[(long)row * n + gc] = v;
         if (a.part) {
           cs[0] += v * v;
 #pragma unroll
@@ -976,6 +1006,16 @@ static inline bool sgp_strip_ok(long E, long n, long M, long d, const void* W) {
   const long tiled_wgs = E * hb_cdiv(n, SGP_BN) * ((hb_cdiv(M, SGP_BM) + 1) / 2);
   static const bool force = getenv("HB_SGP_FORCE_STRIP") != nullptr;  // diagnostic: strip form whenever it is applicable
   return M >= 32 && M <= SGP_SM_MAX && M % 32 == 0 && d <= SGP_DREG && ((uintptr_t)W % 16 == 0) && (tiled_wgs < 1024 || force);
+}
+
+// 1 when hb_sgp_fwd / hb_sgp_bwd, given the fragment-major images of W (Wfrag), run in column-strip form -- the form
+// that can also exchange A and Kbar in fragment-major layout (A_frag / Kbar_frag)
+extern "C" int hb_sgp_strip_path(long E, long n, long M, long d, long P, int prec) {
+  if (hb_sgp_no_strip()) return 0;
+  if (!(M >= 32 && M <= SGP_SM_MAX && M % 32 == 0 && d >= 1 && d <= SGP_DREG && P <= 4 && n > 0 && E >= 1)) return 0;
+  if (prec == HB_PREC_BF16X3) return 1;
+  const long tiled_wgs = E * hb_cdiv(n, SGP_BN) * ((hb_cdiv(M, SGP_BM) + 1) / 2);
+  return (tiled_wgs < 1024 && E * hb_cdiv(n, SGP_SN) <= 4096) ? 1 : 0;
 }
 
 static int sgp_A_strip_launch(SgpArgs<float> a, long E, hipStream_t stream) {
@@ -1160,8 +1200,10 @@ static inline int sgp_grid_y(long E, long n, int nRB) {
 
 template <typename T>
 static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* Wf,
-                   int prec, const T* u, const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* A, T* f, T* v,
-                   long E, long n, long M, long d, long P, T* ws, hipStream_t stream) {
+                   int prec, const T* u, const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* A, T* A_frag, T* f,
+                   T* v, long E, long n, long M, long d, long P, T* ws, hipStream_t stream) {
+  HB_REQUIRE(!A_frag || (sizeof(T) == 4 && Wf && ws && hb_sgp_strip_path(E, n, M, d, P, prec)),
+             "hb_sgp_fwd: a fragment-major A needs the column-strip form (fp32, Wfrag, hb_sgp_strip_path)");
   HB_REQUIRE(prec == HB_PREC_NATIVE || prec == HB_PREC_BF16X3, "hb_sgp_fwd: unknown precision %d", prec);
   HB_REQUIRE(prec == HB_PREC_NATIVE || (sizeof(T) == 4 && Wf && M % 32 == 0 && M <= SGP_SM_MAX && d <= SGP_DREG && P <= 4 && ws),
              "hb_sgp_fwd: bf16x3 needs fp32, the bf16 images in Wfrag, M %% 32 == 0, M <= %d, d <= %d, P <= 4", SGP_SM_MAX, SGP_DREG);
@@ -1169,7 +1211,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   HB_REQUIRE(mode == HB_SGP_NEGLECTED || mode == HB_SGP_DIAGONAL, "hb_sgp_fwd: unknown mode %d", mode);
   HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1 && P >= 0, "hb_sgp_fwd: bad extents");
   HB_REQUIRE(dl == 1 || dl == d, "hb_sgp_fwd: lengthscales must have 1 or d entries");
-  HB_REQUIRE(x && z && ell && W && u && A && f && v, "hb_sgp_fwd: NULL pointer");
+  HB_REQUIRE(x && z && ell && W && u && (A || A_frag) && f && v, "hb_sgp_fwd: NULL pointer");
   HB_REQUIRE(E <= 65535, "hb_sgp_fwd: too many experts");
   HB_REQUIRE(M * n < 2147483647L && M * M < 2147483647L && n * d < 2147483647L, "hb_sgp_fwd: matrix too large for 32-bit indexing");
   if (E * n == 0) return 0;
@@ -1184,8 +1226,10 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.n = n; a.M = M; a.d = d; a.P = P;
     a.W3 = prec == HB_PREC_BF16X3 ? (const void*)(Wf + 2 * E * M * M) : nullptr;
     a.plane3 = E * M * M;
+    a.Af = A_frag;
     a.part = ws + E * n + E * M * d;
-    const bool strip = sizeof(T) == 4 && ((sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip()) || prec == HB_PREC_BF16X3);
+    const bool strip = sizeof(T) == 4 && ((Wf && hb_sgp_strip_path(E, n, M, d, P, prec)) ||
+                                          (sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip()));
     const int gyp = strip ? 1 : gy;  // partial rows of the column statistics
     int rc;
     if (strip) {
@@ -1218,7 +1262,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     SgpArgs<T> a;
     a.x = x; a.sx = sx; a.z = z; a.ell = ell; a.dl = dl; a.W = W; a.Wf = nullptr; a.u = u; a.A = A;
     a.n = n; a.M = M; a.d = d; a.P = P;
-    a.W3 = nullptr; a.plane3 = 0;
+    a.W3 = nullptr; a.plane3 = 0; a.Af = nullptr;
     a.part = nullptr;
     dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), gy, E, a.efast);
     int rc = sgp_A_launch<T>(a, grid, stream);
@@ -1250,6 +1294,7 @@ static int sgp_A_only(int kind, const T* x, long sx, const T* z, const T* ell, l
   a.n = n; a.M = M; a.d = d; a.P = 0;
   a.W3 = prec == HB_PREC_BF16X3 ? (const void*)(Wf + 2 * E * M * M) : nullptr;
   a.plane3 = E * M * M;
+  a.Af = nullptr;
   a.part = nullptr;
   if (sizeof(T) == 4 && ((sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip()) || prec == HB_PREC_BF16X3))
     return sgp_A_strip_launch(a, E, stream);
@@ -1270,17 +1315,18 @@ extern "C" int hb_sgp_A_f64(int kind, const double* x, long sx, const double* z,
 
 extern "C" int hb_sgp_fwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell, long dl,
                               const float* W, const float* Wfrag, int prec, const float* u, const float* eps_in,
-                              uint64_t* rng, long rng_lanes, float* eps_out, float* A, float* f, float* v, long E,
-                              long n, long M, long d, long P, float* ws, void* stream) {
-  return sgp_fwd<float>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E,
-                        n, M, d, P, ws, (hipStream_t)stream);
+                              uint64_t* rng, long rng_lanes, float* eps_out, float* A, float* A_frag, float* f, float* v,
+                              long E, long n, long M, long d, long P, float* ws, void* stream) {
+  return sgp_fwd<float>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps_in, rng, rng_lanes, eps_out, A, A_frag, f, v,
+                        E, n, M, d, P, ws, (hipStream_t)stream);
 }
 extern "C" int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
                               long dl, const double* W, const double* Wfrag, int prec, const double* u,
-                              const double* eps_in, uint64_t* rng, long rng_lanes, double* eps_out, double* A, double* f,
-                              double* v, long E, long n, long M, long d, long P, double* ws, void* stream) {
-  return sgp_fwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps_in, rng, rng_lanes, eps_out, A, f, v, E,
-                         n, M, d, P, ws, (hipStream_t)stream);
+                              const double* eps_in, uint64_t* rng, long rng_lanes, double* eps_out, double* A,
+                              double* A_frag, double* f, double* v, long E, long n, long M, long d, long P, double* ws,
+                              void* stream) {
+  return sgp_fwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps_in, rng, rng_lanes, eps_out, A, A_frag, f,
+                         v, E, n, M, d, P, ws, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -1324,6 +1370,8 @@ struct SgpBwdArgs {
   const void* WT3;  // bf16x3 images of W^T (3 planes) or nullptr
   long plane3;
   T* part;        // [E, nS, 2d + P, M] strip partials of zbar, ell, ubar
+  const T* Af;    // fragment-major A (written by the forward strip kernel), or nullptr: read A row-major
+  T* Kf;          // fragment-major Kbar output for the Lbar contraction, or nullptr
 };
 
 template <typename T>
@@ -1470,7 +1518,6 @@ __device__ __forceinline__ float hb_half_wave_sum_dpp(float v) {
 // a lane sums its 16 columns in registers).  That replaces sgp_kbar_kernel + sgp_rowgrad_vec_kernel, i.e. the second
 // full read of Kbar and A (33.5 MB) disappears; the strips' partial sums are folded by sgp_strip_finish_kernel.
 // ---------------------------------------------------------------------------------------------------------------
-#define SGP_TLD 36
 template <int D, bool BF3>
 __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBwdArgs<float> a) {
   typedef float V4 __attribute__((ext_vector_type(4)));
@@ -1491,9 +1538,9 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
   const float* __restrict__ x = a.x + e * a.sx;
   const float* __restrict__ z = a.z + e * a.M * D;
   const float* __restrict__ ell = a.ell + e * a.dl;
-  const float* __restrict__ A = a.A + e * a.M * a.n;
+  const float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
   const float* __restrict__ fbar = a.fbar + e * a.P * a.n;
-  float* __restrict__ Kbar = a.Kbar + e * a.M * a.n;
+  float* __restrict__ Kbar = a.Kbar ? a.Kbar + e * a.M * a.n : nullptr;
   const int M = (int)a.M, n = (int)a.n, P = (int)a.P;
   const int col0 = bx * SGP_SN, nS = (n + SGP_SN - 1) / SGP_SN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
@@ -1546,9 +1593,56 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
   __syncthreads();
 
   // ---- Abar[:, strip] -> LDS ([column][k]); ubar partials of the strip on the way.
-  // Thread (c, kq) takes groups of G consecutive rows k for its column c: the global loads of a wave cover two
-  // 128-byte row segments, the LDS store is one conflict-free 16-byte vector per group.
-  {
+  if (a.Af) {
+    // fragment-major A: block (t, strip) is one contiguous 4 KB; wave w takes the row tiles w, w + 8, ...;
+    // lane (li, h) of load v holds A[32t + li][16h + 4v .. +3]
+    const float* __restrict__ Af = a.Af;
+    const int nTp = M / 32;
+    for (int t = w; t < nTp; t += SGP_STRIP_THREADS / 64) {
+      const float* blk = Af + ((((long)e * nTp + t) * nS + bx) << 10) + 4 * lane;
+      V4 av[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) av[v] = *reinterpret_cast<const V4*>(blk + 256 * v);
+      const int k = 32 * t + li;
+      float uk[4], usum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) uk[p] = p < P ? us[p][k] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const V4 cj4 = *reinterpret_cast<const V4*>(&cjs[16 * h + 4 * v]);
+        V4 fb4[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) fb4[p] = *reinterpret_cast<const V4*>(&fbs[p][16 * h + 4 * v]);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          const int c = 16 * h + 4 * v + s2;
+          float val = av[v][s2] * cj4[s2];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            if (p < P) {
+              val += uk[p] * fb4[p][s2];
+              usum[p] += fb4[p][s2] * av[v][s2];
+            }
+          if (BF3) {
+            const __bf16 b0 = (__bf16)val;
+            const float r1 = val - (float)b0;
+            const __bf16 b1 = (__bf16)r1;
+            K3[0][c][k] = b0, K3[1][c][k] = b1, K3[2][c][k] = (__bf16)(r1 - (float)b1);
+          } else {
+            Ks[c][k] = val;
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (p < P) {
+          const float tsum = usum[p] + __shfl_xor(usum[p], 32);
+          if (h == 0) part[(long)(2 * D + p) * M + k] = tsum;
+        }
+    }
+  } else {
+    // row-major A.  Thread (c, kq) takes groups of G consecutive rows k for its column c: the global loads of a wave
+    // cover two 128-byte row segments, the LDS store is one conflict-free 16-byte vector per group.
     constexpr int G = BF3 ? 8 : 4;
     const int c = tid & 31, kq = tid >> 5;           // 16 row-group lanes
     const bool cok = col0 + c < n;
@@ -1635,16 +1729,21 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * tile + MM::acc_row(lane, r);
-      if (gc < n) Kbar[(long)row * n + gc] = acc[r];
+      if (a.Kbar && gc < n) Kbar[(long)row * n + gc] = acc[r];
       Tw[w][MM::acc_row(lane, r)][li] = acc[r];
     }
     // row-per-lane view: lane (li, h) takes row li, columns 16h .. 16h+15 of the tile
     float kb[16];
+    float* kfblk = a.Kf ? a.Kf + ((((long)e * nT + tile) * nS + bx) << 10) + 4 * lane : nullptr;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const V4 q = *reinterpret_cast<const V4*>(&Tw[w][li][16 * h + 4 * v]);
+      V4 q = *reinterpret_cast<const V4*>(&Tw[w][li][16 * h + 4 * v]);
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) kb[4 * v + s2] = q[s2];
+      for (int s2 = 0; s2 < 4; ++s2) {
+        if (col0 + 16 * h + 4 * v + s2 >= n) q[s2] = 0.f;
+        kb[4 * v + s2] = q[s2];
+      }
+      if (kfblk) *reinterpret_cast<V4*>(kfblk + 256 * v) = q;   // fragment-major Kbar: one contiguous KB per store
     }
     const int row = 32 * tile + li;
     float zr[D], zacc[D], lacc[D];
@@ -1659,7 +1758,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
         tt[dd] = zr[dd] - xss[c * D + dd];
         r2 += tt[dd] * tt[dd];
       }
-      const float gk = (col0 + c < n) ? kb[i] * hb_exp2_neg<float>(r2) : 0.f;
+      const float gk = kb[i] * hb_exp2_neg<float>(r2);   // (columns past n hold zeros)
 #pragma unroll
       for (int dd = 0; dd < D; ++dd) {
         zacc[dd] -= gk * tt[dd];
@@ -1774,6 +1873,136 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
       for (int ww = 0; ww < SGP_STRIP_THREADS / 64; ++ww) t += red[ww * D + dd];
       part[(long)(D + dd) * M] = t * sc[dd] * float(1.0 / (SGP_EXP2_SCALE * SGP_EXP2_SCALE * SGP_EXP2_SCALE));
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Lbar = -tril(Kbar A^T) from the FRAGMENT-MAJOR Kbar and A that the strip kernels leave (contraction over the data
+// axis, M^2 n flops on the lower tiles).  Workgroup = one 32 x 32 output tile (t >= t') x one slab of 32 strips; its
+// eight waves take four strips each -- all eight operand loads of a wave are issued before its 64 MFMAs, and every
+// load is one contiguous kilobyte -- and meet in LDS; the workgroup writes ONE partial tile.  sgp_lbar_finish_kernel
+// sums the slabs (fixed order), negates and clears the upper triangle.  Replaces the LDS-staged split-K GEMM over
+// the row-major operands (36.8 + 5.4 us at cfg 2, 33 % of its LDS cycles bank conflicts).
+// ---------------------------------------------------------------------------------------------------------------
+// Work split.  The operands are re-read once per output tile they meet, and at 32 x 32 tiles per wave that traffic
+// (285 MB out of L2 at cfg 2 for 33.5 MB of operands) -- not the MFMAs -- set the time (32-41 us in two variants).
+// A WAVE therefore owns a 64 x 64 block (2 x 2 tiles, four accumulators): per strip it loads two Kbar and two A
+// fragment sets (16 contiguous-kilobyte loads) for 64 MFMAs, halving the bytes per flop; the four waves of a
+// workgroup split a slab of strips and meet in LDS; S slabs give ~2 waves per SIMD.  On the diagonal blocks the
+// tile above the diagonal is skipped.
+template <int DUMMY>
+__global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restrict__ Kf, const float* __restrict__ Af,
+                                                            float* __restrict__ slabs, int M, int nS, int S, long E) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef Mma<float> MM;
+  __shared__ float red[4][4][32][33];
+  const int nT = M / 32, nB = (nT + 1) / 2;             // 64-row blocks (the last one may hold a single tile)
+  const int slab = blockIdx.x % S, pair = blockIdx.x / S;
+  const long e = blockIdx.y;
+  int bi = (int)((sqrtf(8.f * (float)pair + 1.f) - 1.f) * 0.5f);
+  while (bi * (bi + 1) / 2 > pair) --bi;
+  while ((bi + 1) * (bi + 2) / 2 <= pair) ++bi;
+  const int bj = pair - bi * (bi + 1) / 2;
+  (void)nB;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int base = nS / S, rem = nS % S;
+  const int sb = slab * base + (slab < rem ? slab : rem), se = sb + base + (slab < rem ? 1 : 0);
+  const int cnt = se - sb, wq = cnt / 4, wr = cnt % 4;
+  const int s0 = sb + w * wq + (w < wr ? w : wr), s1 = s0 + wq + (w < wr ? 1 : 0);
+  // tiles of the block: rows 2bi, 2bi+1 (the second may not exist), columns 2bj, 2bj+1
+  const int ti0 = 2 * bi, ti1 = 2 * bi + 1 < nT ? 2 * bi + 1 : ti0, tj0 = 2 * bj, tj1 = 2 * bj + 1 < nT ? 2 * bj + 1 : tj0;
+  const bool has_i1 = 2 * bi + 1 < nT, has_j1 = 2 * bj + 1 < nT;
+  const bool upper01 = bi == bj;                         // tile (ti0, tj1) lies above the diagonal
+  const long tstride = (long)nS << 10;
+  const float* __restrict__ kbase = Kf + (long)e * nT * tstride + 4 * lane;
+  const float* __restrict__ abase = Af + (long)e * nT * tstride + 4 * lane;
+  typename MM::Acc acc[4];                               // [2 * row + col]
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  struct Frag {
+    V4 a0[4], a1[4], b0[4], b1[4];
+  };
+  auto load = [&](Frag& f, int sidx) {
+    const int sc = sidx < s1 ? sidx : (s1 > s0 ? s1 - 1 : s0);
+    const long off = (long)sc << 10;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      f.a0[v] = *reinterpret_cast<const V4*>(kbase + ti0 * tstride + off + 256 * v);
+      f.a1[v] = *reinterpret_cast<const V4*>(kbase + ti1 * tstride + off + 256 * v);
+      f.b0[v] = *reinterpret_cast<const V4*>(abase + tj0 * tstride + off + 256 * v);
+      f.b1[v] = *reinterpret_cast<const V4*>(abase + tj1 * tstride + off + 256 * v);
+    }
+  };
+  auto compute = [&](const Frag& f, int sidx) {
+    if (sidx >= s1) return;  // uniform
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        acc[0] = MM::mma(f.a0[v][s2], f.b0[v][s2], acc[0]);
+        acc[2] = MM::mma(f.a1[v][s2], f.b0[v][s2], acc[2]);
+        acc[3] = MM::mma(f.a1[v][s2], f.b1[v][s2], acc[3]);
+        if (!upper01) acc[1] = MM::mma(f.a0[v][s2], f.b1[v][s2], acc[1]);
+      }
+  };
+  if (s1 > s0) {
+    Frag fa, fb;
+    load(fa, s0);
+#pragma nounroll
+    for (int sidx = s0; sidx < s1; sidx += 2) {
+      load(fb, sidx + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fa, sidx);
+      __builtin_amdgcn_sched_barrier(0);
+      load(fa, sidx + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fb, sidx + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][q][MM::acc_row(lane, r)][lane & 31] = acc[q][r];
+  __syncthreads();
+  float* out = slabs + (((long)slab * E + e) * M) * M;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ti = (q >> 1) ? ti1 : ti0, tj = (q & 1) ? tj1 : tj0;
+    const bool live = ((q >> 1) == 0 || has_i1) && ((q & 1) == 0 || has_j1) && !(q == 1 && upper01);
+    if (!live) continue;  // uniform
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + 256 * k, r = idx >> 5, c = idx & 31;
+      const float v = (red[0][q][r][c] + red[1][q][r][c]) + (red[2][q][r][c] + red[3][q][r][c]);
+      out[(long)(32 * ti + r) * M + 32 * tj + c] = v;
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_lbar_finish_kernel(const T* __restrict__ slabs, int S, long E, long M,
+                                                              T* __restrict__ Lbar) {
+  const long total = E * M * M;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long rem = t % (M * M);
+    const long r = rem / M, c = rem - r * M;
+    T acc = T(0);
+    if (c <= r) {
+      T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+      int s = 0;
+      for (; s + 4 <= S; s += 4) {
+        const T v0 = slabs[(long)s * total + t], v1 = slabs[(long)(s + 1) * total + t];
+        const T v2 = slabs[(long)(s + 2) * total + t], v3 = slabs[(long)(s + 3) * total + t];
+        a0 += v0, a1 += v1, a2 += v2, a3 += v3;
+      }
+      for (; s < S; ++s) a0 += slabs[(long)s * total + t];
+      acc = -((a0 + a1) + (a2 + a3));
+    }
+    Lbar[t] = acc;
+  }
 }
 
 // Fold the strips' partial sums (sgp_kbar_strip_kernel):  zbar[e, m, q] = sum_s part[e, s, q, m];
@@ -2095,18 +2324,47 @@ static int sgp_bwd_strip_launch(SgpBwdArgs<float> a, long E, long nS, hipStream_
 }
 static int sgp_bwd_strip_launch(SgpBwdArgs<double>, long, long, hipStream_t) { return -1; }  // fp32 only
 
+static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, float* Lbar, long E, long M, long nS,
+                                hipStream_t stream) {
+  const int nT = (int)(M / 32);
+  const long nB = (nT + 1) / 2, pairs = nB * (nB + 1) / 2;   // lower 64 x 64 blocks
+  // ~2 waves per SIMD over the whole grid (4 waves per workgroup, 1024 SIMDs), each wave at least two strips
+  long S = 512 / (pairs * E);
+  if (S > nS / 8) S = nS / 8;
+  if (S > 32) S = 32;     // the slabs live in the 32*E*M*M-element workspace
+  if (S < 1) S = 1;
+  // slab <-> XCD affinity: workgroups are dealt to the 8 XCDs round-robin by blockIdx.x and the slab index is its
+  // fastest coordinate, so with S a multiple of 8 all workgroups of a slab -- which re-read the same strips of Kbar
+  // and A -- share one L2 instead of pulling the operands through the Infinity Cache into all eight
+  if (S >= 8) S = (S + 4) / 8 * 8;
+  if (S > 32) S = 32;
+  {
+    static const char* fs = getenv("HB_LBAR_FORCE_S");  // diagnostic
+    if (fs) S = atol(fs);
+  }
+  dim3 grid((unsigned)(pairs * S), (unsigned)E, 1);
+  hipLaunchKernelGGL(sgp_lbar_frag_kernel<0>, grid, dim3(256), 0, stream, Kf, Af, slabs, (int)M, (int)nS, (int)S, E);
+  HB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sgp_lbar_finish_kernel<float>, dim3(hb_stream_grid(E * M * M, 256)), dim3(256), 0, stream, slabs, (int)S, E,
+                     M, Lbar);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+static int sgp_lbar_frag_launch(const double*, const double*, double*, double*, long, long, long, hipStream_t) { return -1; }
+
 template <typename T>
 static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W,
-                   const T* Wfrag, int prec, const T* u, const T* eps, const T* A, const T* v, const T* fbar, T* Kbar,
-                   T* Lbar, T* ubar, T* zbar, T* ellbar, T* xbar, long E, long n, long M, long d, long P, T* ws,
-                   hipStream_t stream) {
+                   const T* Wfrag, int prec, const T* u, const T* eps, const T* A, const T* A_frag, const T* v,
+                   const T* fbar, T* Kbar, T* Kbar_frag, T* Lbar, T* ubar, T* zbar, T* ellbar, T* xbar, long E, long n,
+                   long M, long d, long P, T* ws, hipStream_t stream) {
   HB_REQUIRE(prec == HB_PREC_NATIVE || prec == HB_PREC_BF16X3, "hb_sgp_bwd: unknown precision %d", prec);
   HB_REQUIRE(kind == HB_KERN_RBF, "hb_sgp_bwd: only the UnitRBF kernel is fused (kind=%d)", kind);
   HB_REQUIRE(mode == HB_SGP_NEGLECTED || mode == HB_SGP_DIAGONAL, "hb_sgp_bwd: unknown mode %d", mode);
   HB_REQUIRE(E >= 0 && n >= 0 && M >= 0 && d >= 1 && P >= 0, "hb_sgp_bwd: bad extents");
   HB_REQUIRE(dl == 1 || dl == d, "hb_sgp_bwd: lengthscales must have 1 or d entries");
-  HB_REQUIRE(x && z && ell && W && u && A && v && fbar && Kbar && Lbar && ubar && zbar && ellbar && ws,
+  HB_REQUIRE(x && z && ell && W && u && (A || A_frag) && v && fbar && (Kbar || Kbar_frag) && Lbar && ubar && zbar && ellbar && ws,
              "hb_sgp_bwd: NULL pointer");
+  HB_REQUIRE((A_frag != nullptr) == (Kbar_frag != nullptr), "hb_sgp_bwd: A_frag and Kbar_frag go together");
   HB_REQUIRE(mode == HB_SGP_NEGLECTED || eps, "hb_sgp_bwd: eps required for the diagonal mode");
   HB_REQUIRE(E <= 65535, "hb_sgp_bwd: too many experts");
   HB_REQUIRE(M * n < 2147483647L && M * M < 2147483647L && n * d < 2147483647L, "hb_sgp_bwd: matrix too large for 32-bit indexing");
@@ -2116,9 +2374,10 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   const long mmws_elems = 32 * E * M * M;
   // column-strip form: fp32, fragment-major W^T available, M a multiple of 32 up to SGP_SM_MAX, small d and P, no xbar
   const long nS = hb_cdiv(n, SGP_SN);
-  const bool strip = sizeof(T) == 4 && Wfrag && n > 0 && M % 32 == 0 && M >= 32 && M <= SGP_SM_MAX && d <= SGP_DREG &&
-                     P <= 4 && !xbar && nS * (2 * d + P) * M * E <= mmws_elems && !hb_sgp_no_strip() &&
-                     (E * nS <= 4096 || prec == HB_PREC_BF16X3);
+  const bool strip = sizeof(T) == 4 && Wfrag && !xbar && hb_sgp_strip_path(E, n, M, d, P, prec) &&
+                     nS * (2 * d + P) * M * E <= mmws_elems;
+  HB_REQUIRE(!A_frag || strip, "hb_sgp_bwd: fragment-major A / Kbar need the column-strip form (see hb_sgp_strip_path)");
+  HB_REQUIRE(strip || (A && Kbar), "hb_sgp_bwd: row-major A and Kbar required outside the column-strip form");
   HB_REQUIRE(prec == HB_PREC_NATIVE || strip, "hb_sgp_bwd: bf16x3 needs the column-strip form (fp32, Wfrag, M %% 32 == 0, M <= %d, "
              "d <= %d, P <= 4, no xbar)", SGP_SM_MAX, SGP_DREG);
   if (strip) {
@@ -2131,11 +2390,14 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
                                    : nullptr;
     a.plane3 = E * M * M;
     a.part = mmws;   // consumed by the finish kernel before the Lbar contraction reuses the space
+    a.Af = A_frag; a.Kf = Kbar_frag;
+    if (A_frag) a.Kbar = nullptr;   // Kbar only feeds the Lbar contraction: the fragment-major copy is enough
     int rc = sgp_bwd_strip_launch(a, E, nS, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(sgp_strip_finish_kernel<T>, dim3((unsigned)hb_cdiv(M, 64), (unsigned)(2 * d + P), (unsigned)E), dim3(256), 0,
                        stream, mmws, (int)nS, M, d, dl, P, zbar, ellbar, ubar);
     HB_LAUNCH_CHECK();
+    if (A_frag) return sgp_lbar_frag_launch(Kbar_frag, A_frag, mmws, Lbar, E, M, nS, stream);
     int rc2 = sgp_matmul(Kbar, A, Lbar, E, M, M, n, n, n, M, M * n, M * n, M * M, 0, 1, -1.0, HB_MM_TRIL_OUT, mmws, mmws_elems,
                          (void*)stream);
     return rc2;
@@ -2145,7 +2407,7 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.W = W; a.u = u; a.A = A; a.fbar = fbar; a.eps = eps; a.v = v; a.Kbar = Kbar;
     a.n = n; a.M = M; a.P = P; a.mode = mode;
     a.x = nullptr; a.sx = 0; a.z = nullptr; a.ell = nullptr; a.dl = 0; a.d = d; a.WTf = nullptr; a.WT3 = nullptr;
-    a.plane3 = 0; a.part = nullptr;
+    a.plane3 = 0; a.part = nullptr; a.Af = nullptr; a.Kf = nullptr;
     const int nRB = hb_cdiv(M, SGP_BM);
     dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), sgp_grid_y(E, n, nRB), E, a.efast);
     constexpr long VECH = 16 / sizeof(T);
@@ -2200,17 +2462,17 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
 
 extern "C" int hb_sgp_bwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell, long dl,
                               const float* W, const float* Wfrag, int prec, const float* u, const float* eps,
-                              const float* A, const float* v, const float* fbar, float* Kbar, float* Lbar, float* ubar,
-                              float* zbar, float* ellbar, float* xbar, long E, long n, long M, long d, long P, float* ws,
-                              void* stream) {
-  return sgp_bwd<float>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps, A, v, fbar, Kbar, Lbar, ubar, zbar, ellbar,
-                        xbar, E, n, M, d, P, ws, (hipStream_t)stream);
+                              const float* A, const float* A_frag, const float* v, const float* fbar, float* Kbar,
+                              float* Kbar_frag, float* Lbar, float* ubar, float* zbar, float* ellbar, float* xbar, long E,
+                              long n, long M, long d, long P, float* ws, void* stream) {
+  return sgp_bwd<float>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps, A, A_frag, v, fbar, Kbar, Kbar_frag, Lbar,
+                        ubar, zbar, ellbar, xbar, E, n, M, d, P, ws, (hipStream_t)stream);
 }
 extern "C" int hb_sgp_bwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
                               long dl, const double* W, const double* Wfrag, int prec, const double* u, const double* eps,
-                              const double* A, const double* v, const double* fbar, double* Kbar, double* Lbar,
-                              double* ubar, double* zbar, double* ellbar, double* xbar, long E, long n, long M, long d,
-                              long P, double* ws, void* stream) {
-  return sgp_bwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps, A, v, fbar, Kbar, Lbar, ubar, zbar,
-                         ellbar, xbar, E, n, M, d, P, ws, (hipStream_t)stream);
+                              const double* A, const double* A_frag, const double* v, const double* fbar, double* Kbar,
+                              double* Kbar_frag, double* Lbar, double* ubar, double* zbar, double* ellbar, double* xbar,
+                              long E, long n, long M, long d, long P, double* ws, void* stream) {
+  return sgp_bwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps, A, A_frag, v, fbar, Kbar, Kbar_frag, Lbar,
+                         ubar, zbar, ellbar, xbar, E, n, M, d, P, ws, (hipStream_t)stream);
 }

@@ -1406,8 +1406,20 @@ def _sgp_emit(plan, node):
     # bf16x3 operands (settings.numerics.contraction): column-strip kernel only (d <= 4, at most 4 latent functions)
     bf3 = bf3 and node.inputs[0].shape[-1] <= 4 and node.inputs[5].shape[-2] <= 4
     prec = H.PREC_BF16X3 if bf3 else H.PREC_NATIVE
+    # A = L^-1 K(z,x) is only an intermediate between this op and its VJP: when both run in column-strip form it is
+    # exchanged in fragment-major layout (every load and store of the three M^2 n contractions a contiguous KB),
+    # and the row-major copy is not written at all
+    zsh, xsh = node.inputs[1].shape, node.inputs[0].shape
+    E, M, n, d, P = int(np.prod(zsh[:-2])) if len(zsh) > 2 else 1, zsh[-2], xsh[-2], xsh[-1], node.inputs[5].shape[-2]
+    a_frag, skip_a = None, False
+    if wfrag is not None and plan.dtype == plan.torch.float32 and H.sgp_strip_path(E, n, M, d, P, prec):
+        users = list(plan._consumers.get(node.outputs[1], ()))
+        if users and all(c.op == "sgp_grad" and not plan.needed(c.outputs[4]) for c in users):
+            a_frag = plan.scratch((H.sgp_frag_elems(E, n, M),))
+            plan._afrag[node.outputs[1]] = a_frag
+            skip_a = node.outputs[1] not in plan.outputs
     plan.steps.append(lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag,
-                                        prec=prec))
+                                        prec=prec, a_frag=a_frag, skip_a=skip_a))
 
 
 def _sgp_vjp(node, gs):
@@ -1428,7 +1440,6 @@ def _sgp_grad_emit(plan, node):
     H = plan.H
     x, z, ell, W, u, eps, A, v, gf = (plan.buf(t) for t in node.inputs)
     Lb, ub, zb, lb, xb = (plan.out(t) for t in node.outputs)
-    Kbar = plan.scratch(A.shape)
     mode = SGP_MODES[node.attrs["mode"]]
     need_x = plan.needed(node.outputs[4])
     if need_x and len(node.inputs[1].shape) > 2 and len(node.inputs[0].shape) == 2:
@@ -1437,8 +1448,12 @@ def _sgp_grad_emit(plan, node):
     wfrag, bf3 = plan._wfrag.get(_through_stop_gradient(node.inputs[3]), (None, False))
     bf3 = bf3 and not need_x and node.inputs[0].shape[-1] <= 4 and node.inputs[4].shape[-2] <= 4
     prec = H.PREC_BF16X3 if bf3 else H.PREC_NATIVE
+    a_frag = plan._afrag.get(node.inputs[6])          # fragment-major A from the forward op (see _sgp_emit)
+    kbar_frag = plan.scratch((a_frag.numel(),)) if a_frag is not None else None
+    Kbar = plan.scratch(A.shape) if a_frag is None else None
     plan.steps.append(lambda: H.sgp_bwd(x, z, ell, W, u, eps, A, v, gf, mode=mode, need_xbar=need_x,
-                                        out=(Kbar, Lb, ub, zb, lb, xbuf), wfrag=wfrag, prec=prec))
+                                        out=(Kbar, Lb, ub, zb, lb, xbuf), wfrag=wfrag, prec=prec, a_frag=a_frag,
+                                        kbar_frag=kbar_frag))
 
 
 defop("sgp", _sgp_emit, _sgp_vjp)
@@ -1718,6 +1733,7 @@ class Plan:
         self._extra_copies = []
         self._fused_trinv = set()
         self._wfrag: Dict[Tensor, object] = {}   # W tensor -> fragment-major copies written by the fused factorisation
+        self._afrag: Dict[Tensor, object] = {}   # A tensor of an sgp op -> its fragment-major copy (read by sgp_grad)
         self._fused_matutil = set()
         self._fused_concat = set()
         self._lazy_cols: Dict[Tensor, object] = {}

@@ -619,7 +619,18 @@ def _sgp_dims(x, z, u):
     return E, n, M, d, P, sx
 
 
-def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None, wfrag=None, prec=PREC_NATIVE):
+def sgp_strip_path(E, n, M, d, P, prec=PREC_NATIVE):
+    """True when sgp_fwd / sgp_bwd (given wfrag) run in column-strip form and may exchange A / Kbar fragment-major."""
+    return bool(_lib.lib().raw("hb_sgp_strip_path")(E, n, M, d, P, int(prec)))
+
+
+def sgp_frag_elems(E, n, M):
+    """Elements of a fragment-major [E, M, n] operand (columns padded to whole strips of 32)."""
+    return E * M * 32 * ((n + 31) // 32)
+
+
+def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None, wfrag=None, prec=PREC_NATIVE,
+            a_frag=None, skip_a=False):
     """Returns (f[E?,P,n], A[E?,M,n], v[E?,n], eps[E?,n]).  `wfrag`: cholesky_inverse's fragment-major copies of W."""
     for t in (x, z, ell, W, u):
         _chk(t)
@@ -636,8 +647,10 @@ def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None,
     dl = ell.numel() // E
     rp, rl = _rng_args(rng)
     ws = workspace(dt, dev, int(_lib.lib().raw("hb_sgp_ws_elems")(E, n, M, d, P)))
+    # a_frag: also (skip_a: only) leave A fragment-major for sgp_bwd (column-strip form, see the header)
     _lib.lib().call("hb_sgp_fwd" + _suf(x), KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(wfrag), int(prec), _p(u), _p(eps_in),
-                    rp, rl, _p(eps), _p(A), _p(f), _p(v), E, n, M, d, P, _p(ws), stream())
+                    rp, rl, _p(eps), None if (skip_a and a_frag is not None) else _p(A), _p(a_frag), _p(f), _p(v), E, n,
+                    M, d, P, _p(ws), stream())
     return f, A, v, eps
 
 
@@ -655,13 +668,13 @@ def sgp_A(x, z, ell, W, out=None, wfrag=None, prec=PREC_NATIVE):
 
 
 def sgp_bwd(x, z, ell, W, u, eps, A, v, fbar, mode=SGP_DIAGONAL, need_xbar=False, out=None, wfrag=None,
-            prec=PREC_NATIVE):
+            prec=PREC_NATIVE, a_frag=None, kbar_frag=None):
     """Returns (Lbar, ubar, zbar, ellbar, xbar|None)."""
     E, n, M, d, P, sx = _sgp_dims(x, z, u)
     dev, dt = x.device, x.dtype
     dl = ell.numel() // E
     if out is None:
-        Kbar = _empty_like(A)
+        Kbar = _empty_like(A) if a_frag is None else None
         Lbar = _empty_like(W)
         ubar = _empty_like(u)
         zbar = _empty_like(z)
@@ -671,9 +684,11 @@ def sgp_bwd(x, z, ell, W, u, eps, A, v, fbar, mode=SGP_DIAGONAL, need_xbar=False
         Kbar, Lbar, ubar, zbar, ellbar, xbar = out
     wse = _lib.lib().raw("hb_sgp_ws_elems")(E, n, M, d, P)
     ws = workspace(dt, dev, wse)
+    if a_frag is not None and kbar_frag is None:
+        kbar_frag = _empty(a_frag.numel(), dtype=dt, device=dev)
     _lib.lib().call("hb_sgp_bwd" + _suf(x), KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(wfrag), int(prec), _p(u), _p(eps),
-                    _p(A), _p(v), _p(fbar), _p(Kbar), _p(Lbar), _p(ubar), _p(zbar), _p(ellbar), _p(xbar), E, n, M, d,
-                    P, _p(ws), stream())
+                    _p(A) if a_frag is None else None, _p(a_frag), _p(v), _p(fbar), _p(Kbar) if a_frag is None else None,
+                    _p(kbar_frag), _p(Lbar), _p(ubar), _p(zbar), _p(ellbar), _p(xbar), E, n, M, d, P, _p(ws), stream())
     return Lbar, ubar, zbar, ellbar, xbar
 
 

@@ -341,15 +341,22 @@ enum { HB_PREC_NATIVE = 0, HB_PREC_BF16X3 = 1 };
  * Wfrag (nullable): the fragment-major copies hb_cholesky_inverse wrote for this W (faster operand loads).
  * ws >= hb_sgp_ws_elems(...) elements. */
 long hb_sgp_ws_elems(long E, long n, long M, long d, long P);
+/* Column-strip form and fragment-major exchange.  With Wfrag and hb_sgp_strip_path(...) == 1 the contraction runs
+ * as column strips (one workgroup = 32 data columns x all M rows) and A may be left -- additionally (A_frag), or
+ * only (A == NULL) -- in FRAGMENT-MAJOR layout for hb_sgp_bwd:
+ *   A_frag [E][M/32 row tiles t][nS = ceil(n/32) strips s][4 v][64 lanes (li + 32 h)][4 s'] = A[32t+li][32s+16h+4v+s']
+ * (zeros past column n): the MFMA operand fragments of the Lbar contraction over the data axis, in load order. */
+int hb_sgp_strip_path(long E, long n, long M, long d, long P, int prec);
 int hb_sgp_fwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell,
                    long dl, const float* W, const float* Wfrag, int prec, const float* u,
-                   const float* eps_in, uint64_t* rng, long rng_lanes, float* eps_out, float* A, float* f,
-                   float* v, long E, long n, long M, long d, long P, float* ws, void* stream);
+                   const float* eps_in, uint64_t* rng, long rng_lanes, float* eps_out, float* A,
+                   float* A_frag, float* f, float* v, long E, long n, long M, long d, long P, float* ws,
+                   void* stream);
 int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
                    long dl, const double* W, const double* Wfrag, int prec, const double* u,
                    const double* eps_in, uint64_t* rng, long rng_lanes, double* eps_out, double* A,
-                   double* f, double* v, long E, long n, long M, long d, long P, double* ws,
-                   void* stream);
+                   double* A_frag, double* f, double* v, long E, long n, long M, long d, long P,
+                   double* ws, void* stream);
 /* The contraction alone, A = W k(z,x) (posterior-prediction callers; isolated timing). */
 int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
                  const float* W, const float* Wfrag, int prec, float* A, long E, long n, long M, long d,
@@ -364,17 +371,21 @@ int hb_sgp_A_f64(int kind, const double* x, long sx, const double* z, const doub
  *   ubar = fbar A^T            [E,P,M]
  * Wfrag (nullable) / prec: as for hb_sgp_fwd; with Wfrag (fp32, M %% 32 == 0, M <= 512, d <= 4, P <= 4, no xbar) Kbar
  * and the row gradients come from ONE column-strip kernel (no second pass over Kbar and A).
+ * A_frag / Kbar_frag (both or neither; need hb_sgp_strip_path): A is read, and Kbar written, in the fragment-major
+ * layout of hb_sgp_fwd's A_frag (A / Kbar may then be NULL), and Lbar comes from a contraction whose every operand
+ * load is one contiguous kilobyte (E*M*32*ceil(n/32) elements each).
  *   zbar, ellbar (and xbar, nullable) through Kmn = k(z,x). */
 int hb_sgp_bwd_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell,
                    long dl, const float* W, const float* Wfrag, int prec, const float* u, const float* eps,
-                   const float* A, const float* v, const float* fbar, float* Kbar, float* Lbar,
-                   float* ubar, float* zbar, float* ellbar, float* xbar, long E, long n, long M, long d,
-                   long P, float* ws, void* stream);
+                   const float* A, const float* A_frag, const float* v, const float* fbar, float* Kbar,
+                   float* Kbar_frag, float* Lbar, float* ubar, float* zbar, float* ellbar, float* xbar,
+                   long E, long n, long M, long d, long P, float* ws, void* stream);
 int hb_sgp_bwd_f64(int kind, int mode, const double* x, long sx, const double* z, const double* ell,
                    long dl, const double* W, const double* Wfrag, int prec, const double* u,
-                   const double* eps, const double* A, const double* v, const double* fbar, double* Kbar,
-                   double* Lbar, double* ubar, double* zbar, double* ellbar, double* xbar, long E, long n,
-                   long M, long d, long P, double* ws, void* stream);
+                   const double* eps, const double* A, const double* A_frag, const double* v,
+                   const double* fbar, double* Kbar, double* Kbar_frag, double* Lbar, double* ubar,
+                   double* zbar, double* ellbar, double* xbar, long E, long n, long M, long d, long P,
+                   double* ws, void* stream);
 
 /* ---- K9: flat-buffer Adam, TensorFlow-1 formula (reference model.py:206,220
  *      tf.train.AdamOptimizer via optimizer.minimize) --------

@@ -686,12 +686,24 @@ def test_sgp_backward_column_strip_form(H, E, M, n, d, P, mode):
     old = H.sgp_bwd(*bargs, mode=m)                                          # generic fp32 kernels
     new = H.sgp_bwd(*bargs, mode=m, wfrag=frag)                              # column-strip form
     bf3 = H.sgp_bwd(*bargs, mode=m, wfrag=frag, prec=H.PREC_BF16X3)          # ... with bf16x3 operands
+    # fragment-major exchange of A and Kbar (no row-major copies), Lbar from the fragment-major contraction
+    assert H.sgp_strip_path(E, n, M, d, P)
+    a_frag = torch.full((H.sgp_frag_elems(E, n, M),), float("nan"), dtype=dt, device="cuda")
+    f2, _, v2, _ = H.sgp_fwd(*args, eps_in=dev(sq(eps), dt), mode=m, wfrag=frag, a_frag=a_frag, skip_a=True)
+    assert torch.equal(f2, f) and torch.equal(v2, v)
+    nS, nT = (n + 31) // 32, M // 32
+    Ah = np.zeros((E, M, 32 * nS))
+    Ah[:, :, :n] = host(A).reshape(E, M, n)
+    t_, s_, v_, l_, q_ = np.meshgrid(np.arange(nT), np.arange(nS), np.arange(4), np.arange(64), np.arange(4), indexing="ij")
+    want = Ah[:, 32 * t_ + (l_ & 31), 32 * s_ + 16 * (l_ >> 5) + 4 * v_ + q_]
+    assert np.array_equal(host(a_frag).reshape(E, nT, nS, 4, 64, 4), want), "fragment-major A layout"
+    frg = H.sgp_bwd(*(args + (dev(sq(eps), dt), None, v, dev(sq(fbar), dt))), mode=m, wfrag=frag, a_frag=a_frag)
     names = ("Lbar", "ubar", "zbar", "ellbar")
     for i, nm in enumerate(names):
         r = ref[i].reshape(host(old[i]).shape)
         scale = max(1.0, np.abs(r).max())
         e_old = np.abs(host(old[i]) - r).max() / scale
-        for tag, got in (("strip", new), ("bf16x3", bf3)):
+        for tag, got in (("strip", new), ("bf16x3", bf3), ("fragment-major", frg)):
             e_new = np.abs(host(got[i]) - r).max() / scale
             assert e_new <= 3.0 * e_old + 2e-5, (nm, tag, e_old, e_new)
 
