@@ -1883,6 +1883,9 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
 // sums the slabs (fixed order), negates and clears the upper triangle.  Replaces the LDS-staged split-K GEMM over
 // the row-major operands (36.8 + 5.4 us at cfg 2, 33 % of its LDS cycles bank conflicts).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef HB_LSTAMP
+#define HB_LSTAMP(i)
+#endif
 // Work split.  The operands are re-read once per output tile they meet, and at 32 x 32 tiles per wave that traffic
 // (285 MB out of L2 at cfg 2 for 33.5 MB of operands) -- not the MFMAs -- set the time (32-41 us in two variants).
 // A WAVE therefore owns a 64 x 64 block (2 x 2 tiles, four accumulators): per strip it loads two Kbar and two A
@@ -1894,7 +1897,7 @@ __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restr
                                                             float* __restrict__ slabs, int M, int nS, int S, long E) {
   typedef float V4 __attribute__((ext_vector_type(4)));
   typedef Mma<float> MM;
-  __shared__ float red[4][4][32][33];
+  __shared__ float red[4][32][33];   // one tile at a time (16.5 KB: several workgroups per CU)
   const int nT = M / 32, nB = (nT + 1) / 2;             // 64-row blocks (the last one may hold a single tile)
   const int slab = blockIdx.x % S, pair = blockIdx.x / S;
   const long e = blockIdx.y;
@@ -1915,6 +1918,7 @@ __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restr
   const long tstride = (long)nS << 10;
   const float* __restrict__ kbase = Kf + (long)e * nT * tstride + 4 * lane;
   const float* __restrict__ abase = Af + (long)e * nT * tstride + 4 * lane;
+  HB_LSTAMP(0);
   typename MM::Acc acc[4];                               // [2 * row + col]
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -1943,8 +1947,13 @@ __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restr
         acc[0] = MM::mma(f.a0[v][s2], f.b0[v][s2], acc[0]);
         acc[2] = MM::mma(f.a1[v][s2], f.b0[v][s2], acc[2]);
         acc[3] = MM::mma(f.a1[v][s2], f.b1[v][s2], acc[3]);
-        if (!upper01) acc[1] = MM::mma(f.a0[v][s2], f.b1[v][s2], acc[1]);
       }
+    if (!upper01) {   // (uniform; kept out of the MFMA stream above)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc[1] = MM::mma(f.a0[v][s2], f.b1[v][s2], acc[1]);
+    }
   };
   if (s1 > s0) {
     Frag fa, fb;
@@ -1961,11 +1970,7 @@ __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restr
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[w][q][MM::acc_row(lane, r)][lane & 31] = acc[q][r];
-  __syncthreads();
+  HB_LSTAMP(1);
   float* out = slabs + (((long)slab * E + e) * M) * M;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -1973,12 +1978,17 @@ __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restr
     const bool live = ((q >> 1) == 0 || has_i1) && ((q & 1) == 0 || has_j1) && !(q == 1 && upper01);
     if (!live) continue;  // uniform
 #pragma unroll
+    for (int r = 0; r < 16; ++r) red[w][MM::acc_row(lane, r)][lane & 31] = acc[q][r];
+    __syncthreads();
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int idx = tid + 256 * k, r = idx >> 5, c = idx & 31;
-      const float v = (red[0][q][r][c] + red[1][q][r][c]) + (red[2][q][r][c] + red[3][q][r][c]);
+      const float v = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
       out[(long)(32 * ti + r) * M + 32 * tj + c] = v;
     }
+    __syncthreads();
   }
+  HB_LSTAMP(2);
 }
 
 template <typename T>
@@ -2328,16 +2338,14 @@ static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, 
                                 hipStream_t stream) {
   const int nT = (int)(M / 32);
   const long nB = (nT + 1) / 2, pairs = nB * (nB + 1) / 2;   // lower 64 x 64 blocks
-  // ~2 waves per SIMD over the whole grid (4 waves per workgroup, 1024 SIMDs), each wave at least two strips
-  long S = 512 / (pairs * E);
+  // ONE workgroup per CU (256 of them), i.e. one wave per SIMD: fp32 MFMAs occupy the SIMD's vector issue, so a
+  // second wave's reduce / store phase crawls under its partner's MFMA stream (tools/lbar_stamps.hip: 20k cycles of
+  // MFMAs followed by 20k cycles for a 2k-cycle epilogue), and fewer slabs mean fewer partial tiles to write and fold
+  // (S = 7 at M = 512: 70.7 us for the whole backward against 75.7 at S = 14)
+  long S = 256 / (pairs * E);
   if (S > nS / 8) S = nS / 8;
   if (S > 32) S = 32;     // the slabs live in the 32*E*M*M-element workspace
   if (S < 1) S = 1;
-  // slab <-> XCD affinity: workgroups are dealt to the 8 XCDs round-robin by blockIdx.x and the slab index is its
-  // fastest coordinate, so with S a multiple of 8 all workgroups of a slab -- which re-read the same strips of Kbar
-  // and A -- share one L2 instead of pulling the operands through the Infinity Cache into all eight
-  if (S >= 8) S = (S + 4) / 8 * 8;
-  if (S > 32) S = 32;
   {
     static const char* fs = getenv("HB_LBAR_FORCE_S");  // diagnostic
     if (fs) S = atol(fs);
