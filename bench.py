@@ -240,6 +240,10 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
+    ap.add_argument("--contraction", default="native", choices=["native", "bf16x3"],
+                    help="operand form of the M^2 n contractions (bf16x3: BASELINE cfg 5's reduced-precision variant in its "
+                         "usable form: three-term bf16 operands, fp32 accumulation, fp32-level accuracy)")
+    ap.add_argument("--tri-pack", action="store_true", help="cfg3: keep the full-rank q_sqrt as its packed lower triangle")
     args = ap.parse_args()
 
     import numpy as np
@@ -266,6 +270,10 @@ def main():
     import henbun_amd as hb
 
     tf = hb.tf
+    st = hb.settings.get_settings()
+    st.numerics.contraction = args.contraction
+    st.numerics.tri_pack = bool(args.tri_pack)
+    hb.settings._stack.append(st)   # for the whole run (same as `with hb.settings.temp_settings(st):`)
     cfg = CONFIGS[args.config]
     n_global = cfg["n"] * world if args.scaling == "weak" else cfg["n"]
     n_local = n_global // world
@@ -355,10 +363,13 @@ def main():
         "metric": "elbo_samples_per_sec", "value": steps_per_sec * n_global, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
+        "dtype": ("f32" if args.dtype == "float32" else "f64") + ("" if args.contraction == "native" else
+                                                                 " (M^2 n contractions: bf16x3 operands, f32 accumulate)"),
+        "data": "synthetic",
         "config": {"workload": cfg["desc"] % ("per GPU" if args.scaling == "weak" else "global"),
                    "global_batch": n_global, "per_gpu_batch": n_local, "parallelism": "dp%d" % world, "N": cfg["N"],
-                   "M": cfg["M"], "name": args.config, "dp_exchange": getattr(plan, "dp_mode", "none")},
+                   "M": cfg["M"], "name": args.config, "dp_exchange": getattr(plan, "dp_mode", "none"), "contraction": args.contraction,
+                   "tri_pack": bool(args.tri_pack)},
         "steps_per_sec": steps_per_sec,
         "flops_per_step_algorithmic": flops_step,
         "elbo_after": elbo_after,

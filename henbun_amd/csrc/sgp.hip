@@ -611,6 +611,46 @@ __device__ __forceinline__ void sgp_store_frag_tile(float* __restrict__ Xf, floa
   }
 }
 
+// bf16x3 form of the fragment-major exchange (HB_PREC_BF16X3): three planes (hi, mid, lo terms) of bf16, each
+// [E][M/32][nS][2 q][64 lanes][8] with the element X[32t + li][32s + 16h + 8q + j] -- the operand fragment of
+// v_mfma_f32_32x32x16_bf16 for the k16-step q of a strip (the order of the 32 columns inside a strip is the same for
+// both operands of the Lbar contraction, which is all that matters).  `row16` = this lane's 16 columns (row li,
+// columns 16h .. 16h+15) in registers.
+__device__ __forceinline__ void sgp_store_frag3_row(__bf16* __restrict__ X3, long plane, const float (&row16)[16], long e,
+                                                    int nT, int nS, int tile, int strip, int lane) {
+  typedef __bf16 B8 __attribute__((ext_vector_type(8)));
+  __bf16* blk = X3 + ((((long)e * nT + tile) * nS + strip) << 10) + 8 * lane;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    B8 p0, p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = row16[8 * q + j];
+      const __bf16 b0 = (__bf16)x;
+      const float r1 = x - (float)b0;
+      const __bf16 b1 = (__bf16)r1;
+      p0[j] = b0, p1[j] = b1, p2[j] = (__bf16)(r1 - (float)b1);
+    }
+    *reinterpret_cast<B8*>(blk + 512 * q) = p0;
+    *reinterpret_cast<B8*>(blk + plane + 512 * q) = p1;
+    *reinterpret_cast<B8*>(blk + 2 * plane + 512 * q) = p2;
+  }
+}
+// accumulator-layout tile -> row-per-lane registers through the wave's LDS buffer (columns past n zeroed)
+__device__ __forceinline__ void sgp_tile_rows(float (*T)[SGP_TLD], const Mma<float>::Acc& acc, float (&row16)[16], int col0,
+                                              int n, int lane) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  const int li = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) T[Mma<float>::acc_row(lane, r)][li] = acc[r];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const V4 q = *reinterpret_cast<const V4*>(&T[li][16 * h + 4 * v]);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) row16[4 * v + s2] = (col0 + 16 * h + 4 * v + s2 < n) ? q[s2] : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Column-strip contraction, second form: used when the fragment-major image of W is available (hb_cholesky_inverse's
 // Wfrag).  Same decomposition (one workgroup = 32 data columns x all M rows, 8 waves, wave w owns the row tiles
@@ -940,7 +980,13 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip3_kernel(SgpArgs
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[0], acc, 0, 0, 0);
     }
     if (ts == d0 - 1 || ts == nts - 1) {
-      if (a.Af) sgp_store_frag_tile(a.Af, Tw[w], acc, e, nT, (n + SGP_SN - 1) / SGP_SN, tile, bx, col0, n, lane);
+      if (a.Af) {
+        // bf16x3 planes of A for the backward kernels (HB_PREC_BF16X3: A_frag holds 3 bf16 planes)
+        float row16[16];
+        sgp_tile_rows(Tw[w], acc, row16, col0, n, lane);
+        const int nSs = (n + SGP_SN - 1) / SGP_SN;
+        sgp_store_frag3_row(reinterpret_cast<__bf16*>(a.Af), (long)a.plane3 / a.M * 32 * nSs, row16, e, nT, nSs, tile, bx, lane);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * tile + MM::acc_row(lane, r);
@@ -1594,15 +1640,33 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
 
   // ---- Abar[:, strip] -> LDS ([column][k]); ubar partials of the strip on the way.
   if (a.Af) {
-    // fragment-major A: block (t, strip) is one contiguous 4 KB; wave w takes the row tiles w, w + 8, ...;
-    // lane (li, h) of load v holds A[32t + li][16h + 4v .. +3]
-    const float* __restrict__ Af = a.Af;
+    // fragment-major A: wave w takes the row tiles w, w + 8, ...; lane (li, h) ends up with A[32t + li][16h .. 16h+15]
+    // (fp32: four contiguous-kilobyte loads per tile; bf16x3: the three planes, hi + mid + lo)
     const int nTp = M / 32;
+    const long fplane = (long)a.plane3 / a.M * 32 * nS;   // elements per bf16 plane of a fragment-major operand
     for (int t = w; t < nTp; t += SGP_STRIP_THREADS / 64) {
-      const float* blk = Af + ((((long)e * nTp + t) * nS + bx) << 10) + 4 * lane;
-      V4 av[4];
+      float avals[16];
+      if (BF3) {
+        const __bf16* blk = reinterpret_cast<const __bf16*>(a.Af) + ((((long)e * nTp + t) * nS + bx) << 10) + 8 * lane;
+        B8 pl[3][2];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) av[v] = *reinterpret_cast<const V4*>(blk + 256 * v);
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) pl[p][q] = *reinterpret_cast<const B8*>(blk + p * fplane + 512 * q);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) avals[8 * q + j] = ((float)pl[2][q][j] + (float)pl[1][q][j]) + (float)pl[0][q][j];
+      } else {
+        const float* blk = a.Af + ((((long)e * nTp + t) * nS + bx) << 10) + 4 * lane;
+        V4 av[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) av[v] = *reinterpret_cast<const V4*>(blk + 256 * v);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) avals[4 * v + s2] = av[v][s2];
+      }
       const int k = 32 * t + li;
       float uk[4], usum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1616,12 +1680,13 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
           const int c = 16 * h + 4 * v + s2;
-          float val = av[v][s2] * cj4[s2];
+          const float aval = avals[4 * v + s2];
+          float val = aval * cj4[s2];
 #pragma unroll
           for (int p = 0; p < 4; ++p)
             if (p < P) {
               val += uk[p] * fb4[p][s2];
-              usum[p] += fb4[p][s2] * av[v][s2];
+              usum[p] += fb4[p][s2] * aval;
             }
           if (BF3) {
             const __bf16 b0 = (__bf16)val;
@@ -1734,7 +1799,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
     }
     // row-per-lane view: lane (li, h) takes row li, columns 16h .. 16h+15 of the tile
     float kb[16];
-    float* kfblk = a.Kf ? a.Kf + ((((long)e * nT + tile) * nS + bx) << 10) + 4 * lane : nullptr;
+    float* kfblk = (a.Kf && !BF3) ? a.Kf + ((((long)e * nT + tile) * nS + bx) << 10) + 4 * lane : nullptr;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       V4 q = *reinterpret_cast<const V4*>(&Tw[w][li][16 * h + 4 * v]);
@@ -1745,6 +1810,8 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
       }
       if (kfblk) *reinterpret_cast<V4*>(kfblk + 256 * v) = q;   // fragment-major Kbar: one contiguous KB per store
     }
+    if (BF3 && a.Kf)   // ... as three bf16 planes for the bf16x3 Lbar contraction
+      sgp_store_frag3_row(reinterpret_cast<__bf16*>(a.Kf), (long)a.plane3 / a.M * 32 * nS, kb, e, nT, nS, tile, bx, lane);
     const int row = 32 * tile + li;
     float zr[D], zacc[D], lacc[D];
 #pragma unroll
@@ -1892,9 +1959,10 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
 // fragment sets (16 contiguous-kilobyte loads) for 64 MFMAs, halving the bytes per flop; the four waves of a
 // workgroup split a slab of strips and meet in LDS; S slabs give ~2 waves per SIMD.  On the diagonal blocks the
 // tile above the diagonal is skipped.
-template <int DUMMY>
+template <bool BF3>
 __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restrict__ Kf, const float* __restrict__ Af,
                                                             float* __restrict__ slabs, int M, int nS, int S, long E) {
+  typedef __bf16 B8 __attribute__((ext_vector_type(8)));
   typedef float V4 __attribute__((ext_vector_type(4)));
   typedef Mma<float> MM;
   __shared__ float red[4][32][33];   // one tile at a time (16.5 KB: several workgroups per CU)
@@ -1924,50 +1992,107 @@ __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restr
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  struct Frag {
-    V4 a0[4], a1[4], b0[4], b1[4];
-  };
-  auto load = [&](Frag& f, int sidx) {
-    const int sc = sidx < s1 ? sidx : (s1 > s0 ? s1 - 1 : s0);
-    const long off = (long)sc << 10;
+  if (!BF3) {
+    struct Frag {
+      V4 a0[4], a1[4], b0[4], b1[4];
+    };
+    auto load = [&](Frag& f, int sidx) {
+      const int sc = sidx < s1 ? sidx : (s1 > s0 ? s1 - 1 : s0);
+      const long off = (long)sc << 10;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      f.a0[v] = *reinterpret_cast<const V4*>(kbase + ti0 * tstride + off + 256 * v);
-      f.a1[v] = *reinterpret_cast<const V4*>(kbase + ti1 * tstride + off + 256 * v);
-      f.b0[v] = *reinterpret_cast<const V4*>(abase + tj0 * tstride + off + 256 * v);
-      f.b1[v] = *reinterpret_cast<const V4*>(abase + tj1 * tstride + off + 256 * v);
-    }
-  };
-  auto compute = [&](const Frag& f, int sidx) {
-    if (sidx >= s1) return;  // uniform
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        acc[0] = MM::mma(f.a0[v][s2], f.b0[v][s2], acc[0]);
-        acc[2] = MM::mma(f.a1[v][s2], f.b0[v][s2], acc[2]);
-        acc[3] = MM::mma(f.a1[v][s2], f.b1[v][s2], acc[3]);
+      for (int v = 0; v < 4; ++v) {
+        f.a0[v] = *reinterpret_cast<const V4*>(kbase + ti0 * tstride + off + 256 * v);
+        f.a1[v] = *reinterpret_cast<const V4*>(kbase + ti1 * tstride + off + 256 * v);
+        f.b0[v] = *reinterpret_cast<const V4*>(abase + tj0 * tstride + off + 256 * v);
+        f.b1[v] = *reinterpret_cast<const V4*>(abase + tj1 * tstride + off + 256 * v);
       }
-    if (!upper01) {   // (uniform; kept out of the MFMA stream above)
+    };
+    auto compute = [&](const Frag& f, int sidx) {
+      if (sidx >= s1) return;  // uniform
 #pragma unroll
       for (int v = 0; v < 4; ++v)
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) acc[1] = MM::mma(f.a0[v][s2], f.b1[v][s2], acc[1]);
-    }
-  };
-  if (s1 > s0) {
-    Frag fa, fb;
-    load(fa, s0);
+        for (int s2 = 0; s2 < 4; ++s2) {
+          acc[0] = MM::mma(f.a0[v][s2], f.b0[v][s2], acc[0]);
+          acc[2] = MM::mma(f.a1[v][s2], f.b0[v][s2], acc[2]);
+          acc[3] = MM::mma(f.a1[v][s2], f.b1[v][s2], acc[3]);
+        }
+      if (!upper01) {   // (uniform; kept out of the MFMA stream above)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) acc[1] = MM::mma(f.a0[v][s2], f.b1[v][s2], acc[1]);
+      }
+    };
+    if (s1 > s0) {
+      Frag fa, fb;
+      load(fa, s0);
 #pragma nounroll
-    for (int sidx = s0; sidx < s1; sidx += 2) {
-      load(fb, sidx + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(fa, sidx);
-      __builtin_amdgcn_sched_barrier(0);
-      load(fa, sidx + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(fb, sidx + 1);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int sidx = s0; sidx < s1; sidx += 2) {
+        load(fb, sidx + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(fa, sidx);
+        __builtin_amdgcn_sched_barrier(0);
+        load(fa, sidx + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(fb, sidx + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+    // bf16x3 operands: three bf16 planes per operand (written by the strip kernels), six cross products per k16-step
+    const long plane = (long)E * nT * tstride;
+    const __bf16* __restrict__ k3 = reinterpret_cast<const __bf16*>(Kf) + (long)e * nT * tstride + 8 * lane;
+    const __bf16* __restrict__ a3 = reinterpret_cast<const __bf16*>(Af) + (long)e * nT * tstride + 8 * lane;
+    struct Frag3 {
+      B8 a0[3][2], a1[3][2], b0[3][2], b1[3][2];
+    };
+    auto load = [&](Frag3& f, int sidx) {
+      const int sc = sidx < s1 ? sidx : (s1 > s0 ? s1 - 1 : s0);
+      const long off = (long)sc << 10;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          f.a0[p][q] = *reinterpret_cast<const B8*>(k3 + p * plane + ti0 * tstride + off + 512 * q);
+          f.a1[p][q] = *reinterpret_cast<const B8*>(k3 + p * plane + ti1 * tstride + off + 512 * q);
+          f.b0[p][q] = *reinterpret_cast<const B8*>(a3 + p * plane + tj0 * tstride + off + 512 * q);
+          f.b1[p][q] = *reinterpret_cast<const B8*>(a3 + p * plane + tj1 * tstride + off + 512 * q);
+        }
+    };
+    auto six = [&](const B8 (&x)[3][2], const B8 (&y)[3][2], int q, typename MM::Acc c) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2][q], y[0][q], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0][q], y[2][q], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1][q], y[1][q], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1][q], y[0][q], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0][q], y[1][q], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0][q], y[0][q], c, 0, 0, 0);
+      return c;
+    };
+    auto compute = [&](const Frag3& f, int sidx) {
+      if (sidx >= s1) return;  // uniform
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        acc[0] = six(f.a0, f.b0, q, acc[0]);
+        acc[2] = six(f.a1, f.b0, q, acc[2]);
+        acc[3] = six(f.a1, f.b1, q, acc[3]);
+        if (!upper01) acc[1] = six(f.a0, f.b1, q, acc[1]);
+      }
+    };
+    if (s1 > s0) {
+      Frag3 fa, fb;
+      load(fa, s0);
+#pragma nounroll
+      for (int sidx = s0; sidx < s1; sidx += 2) {
+        load(fb, sidx + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(fa, sidx);
+        __builtin_amdgcn_sched_barrier(0);
+        load(fa, sidx + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(fb, sidx + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   HB_LSTAMP(1);
@@ -2335,7 +2460,7 @@ static int sgp_bwd_strip_launch(SgpBwdArgs<float> a, long E, long nS, hipStream_
 static int sgp_bwd_strip_launch(SgpBwdArgs<double>, long, long, hipStream_t) { return -1; }  // fp32 only
 
 static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, float* Lbar, long E, long M, long nS,
-                                hipStream_t stream) {
+                                int prec, hipStream_t stream) {
   const int nT = (int)(M / 32);
   const long nB = (nT + 1) / 2, pairs = nB * (nB + 1) / 2;   // lower 64 x 64 blocks
   // ONE workgroup per CU (256 of them), i.e. one wave per SIMD: fp32 MFMAs occupy the SIMD's vector issue, so a
@@ -2343,6 +2468,7 @@ static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, 
   // MFMAs followed by 20k cycles for a 2k-cycle epilogue), and fewer slabs mean fewer partial tiles to write and fold
   // (S = 7 at M = 512: 70.7 us for the whole backward against 75.7 at S = 14)
   long S = 256 / (pairs * E);
+  if (S < 1) S = hb_cdiv(2048, pairs * E);   // more blocks than CUs (experts): ~8 workgroups per CU for balance
   if (S > nS / 8) S = nS / 8;
   if (S > 32) S = 32;     // the slabs live in the 32*E*M*M-element workspace
   if (S < 1) S = 1;
@@ -2351,14 +2477,17 @@ static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, 
     if (fs) S = atol(fs);
   }
   dim3 grid((unsigned)(pairs * S), (unsigned)E, 1);
-  hipLaunchKernelGGL(sgp_lbar_frag_kernel<0>, grid, dim3(256), 0, stream, Kf, Af, slabs, (int)M, (int)nS, (int)S, E);
+  if (prec == HB_PREC_BF16X3)
+    hipLaunchKernelGGL(sgp_lbar_frag_kernel<true>, grid, dim3(256), 0, stream, Kf, Af, slabs, (int)M, (int)nS, (int)S, E);
+  else
+    hipLaunchKernelGGL(sgp_lbar_frag_kernel<false>, grid, dim3(256), 0, stream, Kf, Af, slabs, (int)M, (int)nS, (int)S, E);
   HB_LAUNCH_CHECK();
   hipLaunchKernelGGL(sgp_lbar_finish_kernel<float>, dim3(hb_stream_grid(E * M * M, 256)), dim3(256), 0, stream, slabs, (int)S, E,
                      M, Lbar);
   HB_LAUNCH_CHECK();
   return 0;
 }
-static int sgp_lbar_frag_launch(const double*, const double*, double*, double*, long, long, long, hipStream_t) { return -1; }
+static int sgp_lbar_frag_launch(const double*, const double*, double*, double*, long, long, long, int, hipStream_t) { return -1; }
 
 template <typename T>
 static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W,
@@ -2405,7 +2534,7 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     hipLaunchKernelGGL(sgp_strip_finish_kernel<T>, dim3((unsigned)hb_cdiv(M, 64), (unsigned)(2 * d + P), (unsigned)E), dim3(256), 0,
                        stream, mmws, (int)nS, M, d, dl, P, zbar, ellbar, ubar);
     HB_LAUNCH_CHECK();
-    if (A_frag) return sgp_lbar_frag_launch(Kbar_frag, A_frag, mmws, Lbar, E, M, nS, stream);
+    if (A_frag) return sgp_lbar_frag_launch(Kbar_frag, A_frag, mmws, Lbar, E, M, nS, prec, stream);
     int rc2 = sgp_matmul(Kbar, A, Lbar, E, M, M, n, n, n, M, M * n, M * n, M * M, 0, 1, -1.0, HB_MM_TRIL_OUT, mmws, mmws_elems,
                          (void*)stream);
     return rc2;

@@ -1415,8 +1415,8 @@ def _sgp_emit(plan, node):
     if wfrag is not None and plan.dtype == plan.torch.float32 and H.sgp_strip_path(E, n, M, d, P, prec):
         users = list(plan._consumers.get(node.outputs[1], ()))
         if users and all(c.op == "sgp_grad" and not plan.needed(c.outputs[4]) for c in users):
-            a_frag = plan.scratch((H.sgp_frag_elems(E, n, M),))
-            plan._afrag[node.outputs[1]] = a_frag
+            a_frag = plan.scratch((H.sgp_frag_elems(E, n, M, prec),))
+            plan._afrag[node.outputs[1]] = (a_frag, prec)
             skip_a = node.outputs[1] not in plan.outputs
     plan.steps.append(lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag,
                                         prec=prec, a_frag=a_frag, skip_a=skip_a))
@@ -1448,7 +1448,9 @@ def _sgp_grad_emit(plan, node):
     wfrag, bf3 = plan._wfrag.get(_through_stop_gradient(node.inputs[3]), (None, False))
     bf3 = bf3 and not need_x and node.inputs[0].shape[-1] <= 4 and node.inputs[4].shape[-2] <= 4
     prec = H.PREC_BF16X3 if bf3 else H.PREC_NATIVE
-    a_frag = plan._afrag.get(node.inputs[6])          # fragment-major A from the forward op (see _sgp_emit)
+    a_frag, fprec = plan._afrag.get(node.inputs[6], (None, None))   # fragment-major A from the forward op (see _sgp_emit)
+    if a_frag is not None:
+        prec = fprec          # the layout (fp32 image / bf16x3 planes) was fixed by the forward op
     kbar_frag = plan.scratch((a_frag.numel(),)) if a_frag is not None else None
     Kbar = plan.scratch(A.shape) if a_frag is None else None
     plan.steps.append(lambda: H.sgp_bwd(x, z, ell, W, u, eps, A, v, gf, mode=mode, need_xbar=need_x,

@@ -624,9 +624,11 @@ def sgp_strip_path(E, n, M, d, P, prec=PREC_NATIVE):
     return bool(_lib.lib().raw("hb_sgp_strip_path")(E, n, M, d, P, int(prec)))
 
 
-def sgp_frag_elems(E, n, M):
-    """Elements of a fragment-major [E, M, n] operand (columns padded to whole strips of 32)."""
-    return E * M * 32 * ((n + 31) // 32)
+def sgp_frag_elems(E, n, M, prec=PREC_NATIVE):
+    """fp32 elements of a fragment-major [E, M, n] operand buffer (columns padded to whole strips of 32); the bf16x3
+    form holds three bf16 planes instead of one fp32 image: 1.5 times the bytes."""
+    base = E * M * 32 * ((n + 31) // 32)
+    return base * 3 // 2 if prec == PREC_BF16X3 else base
 
 
 def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None, wfrag=None, prec=PREC_NATIVE,

@@ -698,12 +698,19 @@ def test_sgp_backward_column_strip_form(H, E, M, n, d, P, mode):
     want = Ah[:, 32 * t_ + (l_ & 31), 32 * s_ + 16 * (l_ >> 5) + 4 * v_ + q_]
     assert np.array_equal(host(a_frag).reshape(E, nT, nS, 4, 64, 4), want), "fragment-major A layout"
     frg = H.sgp_bwd(*(args + (dev(sq(eps), dt), None, v, dev(sq(fbar), dt))), mode=m, wfrag=frag, a_frag=a_frag)
+    # the same exchange as bf16x3 planes: forward, Kbar, row gradients AND the Lbar contraction on bf16x3 operands
+    a_frag3 = torch.zeros(H.sgp_frag_elems(E, n, M, H.PREC_BF16X3), dtype=dt, device="cuda")
+    f3, _, v3, _ = H.sgp_fwd(*args, eps_in=dev(sq(eps), dt), mode=m, wfrag=frag, a_frag=a_frag3, skip_a=True,
+                             prec=H.PREC_BF16X3)
+    assert np.abs(host(f3) - host(f)).max() < 2e-3 and np.abs(host(v3) - host(v)).max() < 2e-3
+    frg3 = H.sgp_bwd(*(args + (dev(sq(eps), dt), None, v3, dev(sq(fbar), dt))), mode=m, wfrag=frag, a_frag=a_frag3,
+                     prec=H.PREC_BF16X3)
     names = ("Lbar", "ubar", "zbar", "ellbar")
     for i, nm in enumerate(names):
         r = ref[i].reshape(host(old[i]).shape)
         scale = max(1.0, np.abs(r).max())
         e_old = np.abs(host(old[i]) - r).max() / scale
-        for tag, got in (("strip", new), ("bf16x3", bf3), ("fragment-major", frg)):
+        for tag, got in (("strip", new), ("bf16x3", bf3), ("fragment-major", frg), ("fragment-major bf16x3", frg3)):
             e_new = np.abs(host(got[i]) - r).max() / scale
             assert e_new <= 3.0 * e_old + 2e-5, (nm, tag, e_old, e_new)
 

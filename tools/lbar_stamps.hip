@@ -31,9 +31,9 @@ int main() {
   (void)hipMemcpy(Kf, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(Af, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) sgp_lbar_frag_launch(Kf, Af, slabs, Lbar, 1, M, nS, 0);
+  for (int i = 0; i < 5; ++i) sgp_lbar_frag_launch(Kf, Af, slabs, Lbar, 1, M, nS, 0, 0);
   (void)hipEventRecord(e0);
-  for (int i = 0; i < 50; ++i) sgp_lbar_frag_launch(Kf, Af, slabs, Lbar, 1, M, nS, 0);
+  for (int i = 0; i < 50; ++i) sgp_lbar_frag_launch(Kf, Af, slabs, Lbar, 1, M, nS, 0, 0);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   printf("lbar (kernel + finish): %.2f us per call\n", ms * 1e3 / 50);
