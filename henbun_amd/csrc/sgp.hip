@@ -1961,14 +1961,24 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
 // tile above the diagonal is skipped.
 template <bool BF3>
 __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restrict__ Kf, const float* __restrict__ Af,
-                                                            float* __restrict__ slabs, int M, int nS, int S, long E) {
+                                                            float* __restrict__ slabs, int M, int nS, int S, long E,
+                                                            int pairs) {
   typedef __bf16 B8 __attribute__((ext_vector_type(8)));
   typedef float V4 __attribute__((ext_vector_type(4)));
   typedef Mma<float> MM;
   __shared__ float red[4][32][33];   // one tile at a time (16.5 KB: several workgroups per CU)
   const int nT = M / 32, nB = (nT + 1) / 2;             // 64-row blocks (the last one may hold a single tile)
-  const int slab = blockIdx.x % S, pair = blockIdx.x / S;
-  const long e = blockIdx.y;
+  // XCD-aware unit order: workgroup w runs on XCD w % 8 (round-robin dispatch), each XCD has its own L2, and the
+  // units that share operand strips are the `pairs` blocks of one (expert, slab).  The units are therefore laid out
+  // (expert, slab)-major and XCD x takes the CONTIGUOUS range [x U/8, (x+1) U/8): an XCD works inside one or two slabs
+  // and re-reads of a strip hit its L2 (with slab = w % S every XCD streamed every slab: 151 MB out of L2 per launch
+  // at cfg 2 for 33.5 MB of operands, profiles/r02_pmc_cfg2_kernels.txt).
+  const int U = gridDim.x, xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+  const int uq = U >> 3, ur = U & 7;
+  const int unit = xcd * uq + (xcd < ur ? xcd : ur) + kx;
+  const int group = unit / pairs, pair = unit - group * pairs;
+  const int slab = group % S;
+  const long e = group / S;
   int bi = (int)((sqrtf(8.f * (float)pair + 1.f) - 1.f) * 0.5f);
   while (bi * (bi + 1) / 2 > pair) --bi;
   while ((bi + 1) * (bi + 2) / 2 <= pair) ++bi;
@@ -2476,11 +2486,13 @@ static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, 
     static const char* fs = getenv("HB_LBAR_FORCE_S");  // diagnostic
     if (fs) S = atol(fs);
   }
-  dim3 grid((unsigned)(pairs * S), (unsigned)E, 1);
+  dim3 grid((unsigned)(pairs * S * E), 1, 1);
   if (prec == HB_PREC_BF16X3)
-    hipLaunchKernelGGL(sgp_lbar_frag_kernel<true>, grid, dim3(256), 0, stream, Kf, Af, slabs, (int)M, (int)nS, (int)S, E);
+    hipLaunchKernelGGL(sgp_lbar_frag_kernel<true>, grid, dim3(256), 0, stream, Kf, Af, slabs, (int)M, (int)nS, (int)S, E,
+                       (int)pairs);
   else
-    hipLaunchKernelGGL(sgp_lbar_frag_kernel<false>, grid, dim3(256), 0, stream, Kf, Af, slabs, (int)M, (int)nS, (int)S, E);
+    hipLaunchKernelGGL(sgp_lbar_frag_kernel<false>, grid, dim3(256), 0, stream, Kf, Af, slabs, (int)M, (int)nS, (int)S, E,
+                       (int)pairs);
   HB_LAUNCH_CHECK();
   hipLaunchKernelGGL(sgp_lbar_finish_kernel<float>, dim3(hb_stream_grid(E * M * M, 256)), dim3(256), 0, stream, slabs, (int)S, E,
                      M, Lbar);
