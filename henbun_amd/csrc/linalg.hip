@@ -1231,79 +1231,66 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
         for (int r = 0; r < 16; ++r) Cs[w * 32 + MM::acc_row(lane, r)][sj * 32 + li] = sj == 0 ? acc[0][r] : acc[1][r];
         // rows 8kb..8kb+7 live in wave kb/4, accumulator rows 8(kb%4) + 4h + (0..3) of its tile
         if (w == sj) {
+          static_assert(Mma<float>::NACC == 16, "32x32 accumulator layout");
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * (kb & 3) + rr;
-            static_assert(Mma<float>::NACC == 16, "32x32 accumulator layout");
-            Dg[4 * h + rr][li & 7] = sj == 0 ? acc[0][r] : acc[1][r];
-          }
+          for (int rr = 0; rr < 4; ++rr)
+            Dg[4 * h + rr][li & 7] = sj == 0 ? acc[0][4 * (kb & 3) + rr] : acc[1][4 * (kb & 3) + rr];
         }
       }
     }
     __syncthreads();
-    if (tid < C64_ROWS) {
-      // potrf8 on Cs[8kb.., 8kb..] (every lane, in registers, by columns in register pairs) + this thread's row solve
-      typedef T T2 __attribute__((ext_vector_type(2)));
-      T2 col[8][4];
-      T pinv[8];
+    if (w < 3) {
+      // The 8-column elimination step, one stacked row per LANE: a lane holds the 8 entries x[0..7] of its row; the
+      // rows of the 8x8 diagonal sub-block sit in lanes dl0 .. dl0+7 of the SAME wave, so the pivot and the
+      // multipliers L[c2][c] (= diagonal row c2's finished x[c]) reach every lane through v_readlane (uniform
+      // values in SGPRs) -- the diagonal rows' own solves ARE the factorisation of the sub-block.  ~80 VALU
+      // instructions per step; the previous form (potrf8 replicated in every lane's registers, then the row solve:
+      // ~175 instructions) was issue bound at ~1300 of the 2200 cycles of a step.
+      //   wave 0: lane l = stacked row l (the diagonal rows are lanes 8kb .. 8kb+7)
+      //   wave 1: lanes 0..55 = rows 64..119, lanes 56..63 = copies of the diagonal rows (from the snapshot Dg)
+      //   wave 2: lanes 0..7 = rows 120..127, lanes 56..63 = copies of the diagonal rows, the rest idle
+      const int dl0 = (w == 0) ? 8 * kb : 56;
+      const bool dup = (w != 0) && lane >= 56;
+      const bool owner = (w == 0) || (w == 1 && lane < 56) || (w == 2 && lane < 8);
+      const int row = (w == 0) ? lane : (w == 1 ? 64 + lane : 120 + (lane & 7));
+      T x[8];
       {
-        T p[8][8];
+        const T* src = dup ? &Dg[lane - 56][0] : &Cs[row][8 * kb];
+        const VT v0 = *reinterpret_cast<const VT*>(src), v1 = *reinterpret_cast<const VT*>(src + 4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int q = 0; q < 8; q += 4) {
-            const VT v = *reinterpret_cast<const VT*>(&Dg[i][q]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) p[i][q + e] = v[e];
-          }
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-          for (int hh = 0; hh < 4; ++hh) {
-            col[c][hh][0] = (2 * hh >= c) ? p[2 * hh][c] : p[c][2 * hh];
-            col[c][hh][1] = (2 * hh + 1 >= c) ? p[2 * hh + 1][c] : p[c][2 * hh + 1];
-          }
+        for (int e = 0; e < 4; ++e) x[e] = v0[e], x[4 + e] = v1[e];
       }
+      auto bcast = [&](T v, int l) { return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const T d = col[c][c / 2][c % 2];
-        if (fail == 0 && !(d > T(0))) fail = 8 * kb + c + 1;
+        const T d = bcast(x[c], dl0 + c);
         T lcc, pi;
         pivot_sqrt(d, lcc, pi);
-        pinv[c] = pi;
-        const T2 pi2 = {pi, pi};
+        (void)lcc;
+        x[c] *= pi;
 #pragma unroll
-        for (int hh = c / 2; hh < 4; ++hh) col[c][hh] *= pi2;
-        col[c][c / 2][c % 2] = lcc;
+        for (int c2 = c + 1; c2 < 8; ++c2) x[c2] = __builtin_fmaf(-x[c], bcast(x[c], dl0 + c2), x[c2]);
+      }
+      // A pivot d <= 0 (or NaN) makes l_cc = d * rsq(d) a NaN, and a NaN column poisons every later pivot: the last
+      // diagonal entry is NaN exactly when some pivot of this step (or an earlier one) failed.  One compare per step;
+      // the failing column is then the first NaN on the diagonal (LAPACK's info).
+      if (w == 0) {
+        const T l77 = bcast(x[7], dl0 + 7);
+        if (fail == 0 && !(l77 == l77)) {
+          fail = 8 * kb + 8;
 #pragma unroll
-        for (int c2 = c + 1; c2 < 8; ++c2) {
-          const T sv = col[c][c2 / 2][c2 % 2];
-          const T2 ns = {-sv, -sv};
-#pragma unroll
-          for (int hh = c2 / 2; hh < 4; ++hh) col[c2][hh] = __builtin_elementwise_fma(col[c][hh], ns, col[c2][hh]);
+          for (int c = 6; c >= 0; --c) {
+            const T lc = bcast(x[c], dl0 + c);
+            if (!(lc == lc)) fail = 8 * kb + c + 1;
+          }
         }
       }
-      T2 xv[4];
+      if (owner) {
+        VT v0, v1;
 #pragma unroll
-      for (int q = 0; q < 8; q += 4) {
-        const VT v = *reinterpret_cast<const VT*>(&Cs[tid][8 * kb + q]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xv[(q + e) / 2][(q + e) % 2] = v[e];
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const T xc = xv[c / 2][c % 2] * pinv[c];
-        const T2 nx = {-xc, -xc};
-#pragma unroll
-        for (int hh = c / 2; hh < 4; ++hh) xv[hh] = __builtin_elementwise_fma(col[c][hh], nx, xv[hh]);
-        xv[c / 2][c % 2] = xc;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; q += 4) {
-        VT v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = xv[(q + e) / 2][(q + e) % 2];
-        *reinterpret_cast<VT*>(&Cs[tid][8 * kb + q]) = v;
+        for (int e = 0; e < 4; ++e) v0[e] = x[e], v1[e] = x[4 + e];
+        *reinterpret_cast<VT*>(&Cs[row][8 * kb]) = v0;
+        *reinterpret_cast<VT*>(&Cs[row][8 * kb + 4]) = v1;
       }
     }
     __syncthreads();
