@@ -37,6 +37,9 @@ _SIGS = {
     "hb_sgp_strip_path": [L, L, L, L, L, I],
     "hb_ewise_prog_image_bytes": [],
     "hb_ewise_prog_build": [I, P, P, I, P, P, I, P, P, P, I, P, P, P, P],
+    "hb_ewise_jit_available": [],
+    "hb_ewise_jit_run": [P, P],
+    "hb_ewise_jit_destroy": [P],
     "hb_comm_available": [],
     "hb_comm_unique_id": [P],
     "hb_comm_init": [P, I, I, P],
@@ -49,6 +52,7 @@ _TYPED = {
     "hb_ewise": [I, I, P, P, I, P, I, P, P, P],
     "hb_ewise_prog": [I, P, P, I, P, P, I, P, P, P, I, P, P],
     "hb_ewise_prog_run": [P, L, I, P],
+    "hb_ewise_jit_build": [I, P, P, I, P, P, I, P, P, P, I, P, P, P, P, P, L],
     "hb_gauss_ll": [P, P, P, P, L, P, P, P, P, P, L, P],
     "hb_reduce": [I, P, P, L, L, L, P, L, P],
     "hb_copy_nd": [P, P, P, P, I, P, P],

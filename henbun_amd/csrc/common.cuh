@@ -96,12 +96,7 @@ static inline hipError_t hb_copy_async(void* dst, const void* src, size_t bytes,
 // ---------------------------------------------------------------------------
 // wave / block reductions (sum, max).  Deterministic (no atomics).
 // ---------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+#include "ew_math.cuh"  // wave_sum, block_sum, hb_exp ... hb_sigmoid
 
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
@@ -111,21 +106,6 @@ __device__ __forceinline__ T wave_max(T v) {
     v = o > v ? o : v;
   }
   return v;
-}
-
-// Block-wide sum for blockDim.x <= 1024 (multiple of 64).  `smem` needs
-// 16 elements.  Result valid in every thread.
-template <typename T>
-__device__ __forceinline__ T block_sum(T v, T* smem) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nw = (blockDim.x + 63) >> 6;
-  v = wave_sum(v);
-  __syncthreads();  // protect smem reuse across consecutive calls
-  if (lane == 0) smem[w] = v;
-  __syncthreads();
-  T r = (lane < nw) ? smem[lane] : T(0);
-  r = wave_sum(r);
-  return r;
 }
 
 template <typename T>
@@ -175,58 +155,6 @@ struct Mma<double> {
   }
   __device__ static __forceinline__ int acc_col(int lane) { return lane & 15; }
 };
-
-// ---------------------------------------------------------------------------
-// math helpers that pick the right precision overload
-// ---------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ T hb_exp(T x);
-template <> __device__ __forceinline__ float hb_exp<float>(float x) { return expf(x); }
-template <> __device__ __forceinline__ double hb_exp<double>(double x) { return exp(x); }
-template <typename T> __device__ __forceinline__ T hb_log(T x);
-template <> __device__ __forceinline__ float hb_log<float>(float x) { return logf(x); }
-template <> __device__ __forceinline__ double hb_log<double>(double x) { return log(x); }
-template <typename T> __device__ __forceinline__ T hb_sqrt(T x);
-template <> __device__ __forceinline__ float hb_sqrt<float>(float x) { return sqrtf(x); }
-template <> __device__ __forceinline__ double hb_sqrt<double>(double x) { return sqrt(x); }
-template <typename T> __device__ __forceinline__ T hb_abs(T x) { return x < T(0) ? -x : x; }
-template <typename T> __device__ __forceinline__ T hb_sign(T x) {
-  return x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0));
-}
-template <typename T> __device__ __forceinline__ T hb_log1p(T x);
-template <> __device__ __forceinline__ float hb_log1p<float>(float x) { return log1pf(x); }
-template <> __device__ __forceinline__ double hb_log1p<double>(double x) { return log1p(x); }
-template <typename T> __device__ __forceinline__ T hb_tanh(T x);
-template <> __device__ __forceinline__ float hb_tanh<float>(float x) { return tanhf(x); }
-template <> __device__ __forceinline__ double hb_tanh<double>(double x) { return tanh(x); }
-template <typename T> __device__ __forceinline__ T hb_lgamma(T x);
-template <> __device__ __forceinline__ float hb_lgamma<float>(float x) { return lgammaf(x); }
-template <> __device__ __forceinline__ double hb_lgamma<double>(double x) { return lgamma(x); }
-template <typename T> __device__ __forceinline__ T hb_pow(T x, T y);
-template <> __device__ __forceinline__ float hb_pow<float>(float x, float y) { return powf(x, y); }
-template <> __device__ __forceinline__ double hb_pow<double>(double x, double y) { return pow(x, y); }
-
-// numerically stable softplus log(1+e^x) (tf.nn.softplus)
-template <typename T>
-__device__ __forceinline__ T hb_softplus(T x) {
-  return (x > T(0) ? x : T(0)) + hb_log1p(hb_exp(-hb_abs(x)));
-}
-template <typename T>
-__device__ __forceinline__ T hb_sigmoid(T x) {
-  if (x >= T(0)) {
-    return T(1) / (T(1) + hb_exp(-x));
-  } else {
-    T e = hb_exp(x);
-    return e / (T(1) + e);
-  }
-}
-// fp32: branch-free on v_exp_f32 / v_rcp_f32 (1 ulp each) -- the IEEE exp + divide sequences are ~40 instructions
-// per element and dominated the epilogue of the bias+sigmoid GEMMs
-template <>
-__device__ __forceinline__ float hb_sigmoid<float>(float x) {
-  const float e = __expf(-fabsf(x));           // in (0, 1]: no overflow
-  const float r = __builtin_amdgcn_rcpf(1.0f + e);
-  return x >= 0.0f ? r : e * r;
-}
 
 // ---------------------------------------------------------------------------
 // xoroshiro128+ per-lane generator.  The state array holds two uint64 per

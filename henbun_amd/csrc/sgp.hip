@@ -2127,11 +2127,11 @@ __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restr
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) sgp_lbar_finish_kernel(const T* __restrict__ slabs, int S, long E, long M,
-                                                              T* __restrict__ Lbar) {
+__device__ __forceinline__ void sgp_lbar_finish_body(const T* __restrict__ slabs, int S, long E, long M, T* __restrict__ Lbar,
+                                                     long vblock, long nvblocks) {
   const long total = E * M * M;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+  const long stride = nvblocks * blockDim.x;
+  for (long t = vblock * blockDim.x + threadIdx.x; t < total; t += stride) {
     const long rem = t % (M * M);
     const long r = rem / M, c = rem - r * M;
     T acc = T(0);
@@ -2149,6 +2149,11 @@ __global__ void __launch_bounds__(256) sgp_lbar_finish_kernel(const T* __restric
     Lbar[t] = acc;
   }
 }
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_lbar_finish_kernel(const T* __restrict__ slabs, int S, long E, long M,
+                                                              T* __restrict__ Lbar) {
+  sgp_lbar_finish_body<T>(slabs, S, E, M, Lbar, blockIdx.x, gridDim.x);
+}
 
 // Fold the strips' partial sums (sgp_kbar_strip_kernel):  zbar[e, m, q] = sum_s part[e, s, q, m];
 // ubar[e, p, m] = sum_s part[e, s, 2D + p, m];  ellbar[e, q | 0] = sum_s lstrip[e, s, q] (already summed over the rows
@@ -2156,18 +2161,14 @@ __global__ void __launch_bounds__(256) sgp_lbar_finish_kernel(const T* __restric
 // 16 loads in flight per thread; the extra block row y = 2D + P - D... (see launch) sums the ell partials.  Fixed
 // summation order: deterministic.
 template <typename T>
-__global__ void __launch_bounds__(256) sgp_strip_finish_kernel(const T* __restrict__ part, int nS, long M, long d, long dl,
-                                                               long P, T* __restrict__ zbar, T* __restrict__ ellbar,
-                                                               T* __restrict__ ubar) {
-  __shared__ T red[4][64];
-  __shared__ T smem[16];
-  const long e = blockIdx.z;
+__device__ __forceinline__ void sgp_strip_finish_body(const T* __restrict__ part, int nS, long M, long d, long dl, long P,
+                                                      T* __restrict__ zbar, T* __restrict__ ellbar, T* __restrict__ ubar,
+                                                      int bx, int q, long e, T (*red)[64], T* smem) {
   const int nq = (int)(2 * d + P);
   part += e * nS * (long)nq * M;
-  const int q = blockIdx.y;
   if (q >= (int)d && q < 2 * (int)d) {
     // ell: per-strip totals were left in row 0 of this quantity's rows ([s][D + q][0]) by the strip kernel
-    if (blockIdx.x != 0) return;
+    if (bx != 0) return;
     T acc = T(0);
     for (int s = threadIdx.x; s < nS; s += 256) acc += part[((long)s * nq + q) * M];
     acc = block_sum(acc, smem);
@@ -2188,7 +2189,7 @@ __global__ void __launch_bounds__(256) sgp_strip_finish_kernel(const T* __restri
     return;
   }
   const int ml = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const long m = (long)blockIdx.x * 64 + ml;
+  const long m = (long)bx * 64 + ml;
   T acc = T(0);
   if (m < M) {
     const T* base = part + (long)q * M + m;
@@ -2211,6 +2212,34 @@ __global__ void __launch_bounds__(256) sgp_strip_finish_kernel(const T* __restri
       zbar[(e * M + m) * d + q] = tot;
     else
       ubar[(e * P + (q - 2 * d)) * M + m] = tot;
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_strip_finish_kernel(const T* __restrict__ part, int nS, long M, long d, long dl,
+                                                               long P, T* __restrict__ zbar, T* __restrict__ ellbar,
+                                                               T* __restrict__ ubar) {
+  __shared__ T red[4][64];
+  __shared__ T smem[16];
+  sgp_strip_finish_body<T>(part, nS, M, d, dl, P, zbar, ellbar, ubar, (int)blockIdx.x, (int)blockIdx.y, (long)blockIdx.z, red, smem);
+}
+// Both finishing passes of the fragment-major backward in ONE launch (they are independent: one folds the strip
+// kernel's partial row gradients, the other the Lbar slabs): blocks [0, nb_strip) take the first job (flattened
+// (64-row block, quantity, expert) index), the rest the second.
+template <typename T>
+__global__ void __launch_bounds__(256) sgp_bwd_finish_kernel(const T* __restrict__ part, int nS, long M, long d, long dl,
+                                                             long P, T* __restrict__ zbar, T* __restrict__ ellbar,
+                                                             T* __restrict__ ubar, int nb_strip, int nbx,
+                                                             const T* __restrict__ slabs, int S, long E,
+                                                             T* __restrict__ Lbar) {
+  __shared__ T red[4][64];
+  __shared__ T smem[16];
+  if ((int)blockIdx.x < nb_strip) {
+    const int nq = (int)(2 * d + P);
+    const int vb = blockIdx.x;
+    sgp_strip_finish_body<T>(part, nS, M, d, dl, P, zbar, ellbar, ubar, vb % nbx, (vb / nbx) % nq, (long)(vb / (nbx * nq)), red,
+                             smem);
+  } else {
+    sgp_lbar_finish_body<T>(slabs, S, E, M, Lbar, (long)blockIdx.x - nb_strip, (long)gridDim.x - nb_strip);
   }
 }
 
@@ -2469,8 +2498,9 @@ static int sgp_bwd_strip_launch(SgpBwdArgs<float> a, long E, long nS, hipStream_
 }
 static int sgp_bwd_strip_launch(SgpBwdArgs<double>, long, long, hipStream_t) { return -1; }  // fp32 only
 
-static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, float* Lbar, long E, long M, long nS,
-                                int prec, hipStream_t stream) {
+// Launches the contraction only; *S_out slabs of E*M*M partial tiles are left at `slabs` for the finish pass.
+static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, long slab_cap, long E, long M, long nS,
+                                int prec, int* S_out, hipStream_t stream) {
   const int nT = (int)(M / 32);
   const long nB = (nT + 1) / 2, pairs = nB * (nB + 1) / 2;   // lower 64 x 64 blocks
   // ONE workgroup per CU (256 of them), i.e. one wave per SIMD: fp32 MFMAs occupy the SIMD's vector issue, so a
@@ -2480,7 +2510,7 @@ static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, 
   long S = 256 / (pairs * E);
   if (S < 1) S = hb_cdiv(2048, pairs * E);   // more blocks than CUs (experts): ~8 workgroups per CU for balance
   if (S > nS / 8) S = nS / 8;
-  if (S > 32) S = 32;     // the slabs live in the 32*E*M*M-element workspace
+  if (S > slab_cap) S = slab_cap;   // the slabs live in what is left of the 32*E*M*M-element workspace
   if (S < 1) S = 1;
   {
     static const char* fs = getenv("HB_LBAR_FORCE_S");  // diagnostic
@@ -2494,12 +2524,10 @@ static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, 
     hipLaunchKernelGGL(sgp_lbar_frag_kernel<false>, grid, dim3(256), 0, stream, Kf, Af, slabs, (int)M, (int)nS, (int)S, E,
                        (int)pairs);
   HB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sgp_lbar_finish_kernel<float>, dim3(hb_stream_grid(E * M * M, 256)), dim3(256), 0, stream, slabs, (int)S, E,
-                     M, Lbar);
-  HB_LAUNCH_CHECK();
+  *S_out = (int)S;
   return 0;
 }
-static int sgp_lbar_frag_launch(const double*, const double*, double*, double*, long, long, long, int, hipStream_t) { return -1; }
+static int sgp_lbar_frag_launch(const double*, const double*, double*, long, long, long, long, int, int*, hipStream_t) { return -1; }
 
 template <typename T>
 static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W,
@@ -2543,10 +2571,23 @@ static int sgp_bwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     if (A_frag) a.Kbar = nullptr;   // Kbar only feeds the Lbar contraction: the fragment-major copy is enough
     int rc = sgp_bwd_strip_launch(a, E, nS, stream);
     if (rc) return rc;
+    if (A_frag) {
+      // strip partials and Lbar slabs side by side in the workspace; ONE finish launch folds both
+      const long npart = ((nS * (2 * d + P) * M * E + 63) / 64) * 64;
+      const long slab_cap = (mmws_elems - npart) / (E * M * M);
+      HB_REQUIRE(slab_cap >= 1, "hb_sgp_bwd: workspace too small for the Lbar slabs");
+      int S = 0;
+      rc = sgp_lbar_frag_launch(Kbar_frag, A_frag, mmws + npart, slab_cap > 32 ? 32 : slab_cap, E, M, nS, prec, &S, stream);
+      if (rc) return rc;
+      const int nbx = (int)hb_cdiv(M, 64), nb_strip = nbx * (int)(2 * d + P) * (int)E;
+      hipLaunchKernelGGL(sgp_bwd_finish_kernel<T>, dim3((unsigned)(nb_strip + hb_stream_grid(E * M * M, 256))), dim3(256), 0, stream,
+                         mmws, (int)nS, M, d, dl, P, zbar, ellbar, ubar, nb_strip, nbx, mmws + npart, S, E, Lbar);
+      HB_LAUNCH_CHECK();
+      return 0;
+    }
     hipLaunchKernelGGL(sgp_strip_finish_kernel<T>, dim3((unsigned)hb_cdiv(M, 64), (unsigned)(2 * d + P), (unsigned)E), dim3(256), 0,
                        stream, mmws, (int)nS, M, d, dl, P, zbar, ellbar, ubar);
     HB_LAUNCH_CHECK();
-    if (A_frag) return sgp_lbar_frag_launch(Kbar_frag, A_frag, mmws, Lbar, E, M, nS, prec, stream);
     int rc2 = sgp_matmul(Kbar, A, Lbar, E, M, M, n, n, n, M, M * n, M * n, M * M, 0, 1, -1.0, HB_MM_TRIL_OUT, mmws, mmws_elems,
                          (void*)stream);
     return rc2;

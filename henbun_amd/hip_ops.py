@@ -161,6 +161,19 @@ def ewise(op, inputs, nout=1, params=None, out=None):
     return outs[0] if nout == 1 else tuple(outs)
 
 
+EWISE_JIT_SOURCE_BYTES = 8192
+
+
+def ewise_jit_enabled():
+    """Fused elementwise programs are compiled at plan-build time (hiprtc) unless `settings.runtime.ewise = interpret`
+    or hiprtc cannot be loaded in this process; the interpreted form is the same program run by ew_prog_image_kernel."""
+    from ._settings import settings
+
+    if getattr(settings.runtime, "ewise", "jit") != "jit":
+        return False
+    return bool(_lib.lib().raw("hb_ewise_jit_available")())
+
+
 class EwiseProgram:
     """A prepared hb_ewise_prog launch (all host-side argument arrays built once)."""
 
@@ -183,9 +196,24 @@ class EwiseProgram:
         self.ostr = _larr(flat_os) if flat_os else _larr([0])
         self.shape = _larr(shape) if shape else _larr([1])
         self._keep = (inputs, outputs)
-        # the launch descriptor is built and uploaded once; a (replayed) launch carries one pointer and the kernel
-        # pulls the descriptor into LDS in one parallel load
         lib = _lib.lib()
+        self.handle = None
+        self.source = None
+        if ewise_jit_enabled():
+            # compiled form: the program becomes a gfx950 kernel of its own at plan-build time (hb_ewise_jit_*)
+            n_out, red_out = c_long(0), c_int(0)
+            handle = c_void_p(None)
+            src = ctypes.create_string_buffer(EWISE_JIT_SOURCE_BYTES)
+            lib.call("hb_ewise_jit_build" + self.suf, self.ninstr, self.code, self.params, self.nin, self.inputs, self.istr,
+                     self.nout, self.outputs, self.out_regs, self.ostr, self.nd, self.shape, ctypes.byref(handle),
+                     ctypes.byref(n_out), ctypes.byref(red_out), src, EWISE_JIT_SOURCE_BYTES)
+            self.n, self.reduces = int(n_out.value), int(red_out.value)
+            self.handle = handle
+            self.source = src.value.decode()
+            self.image = None
+            return
+        # interpreted form: the launch descriptor is built and uploaded once; a (replayed) launch carries one pointer
+        # and the kernel pulls the descriptor into LDS in one parallel load
         nbytes = int(lib.raw("hb_ewise_prog_image_bytes")())
         host = ctypes.create_string_buffer(nbytes)
         n_out, red_out = c_long(0), c_int(0)
@@ -197,7 +225,18 @@ class EwiseProgram:
         torch.cuda.synchronize()
 
     def launch(self):
-        _lib.lib().call("hb_ewise_prog_run" + self.suf, _p(self.image), self.n, self.reduces, stream())
+        if self.image is None:
+            _lib.lib().call("hb_ewise_jit_run", self.handle, stream())
+        else:
+            _lib.lib().call("hb_ewise_prog_run" + self.suf, _p(self.image), self.n, self.reduces, stream())
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().raw("hb_ewise_jit_destroy")(h)
+            except Exception:
+                pass
 
 
 def gauss_ll(x, f, scale, var, out=None):

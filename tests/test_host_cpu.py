@@ -46,6 +46,44 @@ def test_bad_arguments_are_reported_not_crashed():
         lib.call("hb_rng_randint", None, 0, None, 1, 0, 0, None)
 
 
+def test_elementwise_program_source_generates_and_compiles_for_gfx950():
+    """hb_ewise_jit_build in its dry-run form (no handle requested: no device needed): the generated kernel text for a
+    program with broadcast inputs, a 4-input gradient op and sum-reduced outputs compiles with hiprtc for gfx950."""
+    import ctypes
+    from ctypes import c_double, c_int, c_long, c_void_p
+
+    from henbun_amd import _lib, hip_ops as H
+
+    L = _lib.lib()
+    if not L.raw("hb_ewise_jit_available")():
+        pytest.skip("hiprtc cannot be loaded in this process")
+    E = H.EW
+    code = [[E["SOFTPLUS"], 2, 0, 0, 0], [E["AFFINE"], 3, 2, 0, 0], [E["MUL"], 4, 3, 1, 0], [E["GAUSS_LOGPDF_GRAD"], 5, 0, 1, 4]]
+    params = [[0, 0], [2.0, 1e-6], [0, 0], [3.0, 0]]
+    cd = (c_int * 20)(*[v for ins in code for v in ins])
+    pr = (c_double * 8)(*[float(v) for p in params for v in p])
+    ins = (c_void_p * 2)(0x1000, 0x2000)
+    outs = (c_void_p * 3)(0x3000, 0x4000, 0x5000)
+    istr = (c_long * 4)(0, 0, 1, 0)
+    ostr = (c_long * 6)(1, 0, 0, 0, 0, 0)
+    oregs = (c_int * 3)(4, 5 + H.EW_PROG_SUM, 7 + H.EW_PROG_SUM)
+    shape = (c_long * 2)(8192, 1)
+    for suf in ("_f32", "_f64"):
+        n, red = c_long(0), c_int(0)
+        src = ctypes.create_string_buffer(8192)
+        L.call("hb_ewise_jit_build" + suf, 4, cd, pr, 2, ins, istr, 3, outs, oregs, ostr, 2, shape, None, ctypes.byref(n),
+               ctypes.byref(red), src, 8192)
+        text = src.value.decode()
+        assert n.value == 8192 and red.value == 1
+        assert "typedef %s T;" % ("float" if suf == "_f32" else "double") in text
+        assert "ew_apply<T>(%d, r0, r1, r4, r3" % E["GAUSS_LOGPDF_GRAD"] in text and "block_sum(racc1, smem)" in text
+    # a bad program is reported, not compiled
+    oregs_bad = (c_int * 3)(39, 5, 7)
+    with pytest.raises(_lib.HipBackendError):
+        L.call("hb_ewise_jit_build_f32", 4, cd, pr, 2, ins, istr, 3, outs, oregs_bad, ostr, 2, shape, None, ctypes.byref(n),
+               ctypes.byref(red), None, 0)
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
 

@@ -25,7 +25,7 @@ int main() {
   (void)hipMemcpy(A, h.data(), M * M * 4, hipMemcpyHostToDevice);
   for (int inv = 0; inv < 2; ++inv) {
     for (int rep = 0; rep < 3; ++rep) {
-      if (inv) hb_cholesky_inverse_f32(A, L, W, 1, M, info, ws, 0);
+      if (inv) hb_cholesky_inverse_f32(A, L, W, 1, M, info, ws, nullptr, 0, 0);
       else hb_cholesky_f32(A, L, 1, M, info, 0);
     }
     (void)hipDeviceSynchronize();
