@@ -931,6 +931,7 @@ extern "C" int hb_gauss_ll_f64(const double* x, const double* f, const double* s
 // mode 1: add alpha to the diagonal (out = in + alpha*I)
 // mode 2: Cholesky-gradient Phi: lower triangle with halved diagonal
 // mode 3: symmetrise 0.5*(in + in^T) (square only)
+// mode 4: symmetric from half the lower triangle: out[i][j] = 0.5 * in[max(i,j)][min(i,j)] (square only)
 template <typename T>
 __global__ void __launch_bounds__(256) matutil_kernel(const T* __restrict__ in, T* __restrict__ out, long B, long R,
                                                       long C, int mode, long lower, long upper, T alpha) {
@@ -950,6 +951,8 @@ __global__ void __launch_bounds__(256) matutil_kernel(const T* __restrict__ in, 
       v = (i > j) ? v : (i == j ? T(0.5) * v : T(0));
     } else if (mode == 3) {
       v = T(0.5) * (v + in[b * R * C + j * C + i]);
+    } else if (mode == 4) {
+      v = T(0.5) * (i >= j ? v : in[b * R * C + j * C + i]);
     }
     out[t] = v;
   }
@@ -958,8 +961,8 @@ template <typename T>
 static int matutil_launch(const T* in, T* out, long B, long R, long C, int mode, long lower, long upper, double alpha,
                           hipStream_t stream) {
   HB_REQUIRE(B >= 0 && R >= 0 && C >= 0, "hb_matutil: negative extent");
-  HB_REQUIRE(mode >= 0 && mode <= 3, "hb_matutil: bad mode %d", mode);
-  HB_REQUIRE(mode != 3 || (R == C && in != out), "hb_matutil: symmetrise needs square, out-of-place");
+  HB_REQUIRE(mode >= 0 && mode <= 4, "hb_matutil: bad mode %d", mode);
+  HB_REQUIRE((mode != 3 && mode != 4) || (R == C && in != out), "hb_matutil: symmetrise needs square, out-of-place");
   const long n = B * R * C;
   if (n == 0) return 0;
   hipLaunchKernelGGL(matutil_kernel<T>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, in, out, B, R, C, mode,

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
   }
   const int row0 = (tile / tiles_n) * BT;
   const int col0 = (tile % tiles_n) * BT;
-  if ((a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && col0 > row0 + BT - 1) {
+  if ((a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT | HB_MM_SYMLOW_OUT)) && col0 > row0 + BT - 1) {
     if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && !a.to_ws) {
       // a tile wholly above the diagonal: all zero (with split-K the finish kernel writes them)
       T* Cb = a.C + b * a.sC;
@@ -178,6 +178,12 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
         if (a.beta != T(0)) o += a.beta * Cb[r * a.ldc + c];
         if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && c > r) o = T(0);
         if ((a.flags & HB_MM_PHI_OUT) && c == r) o *= T(0.5);
+        if (a.flags & HB_MM_SYMLOW_OUT) {
+          // half the lower triangle, mirrored: elements above the diagonal come from their mirror images
+          if (c > r) return;
+          o *= T(0.5);
+          Cb[c * a.ldc + r] = o;
+        }
         Cb[r * a.ldc + c] = o;
       }
     });
@@ -211,6 +217,10 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
       for (; s < a.S; ++s) acc0 += a.ws[(long)s * total + at];
       return (acc0 + acc1) + (acc2 + acc3);
     };
+    if (a.flags & HB_MM_SYMLOW_OUT) {
+      cp[0] = T(0.5) * slab_sum(c > r ? b * a.M * a.N + c * a.N + r : t);
+      continue;
+    }
     T acc = slab_sum(t);
     if (a.flags & HB_MM_SYM_OUT) {
       const long tt = b * a.M * a.N + c * a.N + r;  // the mirrored element
@@ -269,7 +279,7 @@ __global__ void __launch_bounds__(256) matmul_wgk_kernel(MmArgs<float> a) {
   const int row0 = ti * 32, col0 = tj * 32;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
   float* Cb = a.C + b * a.sC;
-  const bool lower_only = (a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) != 0;
+  const bool lower_only = (a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT | HB_MM_SYMLOW_OUT)) != 0;
   if (!SYM && lower_only && col0 > row0 + 31) {
     if (a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) {
       for (int idx = tid; idx < 1024; idx += 256) Cb[(long)(row0 + (idx >> 5)) * a.ldc + col0 + (idx & 31)] = 0.f;
@@ -366,12 +376,26 @@ __global__ void __launch_bounds__(256) matmul_wgk_kernel(MmArgs<float> a) {
       Cb[gr * a.ldc + gcn] = sy;
       continue;
     }
+    if (a.flags & HB_MM_SYMLOW_OUT) {
+      // half the lower triangle, mirrored.  On a diagonal tile the element above the diagonal takes its mirror
+      // image's value; the mirrored TILE of an off-diagonal one is written below (transposed read: coalesced store)
+      const int rr = (ti == tj && c > r) ? c : r, cc = (ti == tj && c > r) ? r : c;
+      Cb[gr * a.ldc + gcn] = 0.5f * a.alpha * ((red[0][rr][cc] + red[1][rr][cc]) + (red[2][rr][cc] + red[3][rr][cc]));
+      continue;
+    }
     if (biasb) v += biasb[gcn];
     v = apply_act<float>(a.act, v);
     if (a.beta != 0.f) v += a.beta * Cb[gr * a.ldc + gcn];
     if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && gcn > gr) v = 0.f;
     if ((a.flags & HB_MM_PHI_OUT) && gcn == gr) v *= 0.5f;
     Cb[gr * a.ldc + gcn] = v;
+  }
+  if (!SYM && (a.flags & HB_MM_SYMLOW_OUT) && ti != tj) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * e, r = idx >> 5, c = idx & 31;
+      Cb[(long)(col0 + r) * a.ldc + row0 + c] = 0.5f * a.alpha * ((red[0][c][r] + red[1][c][r]) + (red[2][c][r] + red[3][c][r]));
+    }
   }
   if (SYM && ti != tj) {
     // the mirrored tile (tj, ti): element (r, c) there = the symmetrised element (c, r) here
@@ -456,7 +480,9 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
              "hb_matmul: SYM_OUT needs a square result, a workspace, and no other epilogue");
   HB_REQUIRE(!(flags & HB_MM_ACTGRAD) || (bias && beta == 0.0 && flags == HB_MM_ACTGRAD),
              "hb_matmul: ACTGRAD needs Y in `bias`, beta = 0 and no other flag");
-  const bool lower = (flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) != 0;
+  HB_REQUIRE(!(flags & HB_MM_SYMLOW_OUT) || (M == N && !bias && act == HB_ACT_NONE && beta == 0.0 && flags == HB_MM_SYMLOW_OUT),
+             "hb_matmul: SYMLOW_OUT needs a square result and no other epilogue");
+  const bool lower = (flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT | HB_MM_SYMLOW_OUT)) != 0;
   auto active_tiles = [&](int bt) -> long {
     const long tr = hb_cdiv(M, bt), tc = hb_cdiv(N, bt);
     return (lower && M == N) ? tr * (tr + 1) / 2 : tr * tc;

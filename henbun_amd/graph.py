@@ -874,6 +874,8 @@ def _matmul_emit(plan, node):
             epi = H.MM_PHI_OUT
         elif ma["mode"] == 3:
             epi = H.MM_SYM_OUT
+        elif ma["mode"] == 4:
+            epi = H.MM_SYMLOW_OUT
         elif ma["mode"] == 0 and ma["lower"] < 0 and ma["upper"] == 0:
             epi = H.MM_TRIL_OUT
     if epi:
@@ -985,6 +987,8 @@ def _matutil_vjp(node, gs):
         return [g]
     if a["mode"] == 2:
         return [matutil(g, 2)]
+    if a["mode"] == 4:
+        return [matutil(matutil(g, 3), 2)]   # y_ij = x_{max,min} / 2:  xbar = Phi((g + g^T) / 2)
     return [matutil(g, 3)]
 
 
@@ -1038,15 +1042,19 @@ def _cholesky_emit(plan, node):
 
 
 def _cholesky_vjp(node, gs):
-    """Murray (2016) / TF _CholeskyGrad:  P = Phi(L^T Lbar);  S = L^-T P L^-1;  Abar = (S+S^T)/2."""
+    """Murray (2016) / TF _CholeskyGrad:  P = Phi(L^T Lbar);  S = L^-T P L^-1;  Abar = (S+S^T)/2.
+
+    Since (S + S^T)/2 = L^-T ((P + P^T)/2) L^-1, the symmetrisation is applied to the M x M operand instead of the
+    result: Psym = (P + P^T)/2, i.e. Psym_ij = Q_{max(i,j),min(i,j)} / 2 with Q = L^T Lbar (matutil mode 4, the
+    epilogue of the first product), and Abar = L^-T Psym L^-1 comes out symmetric from two plain products -- the
+    symmetrising third product carried a second accumulator per workgroup and took 11.2 us against 6.3 at cfg 2."""
     g = gs[0]
     if g is None:
         return [None]
     L = node.outputs[0]
     W = trinv(L)
-    P = matutil(matmul(L, band_part(g, -1, 0), transpose_a=True), 2)
-    S = matmul(matmul(W, P, transpose_a=True), W)
-    return [matutil(S, 3)]
+    P = matutil(matmul(L, band_part(g, -1, 0), transpose_a=True), 4)
+    return [matmul(matmul(W, P, transpose_a=True), W)]
 
 
 defop("cholesky", _cholesky_emit, _cholesky_vjp)

@@ -33,6 +33,7 @@ MM_LOWER_OUT = 1
 MM_TRIL_OUT = 2
 MM_PHI_OUT = 4
 MM_SYM_OUT = 8
+MM_SYMLOW_OUT = 32
 MM_ACTGRAD = 16
 ACT = dict(none=0, sigmoid=1, relu=2, tanh=3)
 SGP_NEGLECTED, SGP_DIAGONAL = 0, 1

@@ -187,7 +187,10 @@ int hb_gather_rows_multi_draw_f64(int narr, const double* const* srcs, const lon
 /* batched [B,R,C] matrix utilities.  mode 0 = tf.matrix_band_part(lower,upper)
  * (reference variationals.py:145); 1 = + alpha*I (kernels.py:100 jitter);
  * 2 = Phi (lower triangle, halved diagonal) of the Cholesky gradient;
- * 3 = 0.5*(A + A^T). */
+ * 3 = 0.5*(A + A^T);
+ * 4 = symmetric matrix built from HALF the lower triangle: out[i][j] = out[j][i] = 0.5*A[max(i,j)][min(i,j)]
+ *     (= (Phi(A) + Phi(A)^T)/2, the operand that makes the Cholesky gradient's L^-T Phi(.) L^-1 symmetric by
+ *     construction, so no symmetrising pass over the result is needed). */
 int hb_matutil_f32(const float* in, float* out, long B, long R, long C, int mode, long lower,
                    long upper, double alpha, void* stream);
 int hb_matutil_f64(const double* in, double* out, long B, long R, long C, int mode, long lower,
@@ -292,7 +295,9 @@ enum {
   HB_MM_ACTGRAD = 16   /* C = alpha * result * act'(Y): `bias` then points to Y = the activation OUTPUT of the layer
                           being differentiated, [batch, M, N] contiguous (sBias = M*N or 0), and `act` names the
                           activation: y(1-y), [y > 0], 1-y^2.  The MLP backward's "dx GEMM, then activation-gradient
-                          pass" in one launch; beta must be 0 and no other flag may be set */
+                          pass" in one launch; beta must be 0 and no other flag may be set */,
+  HB_MM_SYMLOW_OUT = 32 /* C[i][j] = C[j][i] = 0.5 * result[max(i,j)][min(i,j)] (hb_matutil mode 4 as an epilogue): only the
+                          tiles touching the lower triangle are computed; square result, no bias / activation / beta */
 };
 enum { HB_ACT_NONE = 0, HB_ACT_SIGMOID = 1, HB_ACT_RELU = 2, HB_ACT_TANH = 3 };
 /* C[b] = act(alpha * op(A[b]) op(B[b]) + bias[b]) + beta * C[b], op = transpose if trans?.

@@ -132,6 +132,9 @@ def evaluate(outputs, leaf_values, noise=None):
                 outs = [x + at["alpha"] * torch.eye(x.shape[-1], dtype=DT)]
             elif m == 2:
                 outs = [torch.tril(x, -1) + 0.5 * torch.diag_embed(torch.diagonal(x, dim1=-2, dim2=-1))]
+            elif m == 4:
+                lo = torch.tril(x)
+                outs = [0.5 * (lo + torch.tril(x, -1).transpose(-1, -2))]
             else:
                 outs = [0.5 * (x + x.transpose(-1, -2))]
         elif op == "cholesky":

@@ -354,6 +354,11 @@ def test_matmul_in_workgroup_split_k_small_gemms(H, tA, tB):
             got = host(H.matmul(A_, B_, transA=tA, transB=tB, epilogue=H.MM_SYM_OUT))
             assert np.allclose(got, sq(0.5 * (full + np.transpose(full, (0, 2, 1)))), **tol)
             assert np.array_equal(got, np.swapaxes(got, -1, -2)), "symmetrised output must be exactly symmetric"
+            # half the lower triangle, mirrored (the symmetric operand of the Cholesky VJP): NaN-prefilled output
+            symlow = 0.5 * (np.tril(full) + np.transpose(np.tril(full, -1), (0, 2, 1)))
+            out = torch.full(tuple(sq(full).shape), float("nan"), dtype=dt, device="cuda")
+            got = host(H.matmul(A_, B_, transA=tA, transB=tB, out=out, epilogue=H.MM_SYMLOW_OUT))
+            assert np.allclose(got, sq(symlow), **tol) and np.array_equal(got, np.swapaxes(got, -1, -2))
             got = host(H.matmul(A_, B_, transA=tA, transB=tB, lower_out=True))
             il = np.tril_indices(m)
             assert np.allclose(got[..., il[0], il[1]], sq(full)[..., il[0], il[1]], **tol)
@@ -412,6 +417,11 @@ def test_matmul_batch_bias_act_splitk_lower(H, p):
         assert np.all(np.triu(got, 1) == 0) and np.allclose(got, phi, **tol5)
         got = host(H.matmul(dev(a5, dt), dev(b5, dt), epilogue=H.MM_SYM_OUT))
         assert np.allclose(got, 0.5 * (full + np.transpose(full, (0, 2, 1))), **tol5)
+        symlow = 0.5 * (np.tril(full) + np.transpose(np.tril(full, -1), (0, 2, 1)))
+        out = torch.full((2, 130, 130), float("nan"), dtype=dt, device="cuda")
+        got = host(H.matmul(dev(a5, dt), dev(b5, dt), out=out, epilogue=H.MM_SYMLOW_OUT))
+        assert np.allclose(got, symlow, **tol5) and np.array_equal(got, np.swapaxes(got, -1, -2))
+        assert_close(H.matutil(dev(full, dt), 4), symlow, TOL[p])
     # beta accumulate
     c0 = rng.randn(6, 2)
     out = dev(np.broadcast_to(c0, (5, 6, 2)).copy(), dt)
