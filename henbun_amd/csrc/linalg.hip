@@ -6,6 +6,7 @@
 // (gp/gp.py:162,169).  TensorFlow supplied these through Eigen/cuSOLVER; here
 // they are hand-written for gfx950.
 #include "common.cuh"
+#include "sgp_rider.cuh"
 #include "gemm_tile.cuh"
 #include "../../include/henbun_hip.h"
 
@@ -627,12 +628,22 @@ __device__ __forceinline__ void hb_split_bf16x3(float x, __bf16& hi, __bf16& mid
   lo = (__bf16)(r1 - (float)mid);
 }
 
+// `rider` (fp32, one matrix): blocks past `nown` compute the LAST 64-row block of A = W K(z, x) (sgp_rider.cuh);
+// they read rows of W this kernel only ever overwrites with the zeros they already hold or mask.
 template <typename T>
-__global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, T* __restrict__ W, T* __restrict__ Wf,
-                                                           int bf16x3, long B, long M) {
+__global__ void __launch_bounds__(SGP_RIDER_THREADS) tril_inplace_kernel(T* __restrict__ L, T* __restrict__ W, T* __restrict__ Wf,
+                                                                         int bf16x3, long B, long M, SgpRider rider, int nown) {
+  extern __shared__ __attribute__((aligned(16))) char hb_dyn_lds[];
+  if constexpr (sizeof(T) == 4) {
+    if ((int)blockIdx.x >= nown) {
+      sgp_rider_job(rider, reinterpret_cast<const float*>(W), (int)M, (int)(M / 64) - 1, (int)blockIdx.x - nown,
+                    *reinterpret_cast<SgpRiderLds*>(hb_dyn_lds));
+      return;
+    }
+  }
   const int Mi = (int)M;
   const long mm = M * M, total = B * mm;
-  const long stride = (long)gridDim.x * blockDim.x;
+  const long stride = (long)nown * blockDim.x;
   const int nT = Mi / 32;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const long b = t / mm;
@@ -1112,9 +1123,20 @@ static inline int chol64_grid(int nrt, int k, int inv) {
   return g;
 }
 
-__global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict__ Ain, float* __restrict__ L,
-                                                        float* __restrict__ Y, float* __restrict__ W, int M, int k,
-                                                        int* __restrict__ info) {
+__global__ void __launch_bounds__(SGP_RIDER_THREADS) chol_rl64_kernel(const float* __restrict__ Ain, float* __restrict__ L,
+                                                                      float* __restrict__ Y, float* __restrict__ W, int M,
+                                                                      int k, int* __restrict__ info, SgpRider rider,
+                                                                      int nown) {
+  // forward rider (sgp_rider.cuh): blocks past this launch's own grid compute rows [64(k-1), 64k) of A = W K(z, x)
+  // from the row block of W that launch k-1 finished
+  extern __shared__ __attribute__((aligned(16))) char hb_dyn_lds[];
+  if ((int)blockIdx.x >= nown) {
+    sgp_rider_job(rider, W, M, k - 1, (int)blockIdx.x - nown, *reinterpret_cast<SgpRiderLds*>(hb_dyn_lds));
+    return;
+  }
+  // a launch that carries riders has 512-thread workgroups (the riders' eight waves); the factorisation's own
+  // workgroups are 256 threads: the upper four waves leave before the first barrier
+  if (threadIdx.x >= 256) return;
   typedef float T;
   typedef Mma<float> MM;
   typedef float VT __attribute__((ext_vector_type(4)));
@@ -1380,7 +1402,7 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
 
 template <typename T>
 static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, long B, long M, int* info,
-                           hipStream_t stream) {
+                           hipStream_t stream, const SgpRider* rider = nullptr) {
   HB_REQUIRE(!Wf || (W && M % 32 == 0), "hb_cholesky_inverse: the fragment-major copies need W and M %% 32 == 0");
   HB_REQUIRE(!bf16x3 || (Wf && sizeof(T) == 4), "hb_cholesky_inverse: bf16x3 images need Wfrag and fp32");
   HB_REQUIRE(B >= 0 && M >= 0, "hb_cholesky: negative extent");
@@ -1399,18 +1421,39 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, lon
   const int nblk = hb_cdiv(M, CR_B);
   const bool fast = ((uintptr_t)L % 16 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)ws % 16 == 0) && M % CR_B == 0;
   static const bool no64 = getenv("HB_CHOL_NO64") != nullptr;  // diagnostic A/B switch
+  SgpRider none = {};
   if (sizeof(T) == 4 && fast && M % C64_NB == 0 && !no64) {
     const int nrt = (int)(M / 32);
+    const bool ride = rider != nullptr;
+    HB_REQUIRE(!ride || (inv && B == 1 && M <= SGP_SM_MAX), "hb_cholesky_inverse_sgp: the forward rider needs W, one matrix and M <= %d",
+               SGP_SM_MAX);
+    const SgpRider rd = ride ? *rider : none;
+    const size_t dyn = ride ? sizeof(SgpRiderLds) : 0;
+    if (ride) {
+      static bool once = false;   // > 64 KB of dynamic LDS has to be allowed per kernel (once per process)
+      if (!once) {
+        HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_rl64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(SgpRiderLds)));
+        HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tril_inplace_kernel<float>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SgpRiderLds)));
+        once = true;
+      }
+    }
     for (int k = 0; k < nrt / 2; ++k) {
-      dim3 grid((unsigned)chol64_grid(nrt, k, inv), (unsigned)B);
-      hipLaunchKernelGGL(chol_rl64_kernel, grid, dim3(256), 0, stream, (const float*)A, (float*)L,
-                         inv ? (float*)ws : (float*)nullptr, (float*)W, (int)M, k, info);
+      const int nown = chol64_grid(nrt, k, inv);
+      dim3 grid((unsigned)(nown + ((ride && k > 0) ? rd.nS : 0)), (unsigned)B);
+      hipLaunchKernelGGL(chol_rl64_kernel, grid, dim3(ride ? SGP_RIDER_THREADS : 256), dyn, stream, (const float*)A, (float*)L,
+                         inv ? (float*)ws : (float*)nullptr, (float*)W, (int)M, k, info, rd, nown);
       HB_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, bf16x3, B, M);
+    // with riders every workgroup holds ~95 KB of LDS (one per CU): the finishing pass then runs 256 grid-stride blocks
+    const int nown = ride ? 256 : hb_stream_grid(B * M * M, 256);
+    hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3((unsigned)(nown + (ride ? rd.nS : 0))), dim3(ride ? SGP_RIDER_THREADS : 256), dyn, stream, L, W, Wf, bf16x3,
+                       B, M, rd, nown);
     HB_LAUNCH_CHECK();
     return 0;
   }
+  HB_REQUIRE(!rider, "hb_cholesky_inverse_sgp: the forward rider needs fp32, M %% 64 == 0 and 16-byte aligned operands");
   for (int k = 0; k < nblk; ++k) {
     dim3 grid((unsigned)chol_rl_grid(nblk, k, inv), (unsigned)B);
     if (fast)
@@ -1421,7 +1464,8 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, lon
                          k, info);
     HB_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, bf16x3, B, M);
+  hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, bf16x3, B, M, none,
+                     hb_stream_grid(B * M * M, 256));
   HB_LAUNCH_CHECK();
   return 0;
 }
@@ -1436,6 +1480,21 @@ extern "C" int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long 
                                        float* Wfrag, int frag_bf16x3, void* stream) {
   HB_REQUIRE(W, "hb_cholesky_inverse: NULL pointer");
   return cholesky_launch<float>(A, L, W, ws, Wfrag, frag_bf16x3, B, M, info, (hipStream_t)stream);
+}
+extern "C" int hb_cholesky_inverse_sgp_f32(const float* A, float* L, float* W, long M, int* info, float* ws, float* Wfrag,
+                                           int frag_bf16x3, const float* x, const float* z, const float* ell, long dl,
+                                           const float* u, long n, long d, long P, float* A_frag, float* sgp_ws,
+                                           void* stream) {
+  HB_REQUIRE(x && z && ell && A_frag && sgp_ws && W && ws, "hb_cholesky_inverse_sgp: NULL pointer");
+  HB_REQUIRE(M >= 64 && M % 64 == 0 && M <= SGP_SM_MAX, "hb_cholesky_inverse_sgp: M must be a multiple of 64 up to %d", SGP_SM_MAX);
+  HB_REQUIRE(n >= 1 && d >= 1 && d <= SGP_DREG_R && P >= 1 && P <= 4 && (dl == 1 || dl == d),
+             "hb_cholesky_inverse_sgp: needs n >= 1, 1 <= d <= %d, 1 <= P <= 4, dl in {1, d}", SGP_DREG_R);
+  HB_REQUIRE(((uintptr_t)W % 16) == 0 && ((uintptr_t)A_frag % 16) == 0, "hb_cholesky_inverse_sgp: W and A_frag must be 16-byte aligned");
+  SgpRider r;
+  r.x = x; r.z = z; r.ell = ell; r.u = u; r.Af = A_frag;
+  r.part = sgp_ws + n + M * d;   // where hb_sgp_fwd / hb_sgp_finish keep the column partials (E = 1)
+  r.n = n; r.d = (int)d; r.dl = (int)dl; r.P = (int)P; r.nS = (int)((n + SGP_SN - 1) / SGP_SN);
+  return cholesky_launch<float>(A, L, W, ws, Wfrag, frag_bf16x3, 1, M, info, (hipStream_t)stream, &r);
 }
 extern "C" int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info, double* ws,
                                        double* Wfrag, int frag_bf16x3, void* stream) {

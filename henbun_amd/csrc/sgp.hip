@@ -18,6 +18,7 @@
 // E * M^2 * n (Kbar = W^T Abar), E * M^2 * n (Lbar = -tril(Kbar A^T)).
 // The roofline that bounds them is the f32 MFMA peak (v_mfma_f32_32x32x2_f32).
 #include "common.cuh"
+#include "sgp_rider.cuh"  // strip constants, sgp_store_frag_tile, the forward rider of the Cholesky launches
 #include <type_traits>
 #include "gemm_tile.cuh"
 #include "rng_pairs.cuh"
@@ -84,13 +85,6 @@ static inline dim3 sgp_grid(long gx, long gy, long E, long& efast) {
 template <typename T> __device__ __forceinline__ T hb_exp_fast(T x);
 template <> __device__ __forceinline__ float hb_exp_fast<float>(float x) { return __expf(x); }
 template <> __device__ __forceinline__ double hb_exp_fast<double>(double x) { return exp(x); }
-// exp(-r2/2) = 2^(-(s*r)^2) with s = sqrt(log2(e)/2): coordinates staged pre-multiplied by s/ell make the
-// RBF value a single v_exp_f32 of the negated squared difference.
-#define SGP_EXP2_SCALE 0.84932180028801904272
-template <typename T> __device__ __forceinline__ T hb_exp2_neg(T x);
-template <> __device__ __forceinline__ float hb_exp2_neg<float>(float x) { return __builtin_amdgcn_exp2f(-x); }
-template <> __device__ __forceinline__ double hb_exp2_neg<double>(double x) { return exp2(-x); }
-
 template <typename T, int D>
 struct SgpZ {
   T z[D];
@@ -339,9 +333,6 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
 #ifndef HB_STRIP_ABLATE
 #define HB_STRIP_ABLATE 0
 #endif
-#define SGP_SN 32
-#define SGP_SM_MAX 512
-#define SGP_SLD (SGP_SM_MAX + 4)
 
 #define SGP_STRIP_THREADS 512  // 8 waves: two per SIMD, so one wave's W loads are in flight under the other's MFMAs
 
@@ -584,31 +575,6 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
     }
   }
   HB_SSTAMP(6);
-}
-
-// Fragment-major copy of a finished 32 x 32 tile (accumulator layout: column on the lane, rows in the registers) of
-// an [M, n] operand of the Lbar contraction: block (row tile t, strip s) holds, for v = 0..3, lane (li, h), s' = 0..3,
-//     X[32 t + li][32 s + 16 h + 4 v + s']
-// i.e. the MFMA operand fragments of a contraction over the DATA axis, in load order: each of the four stores of a
-// wave -- and each of the consumer's loads -- is one contiguous kilobyte.  The tile is turned row-per-lane through the
-// wave's own LDS buffer (no barrier: a wave's LDS operations execute in order).  Columns past n are written as zeros.
-#define SGP_TLD 36
-__device__ __forceinline__ void sgp_store_frag_tile(float* __restrict__ Xf, float (*T)[SGP_TLD],
-                                                    const Mma<float>::Acc& acc, long e, int nT, int nS, int tile, int strip,
-                                                    int col0, int n, int lane) {
-  typedef float V4 __attribute__((ext_vector_type(4)));
-  const int li = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) T[Mma<float>::acc_row(lane, r)][li] = acc[r];
-  float* blk = Xf + ((((long)e * nT + tile) * nS + strip) << 10) + 4 * lane;
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    V4 q = *reinterpret_cast<const V4*>(&T[li][16 * h + 4 * v]);
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
-      if (col0 + 16 * h + 4 * v + s2 >= n) q[s2] = 0.f;
-    *reinterpret_cast<V4*>(blk + 256 * v) = q;
-  }
 }
 
 // bf16x3 form of the fragment-major exchange (HB_PREC_BF16X3): three planes (hi, mid, lo terms) of bf16, each
@@ -1229,6 +1195,26 @@ __global__ void __launch_bounds__(256) sgp_rng_fill_kernel(uint64_t* state, long
     if (2 * p + 1 < n) out[2 * p + 1] = (T)z1;
   }
   rng_store(state, nlanes, t, g);
+}
+
+// The finish pass alone: f, v (and the residual noise) from column partials that are already in the workspace -- the
+// ceil(M/64) slices per expert left by the forward riders of hb_cholesky_inverse_sgp.
+template <typename T>
+static int sgp_finish_only(const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* f, T* v, long E, long n, long M,
+                           long d, long P, int mode, T* ws, hipStream_t stream) {
+  HB_REQUIRE(f && v && ws && E >= 1 && n >= 0 && M >= 1 && P >= 1 && P <= 4, "hb_sgp_finish: bad arguments");
+  HB_REQUIRE(mode == HB_SGP_DIAGONAL || mode == HB_SGP_NEGLECTED, "hb_sgp_finish: mode must be diagonal or neglected");
+  const bool draw = mode == HB_SGP_DIAGONAL && !eps_in;
+  HB_REQUIRE(!draw || (rng && rng_lanes > 0), "hb_sgp_finish: eps_in or an RNG state is required for the diagonal residual");
+  if (E * n == 0) return 0;
+  const int gy = (int)((M + SGP_BM - 1) / SGP_BM);
+  const long total = E * n;
+  const int fgrid = draw ? hb_cdiv(rng_lanes, 256) : hb_stream_grid((total + 1) / 2, 256);
+  hipLaunchKernelGGL(sgp_finish_part_kernel<T>, dim3(fgrid), dim3(256), 0, stream, ws + E * n + E * M * d, gy,
+                     mode == HB_SGP_DIAGONAL ? eps_in : (const T*)nullptr, draw ? rng : (uint64_t*)nullptr, rng_lanes,
+                     mode == HB_SGP_DIAGONAL ? eps_out : (T*)nullptr, f, v, total, n, P, mode);
+  HB_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" long hb_sgp_ws_elems(long E, long n, long M, long d, long P) {
@@ -2665,4 +2651,13 @@ extern "C" int hb_sgp_bwd_f64(int kind, int mode, const double* x, long sx, cons
                               long E, long n, long M, long d, long P, double* ws, void* stream) {
   return sgp_bwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps, A, A_frag, v, fbar, Kbar, Kbar_frag, Lbar,
                          ubar, zbar, ellbar, xbar, E, n, M, d, P, ws, (hipStream_t)stream);
+}
+
+extern "C" int hb_sgp_finish_f32(const float* eps_in, uint64_t* rng, long rng_lanes, float* eps_out, float* f, float* v,
+                                 long E, long n, long M, long d, long P, int mode, float* ws, void* stream) {
+  return sgp_finish_only<float>(eps_in, rng, rng_lanes, eps_out, f, v, E, n, M, d, P, mode, ws, (hipStream_t)stream);
+}
+extern "C" int hb_sgp_finish_f64(const double* eps_in, uint64_t* rng, long rng_lanes, double* eps_out, double* f, double* v,
+                                 long E, long n, long M, long d, long P, int mode, double* ws, void* stream) {
+  return sgp_finish_only<double>(eps_in, rng, rng_lanes, eps_out, f, v, E, n, M, d, P, mode, ws, (hipStream_t)stream);
 }

@@ -187,7 +187,8 @@ class Optimizer:
         n = settings.numerics
         return (n.jitter_level, n.clip_by_value, n.clip_value_min, n.clip_value_max, str(getattr(n, "kl_form", "mc")), str(getattr(n, "contraction", "native")),
                 str(settings.runtime.index_source), bool(settings.runtime.fuse_elementwise),
-                bool(getattr(settings.runtime, "force_dp", False)))
+                bool(getattr(settings.runtime, "force_dp", False)), bool(getattr(settings.runtime, "chol_rider", False)),
+                str(getattr(settings.runtime, "ewise", "jit")))
 
     @staticmethod
     def _dp_active(sess):
@@ -452,6 +453,7 @@ class Optimizer:
         grads = G.gradients(obj, leaves)
         outs = [obj] + [g for g in grads if g is not None]
         plan = sess.make_plan(outs, minibatch=minibatch_size)
+        self.last_plan = plan
         self._apply_indices(plan, indices)
         plan.run()
         plan.check()

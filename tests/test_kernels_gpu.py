@@ -728,6 +728,51 @@ def test_sgp_backward_column_strip_form(H, E, M, n, d, P, mode):
             assert e_new <= 3.0 * e_old + slack, (nm, tag, e_old, e_new)
 
 
+@pytest.mark.parametrize("M,n,d,P,mode", [(512, 8192, 1, 1, "diagonal"), (128, 1000, 2, 3, "diagonal"), (64, 33, 4, 1, "neglected"),
+                                          (320, 4097, 1, 2, "diagonal")])
+def test_cholesky_chain_carries_the_forward_contraction(H, M, n, d, P, mode):
+    """hb_cholesky_inverse_sgp: the launches of the factor + inverse chain also compute A = W K(z, x) row block by row
+    block (one rider workgroup per 32 data columns from launch 1 on, the last block with the finishing pass) and its
+    column statistics; hb_sgp_finish turns those into f and v.  Same L and W bits as hb_cholesky_inverse (the chain
+    itself is untouched), and A / f / v equal to hb_sgp_fwd's on those operands up to the summation order of the
+    contraction (split between wave pairs here)."""
+    dt = torch.float32
+    rng = np.random.RandomState(9)
+    z = np.sort(rng.uniform(0, M / 2.0, (M, d)), axis=0)
+    ellv = np.exp(0.1 * rng.randn(d))
+    x = rng.uniform(0, M / 2.0, (n, d))
+    u, eps = rng.randn(P, M), rng.randn(n)
+    zd, ld, xd, ud, ed = dev(z, dt), dev(ellv, dt), dev(x, dt), dev(u, dt), dev(eps, dt)
+    K = H.gram_fwd(zd, zd, ld, diag_add=1e-2)
+    m = H.SGP_DIAGONAL if mode == "diagonal" else H.SGP_NEGLECTED
+    # reference: the separate chain, then the strip kernel
+    frag0 = torch.zeros(2 * M * M, dtype=dt, device="cuda")
+    L0, W0, info0 = H.cholesky_inverse(K, frag=frag0)
+    af0 = torch.zeros(H.sgp_frag_elems(1, n, M), dtype=dt, device="cuda")
+    f0, A0, v0, _ = H.sgp_fwd(xd, zd, ld, W0, ud, eps_in=ed, mode=m, wfrag=frag0, a_frag=af0)
+    # riders
+    frag1 = torch.zeros(2 * M * M, dtype=dt, device="cuda")
+    af1 = torch.full((H.sgp_frag_elems(1, n, M),), float("nan"), dtype=dt, device="cuda")
+    sws = torch.full((H.sgp_rider_ws_elems(n, M, d),), float("nan"), dtype=dt, device="cuda")
+    L1, W1, info1 = H.cholesky_inverse_sgp(K, xd, zd, ld, ud, af1, sws, frag=frag1)
+    f1, v1, e1 = H.sgp_finish(sws, n, M, d, P, eps_in=ed, mode=m)
+    assert not info0.cpu().numpy().any() and not info1.cpu().numpy().any()
+    assert torch.equal(L0, L1) and torch.equal(W0, W1) and torch.equal(frag0, frag1)
+    scale = float(A0.abs().max())
+    if H.sgp_strip_path(1, n, M, d, P):
+        assert np.abs(host(af1) - host(af0)).max() <= 2e-5 * max(1.0, scale), "fragment-major A"
+    else:
+        # the separate path left A row-major only: compare through the layout map
+        nS, nT = (n + 31) // 32, M // 32
+        Ah = np.zeros((M, 32 * nS))
+        Ah[:, :n] = host(A0)
+        t_, s_, v_, l_, q_ = np.meshgrid(np.arange(nT), np.arange(nS), np.arange(4), np.arange(64), np.arange(4), indexing="ij")
+        want = Ah[32 * t_ + (l_ & 31), 32 * s_ + 16 * (l_ >> 5) + 4 * v_ + q_]
+        assert np.abs(host(af1).reshape(nT, nS, 4, 64, 4) - want).max() <= 2e-5 * max(1.0, scale)
+    assert_close(f1, f0, dict(rtol=1e-4, atol=1e-4 * max(1.0, float(f0.abs().max()))))
+    assert_close(v1, v0, dict(rtol=1e-4, atol=1e-4))
+
+
 def test_bf16x3_contraction_has_fp32_accuracy(H):
     """HB_PREC_BF16X3 (BASELINE cfg 5's "fp16-with-fp32-accum" variant in a usable form): A = L^-1 K(z,x) with every
     operand split into three bf16 terms on v_mfma_f32_32x32x16_bf16 is as close to the fp64 result as the fp32-operand

@@ -498,6 +498,42 @@ def test_bf16x3_contraction_mode_tracks_the_fp32_step():
         assert r1 <= 2.0 * r0 + 1e-3, (mine, r0, r1)
 
 
+def test_forward_contraction_riding_on_the_cholesky_chain_gives_the_same_step():
+    """settings.runtime.chol_rider: the launches of the Cholesky + inverse chain carry the sparse-GP forward contraction
+    (hb_cholesky_inverse_sgp + hb_sgp_finish instead of hb_cholesky_inverse + hb_sgp_fwd).  Same ELBO and gradients as
+    the separate kernels up to the summation order of the contraction, against the fp64 oracle, and it trains."""
+    res, nsteps = {}, {}
+    for ride in (False, True):
+        cfg = hb.settings.get_settings()
+        cfg.numerics.jitter_level = 1e-4
+        cfg.runtime.chol_rider = ride
+        with hb.settings.temp_settings(cfg):
+            m, data = make_svgp(20000, 256, 3000, "diagonal", "float32")
+            opt = m.ELBO()
+            opt.compile()
+            res[ride] = opt.gradients(minibatch_size=3000, indices=data[5])
+            labels = [opt.last_plan.step_labels.get(id(s)) for s in opt.last_plan.steps]
+            nsteps[ride] = labels
+            if ride:
+                fn, params = oracle_svgp(m, data, 1e-4, "diagonal")
+                ref_val, ref = O.grads_of(fn, params)
+                m.u.inject_noise(None)
+                m.eps = None
+                o2 = m.ELBO()
+                o2.compile(optimizer=tf.train.AdamOptimizer(1e-3))
+                o2.optimize(maxiter=5, minibatch_size=3000)
+                assert np.isfinite(o2.run(minibatch_size=3000))
+    # the fused plan emits the factorisation where the sgp op stands: [cholesky, sgp (finish only)] back to back
+    lr = nsteps[True]
+    assert "cholesky" in lr and lr[lr.index("cholesky") + 1] == "sgp"
+    (v0, g0), (v1, g1) = res[False], res[True]
+    e0, e1 = abs(v0 - ref_val.item()), abs(v1 - ref_val.item())
+    assert e1 <= 2.0 * e0 + 1e-4 * abs(ref_val.item()), (e0, e1)
+    for mine, theirs in NAMES:
+        r0, r1 = rel_err(g0[mine], ref[theirs].numpy()), rel_err(g1[mine], ref[theirs].numpy())
+        assert r1 <= 2.0 * r0 + 1e-3, (mine, r0, r1)
+
+
 def test_injected_indices_out_of_range_raise():
     """A caller-supplied minibatch index outside the data set is an error, not silently zero-filled rows
     (the reference would fail inside tf.gather / numpy indexing, param.py:733-739)."""

@@ -18,6 +18,9 @@ __device__ long long hb_srt[256 * 2];
 #include <algorithm>
 #include <stdio.h>
 #include <vector>
+// the in-step form: hb_sgp_fwd with the fragment-major A only (no row-major A), statistics and finish
+static float *g_u, *g_eps, *g_Af, *g_f, *g_v, *g_ws;
+#define RUN() hb_sgp_fwd_f32(0, 1, x, 0, z, ell, 1, W, Wf, 0, g_u, g_eps, nullptr, 0, nullptr, nullptr, g_Af, g_f, g_v, 1, n, M, 1, 1, g_ws, 0)
 int main() {
   const int M = 512, n = 8192;
   float *K, *L, *W, *ws, *Wf, *z, *x, *A, *ell;
@@ -25,6 +28,9 @@ int main() {
   (void)hipMalloc(&K, M * M * 4); (void)hipMalloc(&L, M * M * 4); (void)hipMalloc(&W, M * M * 4); (void)hipMalloc(&ws, M * M * 4);
   (void)hipMalloc(&Wf, 2 * M * M * 4); (void)hipMalloc(&info, 4);
   (void)hipMalloc(&z, M * 4); (void)hipMalloc(&x, n * 4); (void)hipMalloc(&A, (size_t)M * n * 4); (void)hipMalloc(&ell, 4);
+  (void)hipMalloc(&g_u, M * 4); (void)hipMalloc(&g_eps, n * 4); (void)hipMalloc(&g_Af, (size_t)M * n * 4); (void)hipMalloc(&g_f, n * 4);
+  (void)hipMalloc(&g_v, n * 4); (void)hipMalloc(&g_ws, (size_t)(n + M + 32L * M * M) * 4);
+  (void)hipMemset(g_u, 0, M * 4); (void)hipMemset(g_eps, 0, n * 4);
   std::vector<float> hz(M), hx(n);
   for (int i = 0; i < M; ++i) hz[i] = i * 0.5f;
   for (int i = 0; i < n; ++i) hx[i] = (i % 997) * 0.25f;
@@ -33,14 +39,15 @@ int main() {
   (void)hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(ell, &one, 4, hipMemcpyHostToDevice);
   if (hb_gram_fwd_f32(0, z, 0, z, 0, ell, 0, 1, K, 1, M, M, 1, 1e-3, 0)) { printf("gram: %s\n", hb_last_error_string()); return 1; }
-  if (hb_cholesky_inverse_f32(K, L, W, 1, M, info, ws, Wf, 0)) { printf("chol: %s\n", hb_last_error_string()); return 1; }
+  if (hb_cholesky_inverse_f32(K, L, W, 1, M, info, ws, Wf, 0, 0)) { printf("chol: %s\n", hb_last_error_string()); return 1; }
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) hb_sgp_A_f32(0, x, 0, z, ell, 1, W, Wf, A, 1, n, M, 1, 0);
+  for (int i = 0; i < 5; ++i) RUN();
   (void)hipEventRecord(e0);
-  for (int i = 0; i < 50; ++i) hb_sgp_A_f32(0, x, 0, z, ell, 1, W, Wf, A, 1, n, M, 1, 0);
+  for (int i = 0; i < 50; ++i) RUN();
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-  printf("hb_sgp_A_f32 (strip2, fragment-major W): %.2f us per launch (back-to-back stream launches)\n", ms * 1e3 / 50);
+  if (RUN()) { printf("fwd: %s\n", hb_last_error_string()); return 1; }
+  printf("hb_sgp_fwd_f32 (strip2 + finish, fragment-major W and A): %.2f us per launch (back-to-back stream launches)\n", ms * 1e3 / 50);
   std::vector<long long> st(256 * 8 * 4), rt(512);
   (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(hb_sstamps), st.size() * 8);
   (void)hipMemcpyFromSymbol(rt.data(), HIP_SYMBOL(hb_srt), rt.size() * 8);
