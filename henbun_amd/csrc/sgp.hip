@@ -1026,6 +1026,13 @@ extern "C" int hb_sgp_strip_path(long E, long n, long M, long d, long P, int pre
   if (hb_sgp_no_strip()) return 0;
   if (!(M >= 32 && M <= SGP_SM_MAX && M % 32 == 0 && d >= 1 && d <= SGP_DREG && P <= 4 && n > 0 && E >= 1)) return 0;
   if (prec == HB_PREC_BF16X3) return 1;
+  // Round 1's crossover (tiled kernels for many experts / long minibatches: 1.68 vs 1.76 ms at cfg 5 with the first
+  // strip kernel) no longer holds with the fragment-major W / A / Kbar exchange: cfg 5 (E = 8, n = 65536) runs
+  // 6.03 ms per step tiled against 5.33 ms in strip form (sgp_grad 3742 -> 3371 us, sgp 1554 -> 1479 us).
+  // HB_SGP_TILED_CROSSOVER=1 restores the old rule (diagnostic).
+  static const bool old_rule = getenv("HB_SGP_TILED_CROSSOVER") != nullptr;
+  // (the backward's strip partials [nS][2d + P][M] and at least one Lbar slab must fit the 32 M^2 workspace per expert)
+  if (!old_rule) return (E * hb_cdiv(n, SGP_SN) <= (1L << 22) && (long)hb_cdiv(n, SGP_SN) * (2 * d + P) <= 31 * M) ? 1 : 0;
   const long tiled_wgs = E * hb_cdiv(n, SGP_BN) * ((hb_cdiv(M, SGP_BM) + 1) / 2);
   return (tiled_wgs < 1024 && E * hb_cdiv(n, SGP_SN) <= 4096) ? 1 : 0;
 }
