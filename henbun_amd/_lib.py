@@ -41,6 +41,11 @@ _SIGS = {
     "hb_ewise_jit_run": [P, P],
     "hb_ewise_jit_destroy": [P],
     "hb_cholesky_inverse_sgp_f32": [P, P, P, L, P, P, P, I, P, P, P, L, P, L, L, L, P, P, P],
+    "hb_side_push_gather_draw_f32": [I, P, P, P, L, P, L, L, L, P, P, L, P, P],
+    "hb_side_push_diag_fwd_f32": [P, P, P, P, L, P, P, P, L, L, L, L, P, P],
+    "hb_side_push_diag_bwd_f32": [P, P, P, P, P, P, P, L, L, L, L, P],
+    "hb_side_pending": [],
+    "hb_side_flush": [P],
     "hb_comm_available": [],
     "hb_comm_unique_id": [P],
     "hb_comm_init": [P, I, I, P],

@@ -6,6 +6,7 @@
 // are written for correctness + coalescing, not for a roofline.
 #include "common.cuh"
 #include "rng_pairs.cuh"
+#include "side_jobs.cuh"  // GatherMultiArgs, gather_draw_body, the side-job list
 #include <string.h>
 #include "../../include/henbun_hip.h"
 
@@ -639,15 +640,6 @@ extern "C" int hb_gather_rows_f64(const double* src, long nsrc, long row, const 
 // Several arrays gathered by the same index vector in ONE launch (a model's MinibatchData arrays all take the same
 // rows; one launch per array is ~4 us of kernel boundary each).  Up to HB_GATHER_MAX arrays, each with its own
 // row width; all arrays have `nsrc` rows.
-#define HB_GATHER_MAX 8
-template <typename T>
-struct GatherMultiArgs {
-  const T* src[HB_GATHER_MAX];
-  T* dst[HB_GATHER_MAX];
-  long row[HB_GATHER_MAX];
-  long start[HB_GATHER_MAX + 1];  // prefix sums of n*row[a]: element range of array a in the flattened work list
-  int narr;
-};
 template <typename T>
 __global__ void __launch_bounds__(256) gather_rows_multi_kernel(GatherMultiArgs<T> g, const long* __restrict__ idx,
                                                                 const long* __restrict__ perm, long n, long nsrc,
@@ -710,37 +702,12 @@ __global__ void __launch_bounds__(256) gather_rows_multi_draw_kernel(GatherMulti
                                                                      long* __restrict__ idx_out,
                                                                      const long* __restrict__ perm, long n, long nsrc,
                                                                      int* __restrict__ err) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long r = t / G;
-  const int sub = (int)(t % G);
-  long j = 0;
-  if (sub == 0 && r < n) {
-    HbRng rg = rng_load(state, nlanes, r);
-    j = lo + (long)__umul64hi(rg.next(), range);
-    rng_store(state, nlanes, r, rg);
-    idx_out[r] = j;
-  }
-  if (G > 1) {
-    // the leader is lane (lane - sub) of the same wave (G divides 64)
-    const int leader = (threadIdx.x & 63) - sub;
-    const int jl = __shfl((int)(j & 0xffffffffL), leader), jh = __shfl((int)(j >> 32), leader);
-    j = ((long)jh << 32) | (unsigned int)jl;
-  }
-  if (r >= n) return;
-  if (perm) j = perm[j];
-  const bool bad = j < 0 || j >= nsrc;
-  if (bad && sub == 0 && err) *err = 1;
-#pragma unroll
-  for (int a = 0; a < HB_GATHER_MAX; ++a) {
-    if (a >= g.narr) break;
-    const long w = g.row[a];
-    for (long c = sub; c < w; c += G) g.dst[a][r * w + c] = bad ? T(0) : g.src[a][j * w + c];
-  }
+  gather_draw_body<T>(g, state, nlanes, lo, range, idx_out, perm, n, nsrc, err, G, (long)blockIdx.x);
 }
 template <typename T>
 static int gather_rows_multi_draw(int narr, const T* const* srcs, const long* rows, T* const* dsts, long nsrc,
                                   uint64_t* state, long nlanes, long lo, long hi, long* idx_out, const long* perm,
-                                  long n, int* err, hipStream_t stream) {
+                                  long n, int* err, hipStream_t stream, bool defer = false) {
   HB_REQUIRE(narr >= 1 && narr <= HB_GATHER_MAX, "hb_gather_rows_multi_draw: %d arrays (max %d)", narr, HB_GATHER_MAX);
   HB_REQUIRE(n >= 0 && nsrc >= 0 && srcs && rows && dsts && state && idx_out, "hb_gather_rows_multi_draw: bad arguments");
   HB_REQUIRE(n <= nlanes, "hb_gather_rows_multi_draw: n=%ld exceeds the %ld RNG lanes (draw with hb_rng_randint instead)", n,
@@ -760,6 +727,20 @@ static int gather_rows_multi_draw(int narr, const T* const* srcs, const long* ro
   }
   if (n == 0) return 0;
   const uint64_t range = (uint64_t)(hi - lo);
+  if constexpr (sizeof(T) == 4) {
+    if (defer) {   // recorded for the next host launch (side_jobs.cuh)
+      HbSideJob j;
+      j.kind = HB_SIDE_GATHER_DRAW;
+      j.gather.G = wmax <= 2 ? 1 : (wmax <= 8 ? 4 : (wmax <= 32 ? 16 : 64));
+      j.nblocks = hb_cdiv(n * j.gather.G, 256);
+      if (j.nblocks <= 1024) {
+        memcpy(&j.gather.g, &g, sizeof(g));
+        j.gather.state = state; j.gather.nlanes = nlanes; j.gather.lo = lo; j.gather.range = range;
+        j.gather.idx_out = idx_out; j.gather.perm = perm; j.gather.n = n; j.gather.nsrc = nsrc; j.gather.err = err;
+        return hb_side_push(j, stream);
+      }
+    }
+  }
 #define HB_GDRAW(G_)                                                                                                   \
   hipLaunchKernelGGL((gather_rows_multi_draw_kernel<T, G_>), dim3((unsigned)hb_cdiv(n * G_, 256)), dim3(256), 0, stream, g, \
                      state, nlanes, lo, range, idx_out, perm, n, nsrc, err)
@@ -780,6 +761,12 @@ extern "C" int hb_gather_rows_multi_draw_f32(int narr, const float* const* srcs,
                                              const long* perm, long n, int* err, void* stream) {
   return gather_rows_multi_draw<float>(narr, srcs, rows, dsts, nsrc, state, nlanes, lo, hi, idx_out, perm, n, err,
                                        (hipStream_t)stream);
+}
+extern "C" int hb_side_push_gather_draw_f32(int narr, const float* const* srcs, const long* rows, float* const* dsts, long nsrc,
+                                           uint64_t* state, long nlanes, long lo, long hi, long* idx_out, const long* perm,
+                                           long n, int* err, void* stream) {
+  return gather_rows_multi_draw<float>(narr, srcs, rows, dsts, nsrc, state, nlanes, lo, hi, idx_out, perm, n, err,
+                                       (hipStream_t)stream, true);
 }
 extern "C" int hb_gather_rows_multi_draw_f64(int narr, const double* const* srcs, const long* rows, double* const* dsts,
                                              long nsrc, uint64_t* state, long nlanes, long lo, long hi, long* idx_out,

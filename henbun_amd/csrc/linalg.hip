@@ -7,6 +7,7 @@
 // they are hand-written for gfx950.
 #include "common.cuh"
 #include "sgp_rider.cuh"
+#include "side_jobs.cuh"
 #include "gemm_tile.cuh"
 #include "../../include/henbun_hip.h"
 
@@ -257,7 +258,11 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
 // ===========================================================================
 #define WGK_LD 33
 template <bool TA, bool TB, bool SYM>
-__global__ void __launch_bounds__(256) matmul_wgk_kernel(MmArgs<float> a) {
+__global__ void __launch_bounds__(256) matmul_wgk_kernel(MmArgs<float> a, int nown, HbSideJobs side) {
+  if ((int)blockIdx.x >= nown) {   // side jobs riding on this launch (side_jobs.cuh)
+    if (blockIdx.y == 0) hb_side_run(side, (int)blockIdx.x - nown);
+    return;
+  }
   typedef float V4 __attribute__((ext_vector_type(4)));
   typedef Mma<float> MM;
   __shared__ float red[SYM ? 8 : 4][32][WGK_LD];
@@ -429,13 +434,15 @@ template <>
 int matmul_wgk_launch<float>(const MmArgs<float>& a, int transA, int transB, hipStream_t stream) {
   const bool sym = (a.flags & HB_MM_SYM_OUT) != 0;
   const long nt = a.M / 32;
-  dim3 grid((unsigned)(sym ? nt * (nt + 1) / 2 : (a.M / 32) * (a.N / 32)), (unsigned)a.batch, 1);
-#define HB_WGK(TA_, TB_)                                                                         \
-  do {                                                                                           \
-    if (sym)                                                                                     \
-      hipLaunchKernelGGL((matmul_wgk_kernel<TA_, TB_, true>), grid, dim3(256), 0, stream, a);    \
-    else                                                                                         \
-      hipLaunchKernelGGL((matmul_wgk_kernel<TA_, TB_, false>), grid, dim3(256), 0, stream, a);   \
+  const int nown = (int)(sym ? nt * (nt + 1) / 2 : (a.M / 32) * (a.N / 32));
+  const HbSideJobs sj = hb_side_take();   // pending side jobs of this thread ride along as extra workgroups
+  dim3 grid((unsigned)(nown + sj.total), (unsigned)a.batch, 1);
+#define HB_WGK(TA_, TB_)                                                                                   \
+  do {                                                                                                     \
+    if (sym)                                                                                               \
+      hipLaunchKernelGGL((matmul_wgk_kernel<TA_, TB_, true>), grid, dim3(256), 0, stream, a, nown, sj);    \
+    else                                                                                                   \
+      hipLaunchKernelGGL((matmul_wgk_kernel<TA_, TB_, false>), grid, dim3(256), 0, stream, a, nown, sj);   \
   } while (0)
   if (!transA && !transB)
     HB_WGK(false, false);
@@ -1126,12 +1133,18 @@ static inline int chol64_grid(int nrt, int k, int inv) {
 __global__ void __launch_bounds__(SGP_RIDER_THREADS) chol_rl64_kernel(const float* __restrict__ Ain, float* __restrict__ L,
                                                                       float* __restrict__ Y, float* __restrict__ W, int M,
                                                                       int k, int* __restrict__ info, SgpRider rider,
-                                                                      int nown) {
+                                                                      int nown, HbSideJobs side) {
   // forward rider (sgp_rider.cuh): blocks past this launch's own grid compute rows [64(k-1), 64k) of A = W K(z, x)
   // from the row block of W that launch k-1 finished
   extern __shared__ __attribute__((aligned(16))) char hb_dyn_lds[];
   if ((int)blockIdx.x >= nown) {
-    sgp_rider_job(rider, W, M, k - 1, (int)blockIdx.x - nown, *reinterpret_cast<SgpRiderLds*>(hb_dyn_lds));
+    if (k == 0) {
+      // launch 0 of the chain keeps 8 workgroups busy: small independent launches of the step (minibatch draw +
+      // gather, the sample of q(u)) ride here as extra workgroups (side_jobs.cuh)
+      if (blockIdx.y == 0 && threadIdx.x < 256) hb_side_run(side, (int)blockIdx.x - nown);
+    } else {
+      sgp_rider_job(rider, W, M, k - 1, (int)blockIdx.x - nown, *reinterpret_cast<SgpRiderLds*>(hb_dyn_lds));
+    }
     return;
   }
   // a launch that carries riders has 512-thread workgroups (the riders' eight waves); the factorisation's own
@@ -1439,11 +1452,13 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, lon
         once = true;
       }
     }
+    HbSideJobs noside = {};
     for (int k = 0; k < nrt / 2; ++k) {
       const int nown = chol64_grid(nrt, k, inv);
-      dim3 grid((unsigned)(nown + ((ride && k > 0) ? rd.nS : 0)), (unsigned)B);
+      const HbSideJobs sj = k == 0 ? hb_side_take() : noside;   // pending side jobs of this thread ride on launch 0
+      dim3 grid((unsigned)(nown + ((ride && k > 0) ? rd.nS : 0) + (k == 0 ? sj.total : 0)), (unsigned)B);
       hipLaunchKernelGGL(chol_rl64_kernel, grid, dim3(ride ? SGP_RIDER_THREADS : 256), dyn, stream, (const float*)A, (float*)L,
-                         inv ? (float*)ws : (float*)nullptr, (float*)W, (int)M, k, info, rd, nown);
+                         inv ? (float*)ws : (float*)nullptr, (float*)W, (int)M, k, info, rd, nown, sj);
       HB_LAUNCH_CHECK();
     }
     // with riders every workgroup holds ~95 KB of LDS (one per CU): the finishing pass then runs 256 grid-stride blocks

@@ -1,6 +1,7 @@
 // Runtime plumbing of libhenbun_hip.so: error string, device info, hipGraph
 // capture/replay of a launch sequence.
 #include "common.cuh"
+#include "side_jobs.cuh"
 #include "../../include/henbun_hip.h"
 #include <stdarg.h>
 #include <stdio.h>
@@ -57,4 +58,42 @@ extern "C" int hb_graph_launch(void* exec, void* stream) {
 extern "C" int hb_graph_destroy(void* exec) {
   if (exec) HB_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Side jobs (side_jobs.cuh): the pending list of the calling thread, and the launch of their own that flushes it.
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local HbSideJobs hb_side_list = {};
+
+__global__ void __launch_bounds__(256) hb_side_jobs_kernel(HbSideJobs J) { hb_side_run(J, (int)blockIdx.x); }
+
+static int hb_side_launch(const HbSideJobs& J, hipStream_t stream) {
+  if (J.n == 0 || J.total == 0) return 0;
+  hipLaunchKernelGGL(hb_side_jobs_kernel, dim3((unsigned)J.total), dim3(256), 0, stream, J);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+HbSideJobs hb_side_take() {
+  HbSideJobs J = hb_side_list;
+  hb_side_list.n = 0;
+  hb_side_list.total = 0;
+  return J;
+}
+
+int hb_side_push(const HbSideJob& job, hipStream_t stream) {
+  if (hb_side_list.n == HB_SIDE_MAX) {   // full: what is pending runs now, as a launch of its own
+    const HbSideJobs J = hb_side_take();
+    const int rc = hb_side_launch(J, stream);
+    if (rc) return rc;
+  }
+  hb_side_list.job[hb_side_list.n++] = job;
+  hb_side_list.total += job.nblocks;
+  return 0;
+}
+
+extern "C" int hb_side_pending(void) { return hb_side_list.n; }
+extern "C" int hb_side_flush(void* stream) {
+  const HbSideJobs J = hb_side_take();
+  return hb_side_launch(J, (hipStream_t)stream);
 }

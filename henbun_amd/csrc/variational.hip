@@ -6,6 +6,7 @@
 // u in registers when drawn in-kernel) or (size^2+3*size)*B (full rank).
 #include "common.cuh"
 #include "rng_pairs.cuh"
+#include "side_jobs.cuh"  // diag_fwd_body, diag_bwd_body, the side-job list
 #include "../../include/henbun_hip.h"
 
 #define HB_KL_MAX_PARTIALS 2048
@@ -20,58 +21,7 @@ __global__ void __launch_bounds__(256) diag_fwd_kernel(const T* __restrict__ mu,
                                                        T* __restrict__ partial, T* __restrict__ kl, long n, long L,
                                                        long ldm, long lds_) {
   __shared__ T smem[16];
-  // element i = (row i / L, column i % L); mu / s may be column blocks of a wider row-major matrix (row strides ldm,
-  // lds_: the mean and log-std halves of an encoder output, read in place); x and u are dense
-  const bool dense = ldm == L && lds_ == L;
-  auto src = [&](long i, long ld) -> long {
-    if (dense) return i;
-    const long r = i / L;
-    return r * ld + (i - r * L);
-  };
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long nthreads = rng ? rng_lanes : (long)gridDim.x * blockDim.x;
-  const long npairs = (n + 1) / 2;
-  T acc = T(0);
-  const bool active = t < nthreads && t < npairs;
-  HbRng g;
-  if (rng && active) g = rng_load(rng, rng_lanes, t);
-  if (active) {
-    for (long p = t; p < npairs; p += nthreads) {
-      const long i0 = 2 * p, i1 = 2 * p + 1;
-      T u0, u1 = T(0);
-      if (rng) {
-        double z0, z1;
-        g.normal2(z0, z1);
-        u0 = (T)z0;
-        u1 = (T)z1;
-      } else {
-        u0 = u_in[i0];
-        if (i1 < n) u1 = u_in[i1];
-      }
-      {
-        const T sv = s[src(i0, lds_)];
-        const T xv = mu[src(i0, ldm)] + hb_exp(sv) * u0;
-        x[i0] = xv;
-        if (u_out) u_out[i0] = u0;
-        acc += T(2) * sv + u0 * u0 - xv * xv;
-      }
-      if (i1 < n) {
-        const T sv = s[src(i1, lds_)];
-        const T xv = mu[src(i1, ldm)] + hb_exp(sv) * u1;
-        x[i1] = xv;
-        if (u_out) u_out[i1] = u1;
-        acc += T(2) * sv + u1 * u1 - xv * xv;
-      }
-    }
-  }
-  if (rng && active) rng_store(rng, rng_lanes, t, g);
-  acc = block_sum(acc, smem);
-  if (threadIdx.x == 0) {
-    if (gridDim.x == 1)
-      kl[0] = T(-0.5) * acc;  // one block covers everything: no finishing pass
-    else
-      partial[blockIdx.x] = acc;
-  }
+  diag_fwd_body<T>(mu, s, u_in, rng, rng_lanes, u_out, x, partial, kl, n, L, ldm, lds_, (long)blockIdx.x, (long)gridDim.x, smem);
 }
 
 template <typename T>
@@ -85,7 +35,7 @@ __global__ void __launch_bounds__(256) kl_finish_kernel(const T* __restrict__ pa
 
 template <typename T>
 static int diag_fwd(const T* mu, const T* s, const T* u_in, uint64_t* rng, long rng_lanes, T* u_out, T* x, T* kl,
-                    long n, long L, long ldm, long lds_, T* ws, hipStream_t stream) {
+                    long n, long L, long ldm, long lds_, T* ws, hipStream_t stream, bool defer = false) {
   HB_REQUIRE(n >= 0, "hb_diag_sample_kl_fwd: n < 0");
   HB_REQUIRE(L >= 1 && ldm >= L && lds_ >= L && n % L == 0, "hb_diag_sample_kl_fwd: bad row layout (L=%ld, ld=%ld/%ld, n=%ld)",
              L, ldm, lds_, n);
@@ -102,6 +52,16 @@ static int diag_fwd(const T* mu, const T* s, const T* u_in, uint64_t* rng, long 
   // blocks past the last pair would only contribute zeros
   const int need = hb_cdiv((n + 1) / 2, 256);
   if (grid > need) grid = need > 0 ? need : 1;
+  if constexpr (sizeof(T) == 4) {
+    if (defer && grid == 1) {   // one workgroup: recorded for the next host launch (side_jobs.cuh)
+      HbSideJob j;
+      j.kind = HB_SIDE_DIAG_FWD;
+      j.nblocks = 1;
+      j.dfwd.mu = mu; j.dfwd.s = s; j.dfwd.u_in = u_in; j.dfwd.rng = rng; j.dfwd.rng_lanes = rng_lanes; j.dfwd.u_out = u_out;
+      j.dfwd.x = x; j.dfwd.kl = kl; j.dfwd.n = n; j.dfwd.L = L; j.dfwd.ldm = ldm; j.dfwd.lds = lds_;
+      return hb_side_push(j, stream);
+    }
+  }
   hipLaunchKernelGGL(diag_fwd_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, s, u_in, rng, rng_lanes, u_out, x, ws,
                      kl, n, L, ldm, lds_);
   HB_LAUNCH_CHECK();
@@ -117,6 +77,11 @@ extern "C" int hb_diag_sample_kl_fwd_f32(const float* mu, const float* s, const 
                                          long ld_s, float* ws, void* stream) {
   return diag_fwd<float>(mu, s, u_in, rng, rng_lanes, u_out, x, kl, n, L, ld_mu, ld_s, ws, (hipStream_t)stream);
 }
+extern "C" int hb_side_push_diag_fwd_f32(const float* mu, const float* s, const float* u_in, uint64_t* rng, long rng_lanes,
+                                        float* u_out, float* x, float* kl, long n, long L, long ld_mu, long ld_s, float* ws,
+                                        void* stream) {
+  return diag_fwd<float>(mu, s, u_in, rng, rng_lanes, u_out, x, kl, n, L, ld_mu, ld_s, ws, (hipStream_t)stream, true);
+}
 extern "C" int hb_diag_sample_kl_fwd_f64(const double* mu, const double* s, const double* u_in, uint64_t* rng,
                                          long rng_lanes, double* u_out, double* x, double* kl, long n, long L,
                                          long ld_mu, long ld_s, double* ws, void* stream) {
@@ -128,31 +93,27 @@ __global__ void __launch_bounds__(256) diag_bwd_kernel(const T* __restrict__ s, 
                                                        const T* __restrict__ x, const T* __restrict__ xbar,
                                                        const T* __restrict__ klbar, T* __restrict__ mubar,
                                                        T* __restrict__ sbar, long n, long L, long lds_, long ldo) {
-  const T kb = klbar ? klbar[0] : T(0);
-  const long stride = (long)gridDim.x * blockDim.x;
-  const bool dense = lds_ == L && ldo == L;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    // s read from, and the two gradients written into, column blocks of wider row-major matrices (see diag_fwd_kernel)
-    long is = i, io = i;
-    if (!dense) {
-      const long r = i / L, c = i - r * L;
-      is = r * lds_ + c;
-      io = r * ldo + c;
-    }
-    const T mb = (xbar ? xbar[i] : T(0)) + kb * x[i];
-    mubar[io] = mb;
-    sbar[io] = mb * hb_exp(s[is]) * u[i] - kb;
-  }
+  diag_bwd_body<T>(s, u, x, xbar, klbar, mubar, sbar, n, L, lds_, ldo, (long)blockIdx.x, (long)gridDim.x);
 }
 
 template <typename T>
 static int diag_bwd(const T* s, const T* u, const T* x, const T* xbar, const T* klbar, T* mubar, T* sbar, long n,
-                    long L, long lds_, long ldo, hipStream_t stream) {
+                    long L, long lds_, long ldo, hipStream_t stream, bool defer = false) {
   HB_REQUIRE(n >= 0, "hb_diag_sample_kl_bwd: n < 0");
   HB_REQUIRE(L >= 1 && lds_ >= L && ldo >= L && n % L == 0, "hb_diag_sample_kl_bwd: bad row layout (L=%ld, ld=%ld/%ld, n=%ld)", L,
              lds_, ldo, n);
   HB_REQUIRE(s && u && x && mubar && sbar, "hb_diag_sample_kl_bwd: NULL pointer");
   if (n == 0) return 0;
+  if constexpr (sizeof(T) == 4) {
+    if (defer && hb_stream_grid(n, 256) <= 64) {   // small: recorded for the next host launch (side_jobs.cuh)
+      HbSideJob j;
+      j.kind = HB_SIDE_DIAG_BWD;
+      j.nblocks = hb_stream_grid(n, 256);
+      j.dbwd.s = s; j.dbwd.u = u; j.dbwd.x = x; j.dbwd.xbar = xbar; j.dbwd.klbar = klbar; j.dbwd.mubar = mubar; j.dbwd.sbar = sbar;
+      j.dbwd.n = n; j.dbwd.L = L; j.dbwd.lds = lds_; j.dbwd.ldo = ldo;
+      return hb_side_push(j, stream);
+    }
+  }
   hipLaunchKernelGGL(diag_bwd_kernel<T>, dim3(hb_stream_grid(n, 256)), dim3(256), 0, stream, s, u, x, xbar, klbar,
                      mubar, sbar, n, L, lds_, ldo);
   HB_LAUNCH_CHECK();
@@ -162,6 +123,10 @@ extern "C" int hb_diag_sample_kl_bwd_f32(const float* s, const float* u, const f
                                          const float* klbar, float* mubar, float* sbar, long n, long L, long ld_s,
                                          long ld_out, void* stream) {
   return diag_bwd<float>(s, u, x, xbar, klbar, mubar, sbar, n, L, ld_s, ld_out, (hipStream_t)stream);
+}
+extern "C" int hb_side_push_diag_bwd_f32(const float* s, const float* u, const float* x, const float* xbar, const float* klbar,
+                                        float* mubar, float* sbar, long n, long L, long ld_s, long ld_out, void* stream) {
+  return diag_bwd<float>(s, u, x, xbar, klbar, mubar, sbar, n, L, ld_s, ld_out, (hipStream_t)stream, true);
 }
 extern "C" int hb_diag_sample_kl_bwd_f64(const double* s, const double* u, const double* x, const double* xbar,
                                          const double* klbar, double* mubar, double* sbar, long n, long L, long ld_s,

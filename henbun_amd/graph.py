@@ -887,8 +887,16 @@ def _matmul_emit(plan, node):
         # third input = the activation output Y: C = (op(A) op(B)) * act'(Y)
         plan.steps.append(lambda: H.matmul(a, b, transA=at["ta"], transB=at["tb"], act=at["actgrad"], actgrad=bias, out=out))
         return
+    # the in-workgroup split-K form (small square-ish fp32 products: the Cholesky VJP) hosts pending side jobs
+    ysh = y.shape
+    kk = node.inputs[0].shape[-2] if at["ta"] else node.inputs[0].shape[-1]
+    wgk_like = (plan.dtype == plan.torch.float32 and bias is None and ysh[-1] % 32 == 0 and ysh[-2] % 32 == 0 and kk % 128 == 0
+                and 128 <= kk <= 4096 and (ysh[-1] // 32) * (ysh[-2] // 32) * int(np.prod(ysh[:-2]) if len(ysh) > 2 else 1) <= 1024)
+    host = wgk_like and plan.attach_side(node)
     plan.steps.append(lambda: H.matmul(a, b, transA=at["ta"], transB=at["tb"], bias=bias, act=at["act"], out=out,
                                        epilogue=epi))
+    if host:
+        plan.steps.append(lambda: H.side_flush())
 
 
 def _sum_lead(g, t):
@@ -1042,7 +1050,11 @@ def _cholesky_emit(plan, node):
             # carries its forward contraction: see _sgp_emit and csrc/sgp_rider.cuh
             plan._chol_rider[rider.id] = dict(a=a, out=out, inv=w, info=info, ws=ws, frag=frag, node=node)
             return
+        # launch 0 of the 64-column chain hosts pending side jobs (minibatch gather, the sample of q(u))
+        host = plan.dtype == plan.torch.float32 and M % 64 == 0 and plan.attach_side(node)
         plan.steps.append(lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws, frag=frag, frag_bf16x3=bf3))
+        if host:
+            plan.steps.append(lambda: H.side_flush())
         return
     plan.steps.append(lambda: H.cholesky(a, out=out, info=info))
 
@@ -1191,7 +1203,8 @@ def _diag_skl_emit(plan, node):
     if ldm is not None or lds is not None:
         nrows, L = node.inputs[0].shape
         rows = (nrows, L, ldm or L, lds or L)
-    plan.steps.append(lambda: H.diag_sample_kl_fwd(mu, s, u_in=u_in, rng=rng, out=(x, kl, u), rows=rows))
+    cell = plan.side_candidate(list(node.outputs))
+    plan.steps.append(lambda: H.diag_sample_kl_fwd(mu, s, u_in=u_in, rng=rng, out=(x, kl, u), rows=rows, defer=cell["defer"]))
 
 
 def _diag_skl_vjp(node, gs):
@@ -1242,7 +1255,9 @@ def _diag_skl_grad_emit(plan, node):
         rows = (nrows, L, lds or L, 2 * L if packed is not None else L)
     else:
         outs, rows = tuple(plan.out(t) for t in node.outputs), None
-    plan.steps.append(lambda: H.diag_sample_kl_bwd(s, u, x, xbar, klbar, out=outs, rows=rows))
+    cand_outs = list(node.outputs) + ([c0[0].outputs[0]] if packed is not None else [])
+    cell = plan.side_candidate(cand_outs)
+    plan.steps.append(lambda: H.diag_sample_kl_bwd(s, u, x, xbar, klbar, out=outs, rows=rows, defer=cell["defer"]))
 
 
 defop("diag_sample_kl", _diag_skl_emit, _diag_skl_vjp)
@@ -1832,12 +1847,25 @@ class Plan:
             for t in n.inputs:
                 consumers.setdefault(t, []).append(n)
         self._consumers = consumers
+        self._emitted: List[Node] = []      # nodes in emission order
+        self._side_cands: List[dict] = []   # small independent steps that may ride on a later host launch (side jobs)
+        # minibatch gathers first: they depend on nothing, and emitted early they can ride on the first launch of the
+        # Cholesky chain instead of being a launch of their own right before their first consumer
+        hoisted = set()
+        if self.side_jobs_enabled():
+            for n in order:
+                if n.op == "leaf:minibatch":
+                    self._emit(n)
+                    hoisted.add(n.id)
         for n in order:
+            if n.id in hoisted:
+                continue
             c = self._clusters.get(n.id)
             if c is None or len(c.nodes) < 2:
                 self._emit(n)
             elif n is c.nodes[-1]:
                 self._emit_cluster(c)
+                self._emitted.extend(c.nodes)
         # outputs that could not be bound in place: explicit copy
         for t, b in list(self._bind.items()) + self._extra_copies:
             got = self._buf.get(t)
@@ -1881,6 +1909,49 @@ class Plan:
 
     def scratch(self, shape):
         return self.torch.empty(tuple(shape), dtype=self.dtype, device=self.device)
+
+    # -- side jobs (csrc/side_jobs.cuh): small independent steps recorded instead of launched, riding on a host launch
+    def side_jobs_enabled(self):
+        from ._settings import settings as _st
+
+        return bool(getattr(_st.runtime, "side_jobs", True)) and self.dtype == self.torch.float32
+
+    def side_candidate(self, outs):
+        """Register the step about to be appended as deferrable; returns the cell its closure must consult
+        (`cell["defer"]` turns True when a later host launch adopts the step).  `outs`: the tensors it writes (a list
+        that may still grow)."""
+        cell = {"defer": False}
+        self._side_cands.append(dict(cell=cell, outs=outs, epos=len(self._emitted)))
+        return cell
+
+    def attach_side(self, host_node):
+        """Called by a host-capable op before it appends its step: adopt the pending candidates whose outputs nobody
+        reads between their position and the host (the host included).  True when at least one was adopted -- the
+        caller then appends H.side_flush() after its own step (a no-op when the host launch took the jobs)."""
+        if not self.side_jobs_enabled():
+            return False
+        adopted = 0
+        for c in self._side_cands:
+            if c["cell"]["defer"] or c.get("dead"):
+                continue
+            outs = set(c["outs"])
+            busy = False
+            for nd in self._emitted[c["epos"] + 1:]:
+                if not any(t in outs for t in nd.inputs):
+                    continue
+                if nd.op in ("reshape", "stop_gradient"):
+                    outs.update(nd.outputs)   # a view of the same buffer: nothing is read yet
+                else:
+                    busy = True
+                    break
+            if busy or any(t in outs for t in host_node.inputs):
+                c["dead"] = True   # somebody needs it before any later host could run it
+                continue
+            c["cell"]["defer"] = True
+            adopted += 1
+            if adopted == 3:
+                break
+        return adopted > 0
 
     def new_info(self, n, label):
         """`n` LAPACK-style status words for one (batched) factorisation, carved from one pool so that the
@@ -1927,6 +1998,7 @@ class Plan:
                 self.steps.append(step)
             else:
                 self._buf[t] = self._leaf_resolver(t)
+            self._emitted.append(n)
             return
         d = OPS.get(n.op)
         if d is None or d.emit is None:
@@ -1938,6 +2010,7 @@ class Plan:
             if id(s) not in self.step_labels:   # (a deferred step appended on behalf of another node keeps its own label)
                 self.step_labels[id(s)] = label
                 self.step_nodes[id(s)] = n
+        self._emitted.append(n)
 
     def _emit_cluster(self, c):
         """One hb_ewise_prog launch for the whole cluster."""

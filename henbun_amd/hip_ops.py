@@ -319,9 +319,11 @@ class MultiGather:
         _lib.lib().call("hb_gather_rows_multi" + self.suf, self.narr, self.srcs, self.rows, self.dsts, self.nsrc,
                         _p(self.idx), _p(self.perm if use_perm else None), self.n, _p(self.err), stream())
 
-    def launch_draw(self, rng, lo, hi, use_perm=True):
-        """draw idx ~ U{lo..hi-1} from `rng` (as rng.randint would) and gather, in one launch; needs n <= rng.nlanes"""
-        _lib.lib().call("hb_gather_rows_multi_draw" + self.suf, self.narr, self.srcs, self.rows, self.dsts, self.nsrc,
+    def launch_draw(self, rng, lo, hi, use_perm=True, defer=False):
+        """draw idx ~ U{lo..hi-1} from `rng` (as rng.randint would) and gather, in one launch; needs n <= rng.nlanes.
+        defer: recorded as a side job of the next host launch (fp32 only) instead of launched now."""
+        name = "hb_side_push_gather_draw_f32" if (defer and self.suf == "_f32") else "hb_gather_rows_multi_draw" + self.suf
+        _lib.lib().call(name, self.narr, self.srcs, self.rows, self.dsts, self.nsrc,
                         _p(rng.state), rng.nlanes, int(lo), int(hi), _p(self.idx), _p(self.perm if use_perm else None),
                         self.n, _p(self.err), stream())
 
@@ -370,7 +372,16 @@ def _rng_args(rng):
 
 
 # ---- K1/K2 variational sampler + MC-KL --------------------------------------
-def diag_sample_kl_fwd(mu, s, u_in=None, rng=None, out=None, rows=None):
+def side_flush():
+    """Launch whatever side jobs are still pending on this thread (hb_side_flush); a no-op when a host launch took them."""
+    _lib.lib().call("hb_side_flush", stream())
+
+
+def side_pending():
+    return int(_lib.lib().raw("hb_side_pending")())
+
+
+def diag_sample_kl_fwd(mu, s, u_in=None, rng=None, out=None, rows=None, defer=False):
     """x = mu + exp(s)*u ; kl = -0.5*sum(2s + u^2 - x^2).  Returns (x, kl, u).
     rows=(nrows, L, ld_mu, ld_s): mu and s are column blocks of wider row-major matrices (1-D views starting at their
     first element), read in place; x and u are dense [nrows, L] (out= is then required)."""
@@ -389,12 +400,13 @@ def diag_sample_kl_fwd(mu, s, u_in=None, rng=None, out=None, rows=None):
         x, kl, u = out
     ws = workspace(mu.dtype, mu.device)
     rp, rl = _rng_args(rng)
-    _lib.lib().call("hb_diag_sample_kl_fwd" + _suf(mu), _p(mu), _p(s), _p(u_in), rp, rl, _p(u), _p(x), _p(kl), n,
-                    L, ldm, lds, _p(ws), stream())
+    # defer: recorded as a side job of the next host launch (hb_side_push_*; fp32 only) instead of launched now
+    name = "hb_side_push_diag_fwd_f32" if (defer and mu.dtype == torch.float32) else "hb_diag_sample_kl_fwd" + _suf(mu)
+    _lib.lib().call(name, _p(mu), _p(s), _p(u_in), rp, rl, _p(u), _p(x), _p(kl), n, L, ldm, lds, _p(ws), stream())
     return x, kl, u
 
 
-def diag_sample_kl_bwd(s, u, x, xbar, klbar, out=None, rows=None):
+def diag_sample_kl_bwd(s, u, x, xbar, klbar, out=None, rows=None, defer=False):
     """rows=(nrows, L, ld_s, ld_out): s read, mubar/sbar written, as column blocks of wider matrices (see _fwd)."""
     if rows is None:
         n = s.numel()
@@ -408,8 +420,8 @@ def diag_sample_kl_bwd(s, u, x, xbar, klbar, out=None, rows=None):
         mubar, sbar = _empty_like(s), _empty_like(s)
     else:
         mubar, sbar = out
-    _lib.lib().call("hb_diag_sample_kl_bwd" + _suf(s), _p(s), _p(u), _p(x), _p(xbar), _p(klbar), _p(mubar), _p(sbar),
-                    n, L, lds, ldo, stream())
+    name = "hb_side_push_diag_bwd_f32" if (defer and s.dtype == torch.float32) else "hb_diag_sample_kl_bwd" + _suf(s)
+    _lib.lib().call(name, _p(s), _p(u), _p(x), _p(xbar), _p(klbar), _p(mubar), _p(sbar), n, L, lds, ldo, stream())
     return mubar, sbar
 
 

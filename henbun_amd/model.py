@@ -188,7 +188,7 @@ class Optimizer:
         return (n.jitter_level, n.clip_by_value, n.clip_value_min, n.clip_value_max, str(getattr(n, "kl_form", "mc")), str(getattr(n, "contraction", "native")),
                 str(settings.runtime.index_source), bool(settings.runtime.fuse_elementwise),
                 bool(getattr(settings.runtime, "force_dp", False)), bool(getattr(settings.runtime, "chol_rider", False)),
-                str(getattr(settings.runtime, "ewise", "jit")))
+                str(getattr(settings.runtime, "ewise", "jit")), bool(getattr(settings.runtime, "side_jobs", True)))
 
     @staticmethod
     def _dp_active(sess):

@@ -254,6 +254,9 @@ class Session:
                     # first array (the list is complete by the time the plan runs)
                     if "arrays" not in feeder:
                         feeder["arrays"] = []
+                        feeder["leaves"] = []
+                        # the fused draw + gather launch may ride on a later host launch (side jobs, graph.Plan)
+                        feeder["cell"] = plan.side_candidate(feeder["leaves"])
 
                         def gather():
                             mg = feeder.get("mg")
@@ -267,7 +270,8 @@ class Session:
                             fused = (mg and feeder.get("draw") and not feeder.get("drawn") and not plan.indices_injected
                                      and n <= feeder["draw"][0].nlanes)
                             if fused:
-                                mg.launch_draw(feeder["draw"][0], 0, feeder["draw"][1], use_perm=not plan.indices_raw)
+                                mg.launch_draw(feeder["draw"][0], 0, feeder["draw"][1], use_perm=not plan.indices_raw,
+                                               defer=feeder["cell"]["defer"])
                             elif mg:
                                 mg.launch(use_perm=not plan.indices_raw)
                             else:
@@ -276,6 +280,7 @@ class Session:
 
                         plan.steps.append(gather)
                     feeder["arrays"].append((full, out))
+                    feeder["leaves"].append(t)
                     plan.gather_err = err
                     return out
                 raise RuntimeError("unknown leaf kind " + kind)

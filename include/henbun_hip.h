@@ -450,6 +450,26 @@ int hb_adam_step_f64(double* theta, const double* g, double* m, double* v, long 
                      double b1, double b2, double eps, double gscale, long* t, int tick,
                      const int* info, long n_info, const double* dpflag, long* fail, void* stream);
 
+/* ---- side jobs: small independent launches riding on another kernel's launch (csrc/side_jobs.cuh) --------------
+ * hb_side_push_* take the arguments of their stand-alone twins (hb_gather_rows_multi_draw_f32,
+ * hb_diag_sample_kl_fwd_f32, hb_diag_sample_kl_bwd_f32) but RECORD the job in a per-thread list instead of launching
+ * it (a job that does not fit the side form -- more than one workgroup for the sampler, fp64 -- is launched at
+ * once, as the twin would).  The next host launch issued by the same thread -- launch 0 of hb_cholesky /
+ * hb_cholesky_inverse on the 64-column fp32 path, hb_matmul on its in-workgroup split-K path -- appends the recorded
+ * jobs' workgroups to its own grid.  hb_side_flush launches whatever is still pending as one kernel of its own, so
+ * push ... host ... flush is always equivalent to the stand-alone calls provided nobody reads the jobs' outputs
+ * before the host launch has run.  hb_side_pending: number of recorded jobs (at most 3; a fourth push flushes). */
+int hb_side_push_gather_draw_f32(int narr, const float* const* srcs, const long* rows, float* const* dsts, long nsrc,
+                                 uint64_t* state, long nlanes, long lo, long hi, long* idx_out, const long* perm,
+                                 long n, int* err, void* stream);
+int hb_side_push_diag_fwd_f32(const float* mu, const float* s, const float* u_in, uint64_t* rng, long rng_lanes,
+                              float* u_out, float* x, float* kl, long n, long L, long ld_mu, long ld_s, float* ws,
+                              void* stream);
+int hb_side_push_diag_bwd_f32(const float* s, const float* u, const float* x, const float* xbar, const float* klbar,
+                              float* mubar, float* sbar, long n, long L, long ld_s, long ld_out, void* stream);
+int hb_side_pending(void);
+int hb_side_flush(void* stream);
+
 /* ---- data-parallel exchange step (no reference counterpart: the reference is one tf.Session on one
  *      device, model.py:57,255-269) --------------------------------------------------
  * One process per GPU; the ranks exchange ONE all-reduce (sum) of the flat gradient buffer per Adam

@@ -773,6 +773,74 @@ def test_cholesky_chain_carries_the_forward_contraction(H, M, n, d, P, mode):
     assert_close(v1, v0, dict(rtol=1e-4, atol=1e-4))
 
 
+def test_side_jobs_ride_on_a_host_launch_and_flush_otherwise(H):
+    """hb_side_push_*: the minibatch draw + gather, the diagonal sampler and its VJP recorded instead of launched, then
+    (a) adopted by launch 0 of the Cholesky chain, (b) adopted by the in-workgroup split-K GEMM, (c) flushed as a
+    launch of their own, (d) a fourth push flushing the first three -- every time the same bits as the stand-alone
+    entry points on the same RNG states."""
+    dt = torch.float32
+    rng_np = np.random.RandomState(3)
+    N, n, Msz = 5000, 700, 512
+    X, Y = dev(rng_np.randn(N, 1), dt), dev(rng_np.randn(N, 3), dt)
+    perm = torch.as_tensor(rng_np.permutation(N)[:4000]).cuda()
+    mu, s = dev(0.1 * rng_np.randn(Msz), dt), dev(0.1 * rng_np.randn(Msz) - 1.0, dt)
+    xbar, klbar = dev(rng_np.randn(Msz), dt), dev(np.array([-1.0]), dt)
+    K = H.gram_fwd(dev(np.linspace(0, 100, 256)[:, None], dt), dev(np.linspace(0, 100, 256)[:, None], dt),
+                   torch.ones(1, device="cuda"), diag_add=1e-2)
+    A_, B_ = dev(rng_np.randn(128, 256), dt), dev(rng_np.randn(256, 64), dt)
+
+    def jobs(defer, seed):
+        r1, r2 = H.Rng(seed, 1, device="cuda"), H.Rng(seed, 2, device="cuda")
+        xo, yo = torch.empty(n, 1, dtype=dt, device="cuda"), torch.empty(n, 3, dtype=dt, device="cuda")
+        idx = torch.zeros(n, dtype=torch.int64, device="cuda")
+        err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        mg = H.MultiGather([X, Y], [xo, yo], idx, perm, err)
+        mg.launch_draw(r1, 0, 4000, defer=defer)
+        x, kl, u = H.diag_sample_kl_fwd(mu, s, rng=r2, defer=defer)
+        return dict(xo=xo, yo=yo, idx=idx, x=x, kl=kl, u=u, r1=r1.state, r2=r2.state, keep=(mg, r1, r2))
+
+    def same(a, b):
+        for k in ("xo", "yo", "idx", "x", "kl", "u", "r1", "r2"):
+            assert torch.equal(a[k], b[k]), k
+
+    ref = jobs(False, 11)
+    assert H.side_pending() == 0
+    # (a) riding on the Cholesky chain
+    got = jobs(True, 11)
+    assert H.side_pending() == 2
+    L1, W1, _ = H.cholesky_inverse(K)
+    assert H.side_pending() == 0
+    torch.cuda.synchronize()
+    same(ref, got)
+    L0, W0, _ = H.cholesky_inverse(K)
+    assert torch.equal(L0, L1) and torch.equal(W0, W1)
+    # (b) the sampler's VJP riding on the small-GEMM kernel
+    mb0, sb0 = H.diag_sample_kl_bwd(s, ref["u"], ref["x"], xbar, klbar)
+    mb1, sb1 = H.diag_sample_kl_bwd(s, ref["u"], ref["x"], xbar, klbar, defer=True)
+    assert H.side_pending() == 1
+    C1 = H.matmul(A_, B_)
+    assert H.side_pending() == 0
+    torch.cuda.synchronize()
+    assert torch.equal(mb0, mb1) and torch.equal(sb0, sb1) and torch.equal(C1, H.matmul(A_, B_))
+    # (c) nobody adopts them: flush
+    got = jobs(True, 11)
+    H.side_flush()
+    assert H.side_pending() == 0
+    torch.cuda.synchronize()
+    same(ref, got)
+    H.side_flush()   # nothing pending: a no-op
+    # (d) a fourth push runs the first three
+    got = jobs(True, 11)
+    mb2, sb2 = H.diag_sample_kl_bwd(s, ref["u"], ref["x"], xbar, klbar, defer=True)
+    assert H.side_pending() == 3
+    mb3, sb3 = H.diag_sample_kl_bwd(s, ref["u"], ref["x"], xbar, klbar, defer=True)
+    assert H.side_pending() == 1
+    H.side_flush()
+    torch.cuda.synchronize()
+    same(ref, got)
+    assert torch.equal(mb0, mb2) and torch.equal(mb0, mb3) and torch.equal(sb0, sb3)
+
+
 def test_bf16x3_contraction_has_fp32_accuracy(H):
     """HB_PREC_BF16X3 (BASELINE cfg 5's "fp16-with-fp32-accum" variant in a usable form): A = L^-1 K(z,x) with every
     operand split into three bf16 terms on v_mfma_f32_32x32x16_bf16 is as close to the fp64 result as the fp32-operand
