@@ -1,3 +1,6 @@
+#!/bin/bash
+# Every measurement the round's profiles/ files come from, in one GPU call:  gpurun -- 'bash tools/final_measurements.sh'
+# Outputs under gpurun_out/r2final/ (copy what is to be kept into profiles/r02_*).
 set -e
 o=gpurun_out/r2final
 mkdir -p $o
@@ -11,10 +14,7 @@ python tools/bw_rows.py > $o/bw_rows.txt 2>/dev/null
 python tools/dump_plan.py cfg2 > $o/plan_cfg2.txt 2>/dev/null
 tools/pmc_traffic.sh r2final/pmc_cfg2 > /dev/null 2>&1
 tools/pmc_traffic.sh r2final/pmc_cfg3 --config cfg3 > /dev/null 2>&1
-tools/pmc_traffic.sh r2final/pmc_cfg5 --config cfg5 > /dev/null 2>&1
-timeout -k 5 60 tools/_bin/chol_stamps > $o/chol_stamps.txt 2>&1 || true
-timeout -k 5 60 tools/_bin/ss > $o/strip_stamps.txt 2>&1 || true
-timeout -k 5 60 tools/_bin/rs > $o/rider_stamps.txt 2>&1 || true
+for t in chol_stamps ss rs; do [ -x tools/_bin/$t ] && (timeout -k 5 60 tools/_bin/$t > $o/$t.txt 2>&1 || true); done
 tools/trace_rider.sh > $o/rider_trace.txt 2>&1 || true
 python tools/jit_vs_interp.py > $o/jit_vs_interp.txt 2>/dev/null || true
-head -c 400 $o/bench_cfg2.json
+head -c 300 $o/bench_cfg2.json
