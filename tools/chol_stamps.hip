@@ -23,6 +23,15 @@ int main() {
   (void)hipMalloc(&A, M * M * 4); (void)hipMalloc(&L, M * M * 4); (void)hipMalloc(&W, M * M * 4); (void)hipMalloc(&ws, M * M * 4);
   (void)hipMalloc(&info, 4);
   (void)hipMemcpy(A, h.data(), M * M * 4, hipMemcpyHostToDevice);
+  {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 5; ++rep) hb_cholesky_inverse_f32(A, L, W, 1, M, info, ws, nullptr, 0, 0);
+    (void)hipEventRecord(e0);
+    for (int rep = 0; rep < 100; ++rep) hb_cholesky_inverse_f32(A, L, W, 1, M, info, ws, nullptr, 0, 0);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("hb_cholesky_inverse_f32, M = %d: %.1f us per call (back-to-back stream launches)\n", M, ms * 10.0);
+  }
   for (int inv = 0; inv < 2; ++inv) {
     for (int rep = 0; rep < 3; ++rep) {
       if (inv) hb_cholesky_inverse_f32(A, L, W, 1, M, info, ws, nullptr, 0, 0);
