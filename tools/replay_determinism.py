@@ -42,12 +42,10 @@ else:
 opt = m.ELBO()
 m.initialize()
 sess = m._session
-sess.world_size = 2          # graph = forward + backward only (no Adam): state stays fixed
+# forward + backward only (the plan behind Optimizer.gradients: no Adam, so the state stays fixed between replays)
 opt.compile(optimizer=tf.train.AdamOptimizer(1e-3))
-plan = opt._get_plan("opt", n, True) if hasattr(opt, "_get_plan") else None
-if plan is None:
-    opt.optimize(maxiter=0, minibatch_size=n)
-    plan = [p for k, p in opt._plans.items() if k[0] == "opt"][0]
+opt.gradients(minibatch_size=n)
+plan = opt.last_plan
 states = {k: r.state.clone() for k, r in sess.rngs.items()}
 def replay():
     for k, r in sess.rngs.items():
@@ -55,7 +53,7 @@ def replay():
     torch.cuda.synchronize()
     plan.run()
     torch.cuda.synchronize()
-    return plan.gflat.clone()
+    return torch.cat([plan._buf[t].reshape(-1).to(torch.float64) for t in plan.outputs])
 g0 = replay()
 print("first replay: |g| %.6g finite %s" % (g0.norm().item(), bool(torch.isfinite(g0).all())), flush=True)
 bad, it, t0 = 0, 0, time.time()
