@@ -1668,7 +1668,9 @@ def gradients(loss: Tensor, wrt: Sequence[Tensor]) -> List[Optional[Tensor]]:
 # ------------------------------------------------------------------------------
 # elementwise clustering: chains / groups of elementwise nodes -> one interpreted launch
 # ------------------------------------------------------------------------------
-EW_CLUSTER_MAX_ELEMS = 1 << 16   # larger tensors keep one specialised launch per op
+EW_CLUSTER_MAX_ELEMS = 1 << 16   # interpreted programs: larger tensors keep one specialised launch per op (the LDS
+                                 # register file caps the interpreter at 256 threads x 40 registers per workgroup)
+EW_CLUSTER_MAX_ELEMS_JIT = 1 << 26   # compiled programs run from registers at full occupancy: no such limit
 EW_CLUSTER_MAX_INSTR = 44
 EW_CLUSTER_MAX_IN = 12
 EW_CLUSTER_MAX_OUT = 6
@@ -1715,7 +1717,7 @@ class _Cluster:
         self.nodes, self.space, self.sealed, self.ninstr, self.reduced = [], (), False, 0, set()
 
 
-def cluster_elementwise(order, enabled=True):
+def cluster_elementwise(order, enabled=True, max_elems=EW_CLUSTER_MAX_ELEMS):
     """Greedy clustering over a topological order.  A node joins the cluster of one of its
     elementwise producers (or, failing that, any open cluster with a compatible iteration
     space); a cluster is sealed as soon as a non-member consumes one of its values, so the
@@ -1726,7 +1728,7 @@ def cluster_elementwise(order, enabled=True):
     open_clusters = []
     for n in order:
         joined = None
-        if _fusable(n) and len(_squeeze_shape(n.outputs[0].shape)) <= 4 and n.outputs[0].size <= EW_CLUSTER_MAX_ELEMS:
+        if _fusable(n) and len(_squeeze_shape(n.outputs[0].shape)) <= 4 and n.outputs[0].size <= max_elems:
             cands = []
             for t in n.inputs:
                 c = member.get(t.node.id)
@@ -1737,7 +1739,7 @@ def cluster_elementwise(order, enabled=True):
                 if any(t in c.reduced for t in n.inputs):
                     continue  # a reduced value is only complete when its whole program has run
                 sp = _merge_space(c.space, n.outputs[0].shape)
-                if sp is None or len(_squeeze_shape(sp)) > 4 or int(np.prod(sp) if sp else 1) > EW_CLUSTER_MAX_ELEMS:
+                if sp is None or len(_squeeze_shape(sp)) > 4 or int(np.prod(sp) if sp else 1) > max_elems:
                     continue
                 if c.ninstr + 1 > EW_CLUSTER_MAX_INSTR:
                     continue
@@ -1841,7 +1843,8 @@ class Plan:
         from ._settings import settings as _st
 
         fuse = bool(getattr(_st.runtime, "fuse_elementwise", True))
-        self._clusters = cluster_elementwise(order, enabled=fuse)
+        self._clusters = cluster_elementwise(order, enabled=fuse,
+                                             max_elems=EW_CLUSTER_MAX_ELEMS_JIT if hip_ops.ewise_jit_enabled() else EW_CLUSTER_MAX_ELEMS)
         consumers = {}
         for n in order:
             for t in n.inputs:
