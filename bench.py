@@ -221,10 +221,12 @@ def time_steps_standalone(plan, torch, iters=40):
                 continue
             for _ in range(3):
                 s()
+            plan.H.side_flush()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             for _ in range(iters):
                 s()
+            plan.H.side_flush()   # a step that only RECORDS a side job (hb_side_push_*): run what it recorded here
             e1.record(st)
             st.synchronize()
             out.append((plan.step_labels.get(id(s), "other"), plan.step_nodes.get(id(s)), e0.elapsed_time(e1) * 1e3 / iters))
