@@ -86,6 +86,7 @@ gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const
   // side 0: block row i of X, loop j over X2; side 1: block row j of X2, loop i over X;
   // side 2: X2 IS X (same points): side 0 whose point gradient also takes the transposed entry Kbar[j,i],
   // i.e. the sum of both sides in one pass (the lengthscale partial still counts every pair once).
+  // side 3: side 2 for a SYMMETRIC Kbar (HB_KERN_KBAR_SYMMETRIC).
   __shared__ T smem[16];
   const long b = blockIdx.y;
   const long row = blockIdx.x;
@@ -113,7 +114,9 @@ gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const
       const T km = kind == HB_KERN_SQDIST ? T(-2) : hb_exp(T(-0.5) * r2);
       const T kp = kind == HB_KERN_CSYM_RBF ? hb_exp(T(-0.5) * r2m) : T(0);
       const T em = kb * km, ep = kb * kp;
-      const T kbg = side == 2 ? kb + Kbar[(b * n + j) * n2 + i] : kb;  // point gradient: both orientations
+      // point gradient: both orientations (side 3: Kbar is symmetric -- the Cholesky VJP's output -- so the
+      // transposed entry, a strided read of one cache line per thread, is the entry itself)
+      const T kbg = side == 2 ? kb + Kbar[(b * n + j) * n2 + i] : (side == 3 ? kb + kb : kb);
       const T gm = kbg * km, gp = kbg * kp;
 #pragma unroll
       for (int k = 0; k < HB_GRAM_MAXD; ++k) {
@@ -165,9 +168,10 @@ __global__ void __launch_bounds__(256) gram_ell_finish_kernel(const T* __restric
 }
 
 template <typename T>
-static int gram_bwd(int kind, const T* X, long sX, const T* X2, long sX2, const T* ell, long sEll, long dl,
+static int gram_bwd(int kind_flags, const T* X, long sX, const T* X2, long sX2, const T* ell, long sEll, long dl,
                     const T* Kbar, T* Xbar, T* X2bar, T* ellbar, long B, long n, long n2, long d, T* ws,
                     hipStream_t stream) {
+  const int kind = kind_flags & ~HB_KERN_KBAR_SYMMETRIC;
   HB_REQUIRE(kind >= HB_KERN_RBF && kind <= HB_KERN_SQDIST, "hb_gram_bwd: unknown kernel kind %d", kind);
   HB_REQUIRE(B >= 0 && n >= 0 && n2 >= 0 && d >= 1, "hb_gram_bwd: bad extents");
   HB_REQUIRE(dl == 1 || dl == d, "hb_gram_bwd: lengthscales must have 1 or d entries");
@@ -184,10 +188,12 @@ static int gram_bwd(int kind, const T* X, long sX, const T* X2, long sX2, const 
   }
   // X2bar == Xbar: X2 is X and the caller wants the total point gradient in one array
   const bool sym = Xbar && X2bar == Xbar;
+  const bool kbar_sym = (kind_flags & HB_KERN_KBAR_SYMMETRIC) != 0;
+  HB_REQUIRE(!kbar_sym || sym, "hb_gram_bwd: HB_KERN_KBAR_SYMMETRIC only applies to the one-pass form (X2 == X, X2bar == Xbar)");
   HB_REQUIRE(!sym || (X == X2 && sX == sX2 && n == n2), "hb_gram_bwd: Xbar == X2bar requires X2 == X");
   // side 0 pass also produces the lengthscale partials
   if (Xbar || ellbar) {
-    hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n, B), dim3(256), 0, stream, kind, sym ? 2 : 0, X, sX, X2, sX2, ell, sEll,
+    hipLaunchKernelGGL(gram_bwd_side_kernel<T>, dim3(n, B), dim3(256), 0, stream, kind, sym ? (kbar_sym ? 3 : 2) : 0, X, sX, X2, sX2, ell, sEll,
                        dl, Kbar, Xbar, ellbar ? ws : (T*)nullptr, n, n2, d);
     HB_LAUNCH_CHECK();
     if (ellbar) {

@@ -1122,7 +1122,9 @@ def _cholesky_vjp(node, gs):
     L = node.outputs[0]
     W = trinv(L)
     P = matutil(matmul(L, band_part(g, -1, 0), transpose_a=True), 4)
-    return [matmul(matmul(W, P, transpose_a=True), W)]
+    res = matmul(matmul(W, P, transpose_a=True), W)
+    res.node.attrs["sym_result"] = True   # L^-T Psym L^-1: symmetric (to rounding); gram_grad then skips the transposed reads
+    return [res]
 
 
 defop("cholesky", _cholesky_emit, _cholesky_vjp)
@@ -1423,9 +1425,11 @@ def _gram_grad_emit(plan, node):
         tmp = plan.scratch((B, n, d)) if (BX == 1 and B > 1) else None
         ws = plan.scratch((max(B * n * d, 1),))
 
+        ksym = k | (H.KERN_KBAR_SYMMETRIC if tg.node.attrs.get("sym_result") else 0)
+
         def sym_step():
             dst = tmp if tmp is not None else oX
-            H.gram_bwd_raw(k, X, sX, X2, sX2, ell, sEll, dl, g, dst, dst, oL, B, n, n2, d, ws)
+            H.gram_bwd_raw(ksym, X, sX, X2, sX2, ell, sEll, dl, g, dst, dst, oL, B, n, n2, d, ws)
             if tmp is not None:
                 H.reduce_mid(tmp, 1, B, n * d, out=oX)
 

@@ -28,6 +28,7 @@ EW = dict(
 )
 RED_SUM, RED_MAX = 0, 1
 KERN_RBF, KERN_CSYM_RBF, KERN_SQDIST = 0, 1, 2
+KERN_KBAR_SYMMETRIC = 256   # OR-ed into the kind of gram_bwd: Kbar is symmetric (no transposed reads)
 EW_PROG_SUM = 256
 MM_LOWER_OUT = 1
 MM_TRIL_OUT = 2

@@ -261,7 +261,9 @@ int hb_tri_to_vec_f64(const double* tri, double* v, long B, long N, void* stream
 
 /* ---- K3: stationary Gram matrices (reference gp/kernels.py:54-84
  *      square_dist, :110-111 UnitRBF.K, :122-131 UnitCsymRBF) -------------- */
-enum { HB_KERN_RBF = 0, HB_KERN_CSYM_RBF = 1, HB_KERN_SQDIST = 2 /* the scaled squared distance itself */ };
+enum { HB_KERN_RBF = 0, HB_KERN_CSYM_RBF = 1, HB_KERN_SQDIST = 2 /* the scaled squared distance itself */,
+       HB_KERN_KBAR_SYMMETRIC = 256 /* hb_gram_bwd only, OR-ed into `kind`: Kbar is symmetric (the Cholesky VJP's output):
+                                       the one-pass form need not read the transposed entries */ };
 /* K[b,i,j] = k(X[b,i,:], X2[b,j,:]); sX/sX2 = batch strides in elements (0 =
  * shared); ell has dl = 1 (scalar) or d entries (ARD), post-transform; sEll = 0
  * (one kernel for the whole batch) or dl (a lengthscale vector per batch entry:
@@ -275,7 +277,8 @@ int hb_gram_fwd_f64(int kind, const double* X, long sX, const double* X2, long s
                     double diag_add, void* stream);
 /* VJP: Xbar[B,n,d], X2bar[B,n2,d] (either nullable), ellbar[dl] or [B,dl] when sEll != 0
  * (nullable).  ws >= B*n*d elements when ellbar != NULL.  X2bar == Xbar (with X2 == X):
- * the total gradient w.r.t. the shared points is written once. */
+ * the total gradient w.r.t. the shared points is written once (kind | HB_KERN_KBAR_SYMMETRIC: for a symmetric Kbar,
+ * without the strided reads of the transposed entries). */
 int hb_gram_bwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
                     long sEll, long dl, const float* Kbar, float* Xbar, float* X2bar, float* ellbar,
                     long B, long n, long n2, long d, float* ws, void* stream);

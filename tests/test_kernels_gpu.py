@@ -1032,6 +1032,14 @@ def test_gram_symmetric_bwd_and_jitter(H, kind):
     assert_close(lb, gl, TOL["f64"])
     got = H.gram_fwd(Xd, Xd, ld, kind=k, diag_add=0.25)
     assert_close(got, K.detach() + 0.25 * torch.eye(n, dtype=dt), TOL["f64"])
+    # a SYMMETRIC Kbar (what the Cholesky VJP hands over) with the hint that it is: same result, no transposed reads
+    Ks = 0.5 * (Kbar + np.transpose(Kbar, (0, 2, 1)))
+    Ksd = dev(Ks, dt)
+    xb2, lb2 = torch.empty_like(Xd), torch.empty_like(ld)
+    H.gram_bwd_raw(k, Xd, n * d, Xd, n * d, ld, 0, d, Ksd, xb, xb, lb, B, n, n, d, ws)
+    H.gram_bwd_raw(k | H.KERN_KBAR_SYMMETRIC, Xd, n * d, Xd, n * d, ld, 0, d, Ksd, xb2, xb2, lb2, B, n, n, d, ws)
+    assert_close(xb2, xb, TOL["f64"])
+    assert_close(lb2, lb, TOL["f64"])
 
 
 @pytest.mark.parametrize("mode", ["jit", "interpret"])
