@@ -92,7 +92,11 @@ gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const
   const long row = blockIdx.x;
   ell += b * sEll;
   const long nother = side != 1 ? n2 : n;
+  // reciprocal lengthscales once per thread (they sat as IEEE divisions inside both inner loops)
+  T ilv[HB_GRAM_MAXD];
   for (long k0 = 0; k0 < d; k0 += HB_GRAM_MAXD) {
+#pragma unroll
+    for (int k = 0; k < HB_GRAM_MAXD; ++k) ilv[k] = k0 + k < d ? T(1) / ell[dl == 1 ? 0 : k0 + k] : T(0);
     T gacc[HB_GRAM_MAXD], lacc[HB_GRAM_MAXD];
 #pragma unroll
     for (int k = 0; k < HB_GRAM_MAXD; ++k) gacc[k] = lacc[k] = T(0);
@@ -104,7 +108,7 @@ gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const
       const T* xj = X2 + b * sX2 + j * d;
       T r2 = T(0), r2m = T(0);
       for (long k = 0; k < d; ++k) {
-        const T il = T(1) / ell[dl == 1 ? 0 : k];
+        const T il = (d <= HB_GRAM_MAXD) ? ilv[k] : T(1) / ell[dl == 1 ? 0 : k];   // (d <= 8: k0 == 0, ilv covers every k)
         const T a = xi[k] * il, bb = xj[k] * il;
         r2 += (a - bb) * (a - bb);
         r2m += (a + bb) * (a + bb);
@@ -121,7 +125,7 @@ gram_bwd_side_kernel(int kind, int side, const T* __restrict__ X, long sX, const
 #pragma unroll
       for (int k = 0; k < HB_GRAM_MAXD; ++k) {
         if (k0 + k < d) {
-          const T il = T(1) / ell[dl == 1 ? 0 : k0 + k];
+          const T il = ilv[k];
           const T a = xi[k0 + k] * il, bb = xj[k0 + k] * il;
           const T dm = a - bb, dp = a + bb;
           if (side != 1)
