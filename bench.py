@@ -13,10 +13,15 @@ reference's Optimizer.optimize, model.py:263-267).  Inputs are resident in HBM.
 --config selects the other BASELINE configs at their full sizes (cfg3 full-rank q(u) M = 1024 n = 16384;
 cfg4 amortised encoder [64,256,32] n = 32768; cfg5 4 experts + 4 gates x M = 512 n = 65536).
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns
-a 1/N shard of the data; `--scaling weak` (default) keeps the per-GPU minibatch,
-`--scaling strong` keeps the GLOBAL minibatch and gives every rank 1/N of it.  The
-flat gradient is all-reduced over RCCL once per step, inside the captured step graph.
+With N > 1 there is one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process IS a rank;
+launched plainly (`python bench.py --gpus N`) it starts the N ranks itself -- fresh child processes through
+`python -m torch.distributed.run` on 127.0.0.1, BEFORE anything in this process touches the GPU -- and exits
+with their return code.  `--gpus` must equal the world size (anything else is an error, rc 2).  Every rank owns a 1/N
+shard of the data; `--scaling weak` (default) keeps the per-GPU minibatch, `--scaling strong` keeps the GLOBAL
+minibatch and gives every rank 1/N of it; with N > 1 the line always carries the OTHER mode too, measured right
+after (`"also": {...}`).  The flat gradient is all-reduced over RCCL once per step (hb_allreduce_sum behind the C ABI).
+`--dry-run` runs the launch plumbing only (gloo process group, shard arithmetic, one all-reduce on CPU tensors)
+and prints the JSON skeleton with `n_gpus` = world size: the CPU test of the N > 1 launch path.
 
 Rank 0 prints ONE JSON line: the contract fields plus
   "roofline"      -- the plan step with the largest share of the step time, FOUND AT RUN TIME (every step of the
@@ -36,7 +41,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix), spec
 PEAK_F64_MFMA_TFLOPS = 78.6
@@ -86,7 +90,7 @@ def cpu_baseline(cfg, seconds=15.0):
     import torch
 
     import henbun_oracle as O
-    from models import svgp_data
+    from henbun_amd.models import svgp_data
 
     M, n, N = 512, 8192, 1_000_000
     threads = usable_cores()
@@ -140,7 +144,7 @@ def build_model(name, cfg, world, rank, dtype, n_local):
     """(model, dp_reduce, flops_per_step_algorithmic(global minibatch))."""
     import numpy as np
 
-    from models import SVGP, Amortised, ExpertsGPR, svgp_data
+    from henbun_amd.models import SVGP, Amortised, ExpertsGPR, svgp_data
 
     np.random.seed(1234)  # identical parameter initialisation on every rank (the data below is rank-specific)
     N, M, n = cfg["N"], cfg["M"], cfg["n"]
@@ -233,6 +237,54 @@ def time_steps_standalone(plan, torch, iters=40):
     return out
 
 
+def _free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one (which has not
+    imported torch, let alone touched a GPU) and return their exit code.  Rank 0's JSON line goes to our stdout."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
+    """Launch plumbing without a GPU: what a rank does up to device bring-up, on a gloo group."""
+    import torch
+    import torch.distributed as dist
+
+    from henbun_amd import parallel
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    cfg = CONFIGS[args.config]
+    n_global = cfg["n"] * world if args.scaling == "weak" else cfg["n"]
+    lo, hi = parallel.shard_rows(cfg["N"], rank, world)
+    t = torch.tensor([float(rank + 1), float(hi - lo)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+    ok = t[0].item() == world * (world + 1) / 2 and int(t[1].item()) == cfg["N"]
+    if rank == 0:
+        print(json.dumps({"metric": "elbo_samples_per_sec", "value": None, "unit": "samples/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling, "dry_run": True,
+                          "config": {"name": args.config, "global_batch": n_global, "per_gpu_batch": n_global // world,
+                                     "parallelism": "dp%d" % world, "shard_rows_rank0": hi - lo},
+                          "plumbing_ok": bool(ok), "rng_streams_rank0": parallel.rng_stream_ids(0)}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,14 +298,29 @@ def main():
                     help="operand form of the M^2 n contractions (bf16x3: BASELINE cfg 5's reduced-precision variant in its "
                          "usable form: three-term bf16 operands, fp32 accumulation, fp32-level accuracy)")
     ap.add_argument("--tri-pack", action="store_true", help="cfg3: keep the full-rank q_sqrt as its packed lower triangle")
+    ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no GPU): see the module docstring")
+    ap.add_argument("--no-also", action="store_true", help="N > 1: skip the second measurement in the other scaling mode")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)       # parent of the ranks: no torch import, no GPU call in this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE): refusing to report a line whose "
+                  "n_gpus would not be what was asked for" % (args.gpus, world), file=sys.stderr)
+        return 2
+    if args.dry_run:
+        return dry_run(args, world, rank)
 
     import numpy as np
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal switches (not used by the driver): HENBUN_DIST_BACKEND=gloo + HENBUN_ONE_DEVICE=1 run the N > 1 code
     # path with every rank on cuda:0 of a one-GPU box (RCCL refuses two ranks on one device)
     backend = os.environ.get("HENBUN_DIST_BACKEND", "nccl")
@@ -266,9 +333,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-
     import henbun_amd as hb
 
     tf = hb.tf
@@ -289,16 +353,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    opt.optimize(maxiter=max(args.warmup, 1), minibatch_size=n_local)
-    barrier()
-    t0 = time.perf_counter()
-    opt.optimize(maxiter=args.steps, minibatch_size=n_local)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_steps(nl):
+        """W warm-up steps, then EXACTLY K steps between barrier + synchronize; max over ranks (seconds)."""
+        opt.optimize(maxiter=max(args.warmup, 1), minibatch_size=nl)
+        barrier()
+        t0 = time.perf_counter()
+        opt.optimize(maxiter=args.steps, minibatch_size=nl)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    elapsed = timed_steps(n_local)
     plan = opt.last_plan
 
     # per-step HIP-event intervals (one event per step on the plan's stream; all ranks take part in the steps)
@@ -314,6 +383,27 @@ def main():
     per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(ksteps))
     elbo_after = opt.run(minibatch_size=n_local)
     barrier()
+
+    # the exchange really spans `world` ranks (an RCCL communicator of another size would be a silent 1-GPU run)
+    dp_ranks = 1
+    if world > 1:
+        from henbun_amd import parallel
+
+        comm = parallel.Communicator.create(m._session.device)
+        dp_ranks = comm.world_size if comm is not None else dist.get_world_size()
+        assert dp_ranks == world, "data-parallel exchange spans %d ranks, expected %d" % (dp_ranks, world)
+        assert getattr(plan, "dp_mode", "none") != "none", "N > 1 but the compiled step has no gradient exchange"
+
+    # N > 1: the other scaling mode, same protocol, right after (strong: global minibatch fixed, n / N per rank;
+    # weak: per-GPU minibatch fixed) -- north_star quotes a strong-scaling target, the contract line is weak by default
+    also = None
+    if world > 1 and not args.no_also:
+        other = "strong" if args.scaling == "weak" else "weak"
+        ng2 = cfg["n"] if other == "strong" else cfg["n"] * world
+        nl2 = ng2 // world
+        el2 = timed_steps(nl2)
+        also = {"scaling": other, "global_batch": ng2, "per_gpu_batch": nl2, "ms_per_step": el2 / args.steps * 1e3,
+                "value": args.steps / el2 * ng2, "unit": "samples/s", "steps_per_sec": args.steps / el2}
 
     if rank != 0:
         if world > 1:
@@ -370,7 +460,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": cfg["desc"] % ("per GPU" if args.scaling == "weak" else "global"),
                    "global_batch": n_global, "per_gpu_batch": n_local, "parallelism": "dp%d" % world, "N": cfg["N"],
-                   "M": cfg["M"], "name": args.config, "dp_exchange": getattr(plan, "dp_mode", "none"), "contraction": args.contraction,
+                   "M": cfg["M"], "name": args.config, "dp_exchange": getattr(plan, "dp_mode", "none"), "dp_ranks": dp_ranks,
+                   "contraction": args.contraction,
                    "tri_pack": bool(args.tri_pack)},
         "steps_per_sec": steps_per_sec,
         "flops_per_step_algorithmic": flops_step,
@@ -383,6 +474,8 @@ def main():
                           "what": "algorithmic flops of one rank's step / ms_per_step"},
         "step_breakdown_us_standalone": breakdown,
     }
+    if also is not None:
+        out["also"] = also
     if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
         out["cpu_baseline"] = cpu_baseline(cfg)
     print(json.dumps(out))
@@ -391,4 +484,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -46,6 +46,7 @@ _SIGS = {
     "hb_side_push_diag_bwd_f32": [P, P, P, P, P, P, P, L, L, L, L, P],
     "hb_side_pending": [],
     "hb_side_flush": [P],
+    "hb_side_discard": [],
     "hb_comm_available": [],
     "hb_comm_unique_id": [P],
     "hb_comm_init": [P, I, I, P],

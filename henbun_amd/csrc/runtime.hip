@@ -93,6 +93,15 @@ int hb_side_push(const HbSideJob& job, hipStream_t stream) {
 }
 
 extern "C" int hb_side_pending(void) { return hb_side_list.n; }
+// Drop the recorded jobs WITHOUT running them: the caller's launch sequence was abandoned between a push and its host
+// (an argument check failed, a Python exception, a failed capture), and the raw device pointers they hold must not ride
+// on some unrelated later launch.  Returns the number of jobs dropped.
+extern "C" int hb_side_discard(void) {
+  const int n = hb_side_list.n;
+  hb_side_list.n = 0;
+  hb_side_list.total = 0;
+  return n;
+}
 extern "C" int hb_side_flush(void* stream) {
   const HbSideJobs J = hb_side_take();
   return hb_side_launch(J, (hipStream_t)stream);

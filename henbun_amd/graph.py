@@ -2129,13 +2129,31 @@ class Plan:
             if self._graph is not None:
                 self._graph.launch()
             else:
-                for s in self.steps:
-                    s()
+                self._run_eager(self.steps)
+
+    def _run_eager(self, steps):
+        """The launch sequence, step by step.  Side jobs (csrc/side_jobs.cuh) are per-thread state of the library, not
+        of a plan: whatever is pending when a plan starts belongs to a sequence somebody abandoned and is dropped, a
+        plan must leave nothing pending, and a step that raises takes its recorded jobs with it -- raw device pointers
+        never ride on a launch of another plan."""
+        H = self.H
+        H.side_discard()
+        try:
+            for s in steps:
+                s()
+            if H.side_pending():
+                raise RuntimeError("plan left %d side job(s) pending: a deferred step has no flushing host" % H.side_pending())
+        except BaseException:
+            H.side_discard()
+            raise
 
     def capture(self):
         """Record the launch sequence into one hipGraph (replayed by run()).  A
         warm-up pass first lets lazily sized workspaces allocate outside the
-        capture; steps with side effects on the parameters are skipped in it.
+        capture; steps with side effects beyond the plan's own buffers (the Adam
+        update, the data-parallel pack + all-reduce) are skipped in it and the RNG
+        streams are put back afterwards, so a capture -- also a later re-capture
+        on one rank only -- is invisible to the trajectory and issues no collective.
         Later changes of the injection state (set_indices / clear_indices /
         inject_noise) re-capture on the next run; graphs are kept per state."""
         if self._nocap:
@@ -2147,17 +2165,27 @@ class Plan:
         return True
 
     def _capture_now(self):
-        for s in self.steps:
-            if s not in self.side_effect_steps:
-                s()
-        self.torch.cuda.current_stream().synchronize()
+        st = self.torch.cuda.current_stream()
+        saved = {k: r.state.clone() for k, r in self._rngs.items()} if self._rngs else {}
+        self._run_eager([s for s in self.steps if s not in self.side_effect_steps])
+        for k, r in self._rngs.items():
+            r.state.copy_(saved[k])
+        st.synchronize()
         g = self.H.CapturedGraph()
+        self.H.side_discard()
         g.begin()
         try:
-            for s in self.steps:
-                s()
-        finally:
-            g.end()
+            try:
+                for s in self.steps:
+                    s()
+            finally:
+                g.end()
+        except BaseException:
+            self.H.side_discard()
+            raise
+        if self.H.side_pending():
+            n = self.H.side_discard()
+            raise RuntimeError("capture left %d side job(s) pending: a deferred step has no flushing host" % n)
         self._graph = g
         self._graphs[self._state_key()] = g
 

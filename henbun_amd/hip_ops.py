@@ -382,6 +382,11 @@ def side_pending():
     return int(_lib.lib().raw("hb_side_pending")())
 
 
+def side_discard():
+    """Drop this thread's recorded side jobs without running them (hb_side_discard); returns how many there were."""
+    return int(_lib.lib().raw("hb_side_discard")())
+
+
 def diag_sample_kl_fwd(mu, s, u_in=None, rng=None, out=None, rows=None, defer=False):
     """x = mu + exp(s)*u ; kl = -0.5*sum(2s + u^2 - x^2).  Returns (x, kl, u).
     rows=(nrows, L, ld_mu, ld_s): mu and s are column blocks of wider row-major matrices (1-D views starting at their

@@ -128,6 +128,7 @@ class AutoOptimize:
 
 
 _DEFAULT_ADAM = AdamOptimizer()
+STATE_FORMAT_VERSION = 2   # Optimizer.save_state: 2 = layout_names / layout_spans (no pickle), adam_fail, format_version
 
 
 class Optimizer:
@@ -187,7 +188,7 @@ class Optimizer:
         n = settings.numerics
         return (n.jitter_level, n.clip_by_value, n.clip_value_min, n.clip_value_max, str(getattr(n, "kl_form", "mc")), str(getattr(n, "contraction", "native")),
                 str(settings.runtime.index_source), bool(settings.runtime.fuse_elementwise),
-                bool(getattr(settings.runtime, "force_dp", False)), bool(getattr(settings.runtime, "chol_rider", False)),
+                bool(getattr(settings.runtime, "force_dp", False)), str(getattr(settings.runtime, "dp_exchange", "auto")),
                 str(getattr(settings.runtime, "ewise", "jit")), bool(getattr(settings.runtime, "side_jobs", True)))
 
     @staticmethod
@@ -289,16 +290,33 @@ class Optimizer:
                     H.dp_pack(tail, objbuf, info)
 
                 comm = parallel.Communicator.create(sess.device)
-                if comm is not None and comm.graph_safe(sess):
-                    plan.steps += [pack, lambda: comm.allreduce_sum(gflat), adam]
-                    plan.side_effect_steps.add(adam)
+                exch = lambda: comm.allreduce_sum(gflat)
+                # Where the exchange runs (settings.runtime.dp_exchange):
+                #   eager  after the captured forward+backward graph, on the plan's stream: pack, ONE RCCL all-reduce
+                #          issued through the C ABI, Adam -- three extra host calls per step, no collective inside a graph;
+                #   graph  the same three steps recorded into the step graph (one host call per step), after
+                #          Communicator.graph_safe has replayed a captured all-reduce against its closed form;
+                #   auto   (default) graph for a one-rank communicator (settings.runtime.force_dp: how the tail is
+                #          exercised on a one-GPU box), eager for world_size > 1: a captured multi-rank RCCL
+                #          collective has not yet been run on hardware by this project (no multi-GPU box in the
+                #          build loop), and an all-reduce that hangs inside a graph takes the whole job with it.
+                mode = str(getattr(settings.runtime, "dp_exchange", "auto"))
+                if mode not in ("auto", "graph", "eager"):
+                    raise ValueError("settings.runtime.dp_exchange must be auto, graph or eager")
+                want_graph = mode == "graph" or (mode == "auto" and sess.world_size == 1)
+                if comm is not None and want_graph and comm.graph_safe(sess):
+                    plan.steps += [pack, exch, adam]
+                    # none of the three runs in the capture warm-up pass: a re-capture on one rank only (per-call
+                    # indices, injected noise) must not issue a collective the other ranks do not take part in
+                    plan.side_effect_steps.update([pack, exch, adam])
                     plan.dp_mode = "rccl-in-graph"
                 elif comm is not None:
-                    plan.eager_tail = [pack, lambda: comm.allreduce_sum(gflat), adam]
+                    plan.eager_tail = [pack, exch, adam]
                     plan.dp_mode = "rccl-eager"
                 else:
                     plan.eager_tail = [pack, lambda: parallel.allreduce_gradient(gflat), adam]
                     plan.dp_mode = "torch-eager"
+                plan.dp_comm = comm
         if settings.runtime.graph_capture:
             plan.capture()
         self._plans[key] = plan
@@ -363,7 +381,12 @@ class Optimizer:
 
     def _check_step_failure(self, plan):
         """Raise CholeskyError if an update was blocked by a failed factorisation.  The parameters, Adam slots and
-        step count are those of the last good step; the record is cleared so that the caller may continue."""
+        step count are those of the last good step; the record is cleared so that the caller may continue.
+        NOT rewound: the steps of the same `optimize` call that were already queued behind the failing one still
+        ran their draws (their updates were blocked too: `fail` is sticky on the device), so the minibatch-index and
+        noise streams have advanced by the remaining iterations of that call -- unlike the reference, where
+        tf.cholesky raises inside session.run and nothing further is drawn (model.py:265-266).  A caller that needs
+        the streams at the failing step restores them from a save_state checkpoint."""
         plan.stream.synchronize() if plan.stream is not None else plan.torch.cuda.synchronize()
         step, what = (int(x) for x in plan.fail.cpu().numpy())
         if step != 0:
@@ -372,7 +395,7 @@ class Optimizer:
             why = ("a factorisation on another rank failed" if what < 0 else
                    "leading minor %d is not positive definite" % what)
             raise G.CholeskyError("optimize: Adam step %d was not applied: %s; the parameters were left at the "
-                                  "last good step" % (step, why))
+                                  "last good step (the RNG streams have advanced past it)" % (step, why))
 
     # ------------------------------------------------------------------ exact resume
     def save_state(self, path):
@@ -386,8 +409,10 @@ class Optimizer:
         sess.torch.cuda.synchronize()
         slots = self._optimizer.slots(sess)
         out = {
+            "format_version": np.array([STATE_FORMAT_VERSION], dtype=np.int64),
             "theta": sess.theta.cpu().numpy(),
             "adam_m": slots["m"].cpu().numpy(), "adam_v": slots["v"].cpu().numpy(), "adam_t": slots["t"].cpu().numpy(),
+            "adam_fail": slots["fail"].cpu().numpy(),     # sticky record of a blocked update (hb_adam_step)
         }
         layout = self._layout_rows()
         out["layout_names"] = np.array([r[0] for r in layout], dtype=np.str_)
@@ -415,6 +440,15 @@ class Optimizer:
         torch = sess.torch
         p = path if path.endswith(".npz") else path + ".npz"
         with np.load(p, allow_pickle=False) as f:
+            if "format_version" not in f.files:
+                if "layout" in f.files or "layout_names" in f.files:
+                    raise ValueError("checkpoint %s was written by an earlier revision of save_state (no format_version; "
+                                     "the pickled 'layout' array was replaced by layout_names / layout_spans): re-save it "
+                                     "with this revision" % p)
+                raise ValueError("%s is not a save_state checkpoint" % p)
+            ver = int(f["format_version"][0])
+            if ver != STATE_FORMAT_VERSION:
+                raise ValueError("checkpoint %s has format_version %d, this revision reads %d" % (p, ver, STATE_FORMAT_VERSION))
             saved = [(str(a), int(b), int(c)) for a, (b, c) in zip(f["layout_names"].tolist(), f["layout_spans"].tolist())]
             if saved != self._layout_rows():
                 raise ValueError("checkpoint %s was written for a different parameter layout" % p)
@@ -424,6 +458,7 @@ class Optimizer:
             slots["m"].copy_(torch.as_tensor(f["adam_m"]).to(slots["m"].dtype))
             slots["v"].copy_(torch.as_tensor(f["adam_v"]).to(slots["v"].dtype))
             slots["t"].copy_(torch.as_tensor(f["adam_t"]))
+            slots["fail"].copy_(torch.as_tensor(f["adam_fail"]))
             for k, r in sess.rngs.items():
                 r.state.copy_(torch.as_tensor(f["rng_" + k]))
             if "index_train" in f.files:

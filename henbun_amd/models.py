@@ -1,11 +1,13 @@
-"""Model definitions shared by the CPU and GPU test suites and by bench.py.
+"""The build's own model counterparts of the BASELINE configurations: SVGP (cfg 1/2/3),
+Amortised (cfg 4), ExpertsGPR (cfg 5), plus the dense GPR and the two-expert form of the notebooks.
+Used by bench.py, __graft_entry__.smoke() and the test suites.
 
 Written the way a reference user would write them (SURVEY.md Appendix C;
 reference notebooks/GaussianProcess.ipynb:109-159), with `tf = hb.tf`.
 """
 import numpy as np
 
-import henbun_amd as hb
+import henbun_amd as hb  # noqa: E402  (the package is fully imported before this module is)
 
 tf = hb.tf
 

@@ -472,6 +472,10 @@ int hb_side_push_diag_bwd_f32(const float* s, const float* u, const float* x, co
                               float* mubar, float* sbar, long n, long L, long ld_s, long ld_out, void* stream);
 int hb_side_pending(void);
 int hb_side_flush(void* stream);
+/* Drops the calling thread's recorded jobs without running them (returns how many): for a caller whose launch sequence
+ * was abandoned between a push and its host launch; the recorded raw pointers must not ride on a later, unrelated
+ * launch.  henbun_amd's Plan calls it before and after every execution / capture of a plan. */
+int hb_side_discard(void);
 
 /* ---- data-parallel exchange step (no reference counterpart: the reference is one tf.Session on one
  *      device, model.py:57,255-269) --------------------------------------------------

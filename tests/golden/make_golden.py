@@ -55,6 +55,17 @@ SOURCES = {
 }
 
 
+# sha256 of the reference files the definitions above were reviewed in.  Definitions are executed ONLY from a file
+# with exactly these bytes: the reference is untrusted public content, and a changed file must be re-read by a person
+# (and this table updated) before any of it runs in the test process.
+PINNED_SHA256 = {
+    "testing/test_kernels.py": "0972f3499d55bb93db15dc22b7c9e2a2313262672b108861032338ebe34d21cb",
+    "testing/test_variationals.py": "74964dcda623c6960f27e0ab86e4263ee40196e2d941be3abe3c9deb3f56c967",
+    "testing/test_densities.py": "77cdf4ad44be87033ea332cabe5e41359de19db972b728df904256f7a72e90a1",
+    "Henbun/transforms.py": "406b8360f99da3104d024dc902ac7fe6f4785df9b411ad3dfd0d0287c874f54a",
+}
+
+
 class _NoTensorFlow(object):
     """Bound to the name `tf` while reference definitions run: any use is an error."""
 
@@ -80,6 +91,10 @@ def load_reference_definitions():
         path = os.path.join(REF, rel)
         with open(path, "rb") as f:
             raw = f.read()
+        digest = hashlib.sha256(raw).hexdigest()
+        if digest != PINNED_SHA256[rel]:
+            raise RuntimeError("%s: sha256 %s is not the reviewed %s -- refusing to execute definitions from a reference "
+                               "file that changed" % (rel, digest[:16], PINNED_SHA256[rel][:16]))
         tree = ast.parse(raw.decode("utf-8"), filename=path)
         picked = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
         missing = set(names) - {n.name for n in picked}

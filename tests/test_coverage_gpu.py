@@ -9,7 +9,7 @@ import henbun_amd as hb
 import henbun_oracle as O
 from henbun_amd import graph as G
 
-from models import ExpertGPR, svgp_data
+from henbun_amd.models import ExpertGPR, svgp_data
 
 pytestmark = pytest.mark.gpu
 tf = hb.tf
@@ -201,7 +201,7 @@ def test_gaussian_variational_and_variational_network_weights():
 def test_prediction_style_evaluation_and_heldout_objective():
     """Model.run(tensor) posterior draws at new inputs and run(training=False)."""
     np.random.seed(0)
-    from models import SVGP
+    from henbun_amd.models import SVGP
 
     X, Y, Z = svgp_data(3000, 48, 0)
     m = SVGP(X=X, Y=Y, Z=Z, dtype="float64")
@@ -220,7 +220,7 @@ def test_prediction_style_evaluation_and_heldout_objective():
 def test_batched_experts_parity():
     """cfg-5 form: 2E independent sparse GPs as ONE expert-batched SparseGP (batched Gram with per-expert
     lengthscales, batched Cholesky / inverse / M^2 n contraction) == the oracle's loop over single GPs."""
-    from models import ExpertsGPR
+    from henbun_amd.models import ExpertsGPR
 
     np.random.seed(2)
     rng = np.random.RandomState(2)
@@ -259,7 +259,7 @@ def test_batched_experts_parity():
 def test_batched_experts_train_in_graph_mode():
     """Regression: a batch of 8 Cholesky `info` words must survive hipGraph replay (a captured
     32-byte hipMemsetAsync replayed garbage on ROCm 7.2; the reset now happens inside the panel kernel)."""
-    from models import ExpertsGPR
+    from henbun_amd.models import ExpertsGPR
 
     np.random.seed(3)
     rng = np.random.RandomState(3)
@@ -541,7 +541,7 @@ def test_tri_packed_fullrank_q_sqrt(dtype, tol):
     and every gradient equal the dense form's (and the oracle's), the gradient / parameter / all-reduce payload
     of q_sqrt is M(M+1)/2 instead of M^2, `.value` and assignment still speak dense matrices; also the closed-form
     KL and the generic logdet through the packed storage."""
-    from models import SVGP
+    from henbun_amd.models import SVGP
     from henbun_amd.param import tri_pack, tri_unpack
 
     N, M, n = 2000, 96, 512

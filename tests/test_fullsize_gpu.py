@@ -20,7 +20,7 @@ import torch
 import henbun_amd as hb
 import henbun_oracle as O
 
-from models import SVGP, Amortised, ExpertsGPR, svgp_data
+from henbun_amd.models import SVGP, Amortised, ExpertsGPR, svgp_data
 
 pytestmark = pytest.mark.gpu
 tf = hb.tf

@@ -11,7 +11,7 @@ import henbun_oracle as O
 from henbun_amd import graph as G
 
 import graph_oracle as GO
-from models import SVGP, Amortised, DenseGPR
+from henbun_amd.models import SVGP, Amortised, DenseGPR
 
 tf = hb.tf
 

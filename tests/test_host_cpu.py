@@ -2,6 +2,7 @@
 declared symbol, the parameter tree / tf_mode / feed semantics mirror the
 reference, settings push/pop, Indexer, data-parallel helpers (gloo, 2 ranks)."""
 import os
+import json
 import re
 import subprocess
 import sys
@@ -303,3 +304,41 @@ def test_data_parallel_helpers_gloo_two_ranks(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def _bench_json(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts the two ranks itself (torch.distributed.run on
+    127.0.0.1, children of a parent that never touches a GPU) and rank 0's ONE JSON line says n_gpus = 2.  --dry-run
+    stops each rank before device bring-up (gloo group, shard arithmetic, one all-reduce): the N > 1 plumbing on CPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _bench_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["plumbing_ok"] is True
+    assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 2 * out["config"]["per_gpu_batch"]
+    assert out["config"]["shard_rows_rank0"] == 500_000
+
+
+def test_bench_refuses_a_world_size_that_is_not_what_was_asked_for():
+    """--gpus 2 inside a 1-rank launch (WORLD_SIZE=1) must fail loudly instead of printing an n_gpus = 1 line."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_side_job_list_can_be_discarded_without_a_gpu():
+    """hb_side_discard / hb_side_pending are host-side list operations (no launch): exported and callable on CPU."""
+    from henbun_amd import _lib
+
+    lib = _lib.lib()
+    assert lib.raw("hb_side_pending")() == 0
+    assert lib.raw("hb_side_discard")() == 0

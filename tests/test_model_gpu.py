@@ -12,7 +12,7 @@ import torch
 import henbun_amd as hb
 import henbun_oracle as O
 
-from models import SVGP, Amortised, DenseGPR, svgp_data
+from henbun_amd.models import SVGP, Amortised, DenseGPR, svgp_data
 
 pytestmark = pytest.mark.gpu
 tf = hb.tf
@@ -324,9 +324,10 @@ def test_data_parallel_step_on_a_one_rank_rccl_group_is_bit_identical_to_the_sin
                                 world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
     try:
         out = {}
-        for dp in (False, True):
+        for dp in (False, "graph", "eager"):
             cfg = hb.settings.get_settings()
-            cfg.runtime.force_dp = dp
+            cfg.runtime.force_dp = bool(dp)
+            cfg.runtime.dp_exchange = dp or "auto"
             with hb.settings.temp_settings(cfg):
                 np.random.seed(11)
                 X, Y, Z = svgp_data(5000, 64, 1)
@@ -336,14 +337,17 @@ def test_data_parallel_step_on_a_one_rank_rccl_group_is_bit_identical_to_the_sin
                 opt.optimize(maxiter=10, minibatch_size=512)
                 plan = opt.last_plan
                 assert plan.is_captured
-                assert plan.dp_mode == ("rccl-in-graph" if dp else "none"), plan.dp_mode
+                # "eager" is what world_size > 1 runs by default (settings.runtime.dp_exchange = auto): the exchange and
+                # Adam follow the captured forward+backward graph as three calls on the plan's stream
+                assert plan.dp_mode == {False: "none", "graph": "rccl-in-graph", "eager": "rccl-eager"}[dp], plan.dp_mode
                 torch.cuda.synchronize()
                 out[dp] = (m._session.theta.clone(), plan.gflat.clone(), opt.dp_objective())
-        assert torch.equal(out[False][0], out[True][0]), "parameters after 10 steps differ between the DP and plain step"
-        P = out[True][0].numel()
-        assert torch.equal(out[False][1][:P], out[True][1][:P])
-        assert out[False][2] is None and np.isfinite(out[True][2])
-        assert float(out[True][1][P + 1].item()) == 0.0          # no factorisation failed
+        P = out["graph"][0].numel()
+        for dp in ("graph", "eager"):
+            assert torch.equal(out[False][0], out[dp][0]), "parameters after 10 steps differ between the DP (%s) and plain step" % dp
+            assert torch.equal(out[False][1][:P], out[dp][1][:P])
+            assert out[False][2] is None and np.isfinite(out[dp][2])
+            assert float(out[dp][1][P + 1].item()) == 0.0          # no factorisation failed
     finally:
         if own_group:
             dist.destroy_process_group()
@@ -397,7 +401,7 @@ def test_rng_noise_statistics_and_minibatch_indices():
 def test_exact_resume_save_state(tmp_path):
     """save_state / restore_state: parameters + Adam slots + RNG streams + index split give a
     bit-identical continuation, in graph-replay mode, without rebuilding any plan."""
-    from models import SVGP, svgp_data
+    from henbun_amd.models import SVGP, svgp_data
 
     np.random.seed(11)
     X, Y, Z = svgp_data(3000, 32, 0, domain=16.0)

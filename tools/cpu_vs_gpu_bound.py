@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import henbun_amd as hb
-from models import SVGP, svgp_data
+from henbun_amd.models import SVGP, svgp_data
 tf = hb.tf
 np.random.seed(0)
 X, Y, Z = svgp_data(200000, 512, 0, domain=256.0)

@@ -10,7 +10,7 @@ torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 import henbun_amd as hb
-from models import SVGP, svgp_data
+from henbun_amd.models import SVGP, svgp_data
 tf = hb.tf
 np.random.seed(1234)
 M, n = int(os.environ.get('DP_M', 128)), int(os.environ.get('DP_n', 1024))

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import henbun_amd as hb
-from models import SVGP, Amortised, ExpertsGPR, svgp_data
+from henbun_amd.models import SVGP, Amortised, ExpertsGPR, svgp_data
 tf = hb.tf
 np.random.seed(1234)
 cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg2"   # cfg2 | cfg2_f64 | cfg3 | cfg3_f64 | cfg4 | cfg5 | ragged_f64

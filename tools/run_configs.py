@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import henbun_amd as hb
-from models import SVGP, Amortised, ExpertsGPR, svgp_data
+from henbun_amd.models import SVGP, Amortised, ExpertsGPR, svgp_data
 tf = hb.tf
 
 def timed(opt, n, steps=100, warm=10):
