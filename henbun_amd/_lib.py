@@ -40,7 +40,6 @@ _SIGS = {
     "hb_ewise_jit_available": [],
     "hb_ewise_jit_run": [P, P],
     "hb_ewise_jit_destroy": [P],
-    "hb_cholesky_inverse_sgp_f32": [P, P, P, L, P, P, P, I, P, P, P, L, P, L, L, L, P, P, P],
     "hb_side_push_gather_draw_f32": [I, P, P, P, L, P, L, L, L, P, P, L, P, P],
     "hb_side_push_diag_fwd_f32": [P, P, P, P, L, P, P, P, L, L, L, L, P, P],
     "hb_side_push_diag_bwd_f32": [P, P, P, P, P, P, P, L, L, L, L, P],
@@ -59,7 +58,6 @@ _TYPED = {
     "hb_ewise": [I, I, P, P, I, P, I, P, P, P],
     "hb_ewise_prog": [I, P, P, I, P, P, I, P, P, P, I, P, P],
     "hb_ewise_prog_run": [P, L, I, P],
-    "hb_sgp_finish": [P, P, L, P, P, P, L, L, L, L, L, I, P, P],
     "hb_ewise_jit_build": [I, P, P, I, P, P, I, P, P, P, I, P, P, P, P, P, L],
     "hb_gauss_ll": [P, P, P, P, L, P, P, P, P, P, L, P],
     "hb_reduce": [I, P, P, L, L, L, P, L, P],

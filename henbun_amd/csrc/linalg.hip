@@ -6,7 +6,7 @@
 // (gp/gp.py:162,169).  TensorFlow supplied these through Eigen/cuSOLVER; here
 // they are hand-written for gfx950.
 #include "common.cuh"
-#include "sgp_rider.cuh"
+#include "sgp_strip.cuh"
 #include "side_jobs.cuh"
 #include "gemm_tile.cuh"
 #include "../../include/henbun_hip.h"
@@ -635,22 +635,12 @@ __device__ __forceinline__ void hb_split_bf16x3(float x, __bf16& hi, __bf16& mid
   lo = (__bf16)(r1 - (float)mid);
 }
 
-// `rider` (fp32, one matrix): blocks past `nown` compute the LAST 64-row block of A = W K(z, x) (sgp_rider.cuh);
-// they read rows of W this kernel only ever overwrites with the zeros they already hold or mask.
 template <typename T>
-__global__ void __launch_bounds__(SGP_RIDER_THREADS) tril_inplace_kernel(T* __restrict__ L, T* __restrict__ W, T* __restrict__ Wf,
-                                                                         int bf16x3, long B, long M, SgpRider rider, int nown) {
-  extern __shared__ __attribute__((aligned(16))) char hb_dyn_lds[];
-  if constexpr (sizeof(T) == 4) {
-    if ((int)blockIdx.x >= nown) {
-      sgp_rider_job(rider, reinterpret_cast<const float*>(W), (int)M, (int)(M / 64) - 1, (int)blockIdx.x - nown,
-                    *reinterpret_cast<SgpRiderLds*>(hb_dyn_lds));
-      return;
-    }
-  }
+__global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, T* __restrict__ W, T* __restrict__ Wf, int bf16x3,
+                                                           long B, long M) {
   const int Mi = (int)M;
   const long mm = M * M, total = B * mm;
-  const long stride = (long)nown * blockDim.x;
+  const long stride = (long)gridDim.x * blockDim.x;
   const int nT = Mi / 32;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const long b = t / mm;
@@ -755,6 +745,10 @@ __device__ __forceinline__ void trsolve_row32(T (&t)[CH_NB], const T (*LsT)[CH_L
 // In-kernel phase stamps: compiled in only by tools/chol_stamps.hip (diagnostic build).
 #ifndef HB_STAMP
 #define HB_STAMP(i)
+#endif
+#ifndef HB_WSTAMP
+#define HB_WSTAMP(w, lane, i)   // per-wave stamps of the in-panel chain (tools/chol_stamps.hip)
+#define HB_PSTAMP(i)            // wave 0's stamps inside the load / update phase
 #endif
 #define CR_B 32         // block size
 #define CR_ROWS 128     // stacked panel: diagonal block + 96 rows
@@ -1106,14 +1100,32 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
 }
 
 // ===========================================================================
-// 64-column launches (fp32, M % 64 == 0): the same algorithm with two 32-column blocks per launch.
-// Half the launches means half the kernel boundaries, cold-start load round trips and panel stores on
-// the critical path (each ~1.5 + 2.3 + 0.9 us of the 8.8 us a 32-column launch costs); the price is a
-// rank-64 instead of a rank-32 update per wave tile (+1.3 us) -- the in-panel work (8-column steps) is
-// the same in total.  A wave tile is 32 rows x 64 columns (two 32x32 accumulators); a factor workgroup
-// stacks the 64x64 diagonal block (waves 0, 1) and 64 more rows (waves 2, 3) in LDS.
-// Row tiles are 32 rows (index rt), column blocks 64 wide (index j); the diagonal block of column j
-// (row tiles 2j, 2j+1) lives one block up, in the unused upper block (j-1, j), until it is factored.
+// 64-column launches (fp32, M % 64 == 0): the same right-looking algorithm with two 32-column blocks per launch
+// (half the kernel boundaries, cold-start load round trips and panel stores on the critical path).
+// A wave tile is 32 rows x 64 columns (two 32x32 accumulators); a factor workgroup stacks the 64x64 diagonal block
+// (waves 0, 1) and 64 more rows (waves 2, 3).  Row tiles are 32 rows (index rt), column blocks 64 wide (index j);
+// the diagonal block of column j (row tiles 2j, 2j+1) lives one block up, in the unused upper block (j-1, j),
+// until it is factored.
+//
+// Round 3: the in-panel phase of a factor workgroup is a chain of INDEPENDENT waves, not a barrier-stepped loop.
+//   * The accumulators of a factor workgroup are TRANSPOSED tiles (the update computes T^T = B X^T instead of X B^T):
+//     the 32x32 accumulator layout then puts the stacked ROW on the lane (l & 31) and the panel columns in the
+//     registers -- lane (i, h) holds columns {0-3, 8-11, 16-19, 24-27} + 4h of row i -- so the 8 entries of a row that
+//     an 8-column elimination step needs are the lane's own registers plus four v_permlane32_swap with its
+//     half-wave partner.  No LDS publish, no barrier, in front of a step.
+//   * The 64 x 64 diagonal block is factored by its two waves alone: wave 0 owns rows 0..31 and is the PIVOT wave of
+//     steps 0..3, wave 1 owns rows 32..63 (pivot wave of steps 4..7).  A pivot wave eliminates through v_readlane as
+//     before (its pivot rows are its own lanes), writes its 32 solved rows and the 8 reciprocal pivots to LDS, raises
+//     a step counter -- and continues with the rank-8 update of ITS OWN tile straight from registers (the A and B
+//     operands of that update are both the wave's own solved entries).  Its loop never reads LDS and never waits:
+//     ~1000 cycles per 8 columns (elimination ~700 + 4 dependent MFMAs) against ~1940 for the barrier-stepped form.
+//   * Every other wave FOLLOWS: it waits (LDS counter, s_sleep poll) until the step it needs is published, solves
+//     its rows by substitution with the published 8 x 8 sub-block (uniform LDS reads, the same operation order as
+//     the pivot wave's, so results do not depend on which wave solved a row), writes them to its own LDS rows for the
+//     final store and updates its tiles with the published diagonal rows as the MFMA A operand.  Followers lag the
+//     pivot wave by a step or two and finish ~1000 cycles after it; they never hold it back: the counters are
+//     monotonic, a published entry is never rewritten, and nobody a wave waits for ever waits for that wave
+//     (diag wave 1 waits for wave 0 only; row waves wait for diag waves only), so the polls cannot deadlock.
 // ===========================================================================
 #define C64_NB 64
 #define C64_ROWS 128
@@ -1130,36 +1142,199 @@ static inline int chol64_grid(int nrt, int k, int inv) {
   return g;
 }
 
-__global__ void __launch_bounds__(SGP_RIDER_THREADS) chol_rl64_kernel(const float* __restrict__ Ain, float* __restrict__ L,
-                                                                      float* __restrict__ Y, float* __restrict__ W, int M,
-                                                                      int k, int* __restrict__ info, SgpRider rider,
-                                                                      int nown, HbSideJobs side) {
-  // forward rider (sgp_rider.cuh): blocks past this launch's own grid compute rows [64(k-1), 64k) of A = W K(z, x)
-  // from the row block of W that launch k-1 finished
-  extern __shared__ __attribute__((aligned(16))) char hb_dyn_lds[];
-  if ((int)blockIdx.x >= nown) {
-    if (k == 0) {
-      // launch 0 of the chain keeps 8 workgroups busy: small independent launches of the step (minibatch draw +
-      // gather, the sample of q(u)) ride here as extra workgroups (side_jobs.cuh)
-      if (blockIdx.y == 0 && threadIdx.x < 256) hb_side_run(side, (int)blockIdx.x - nown);
-    } else {
-      sgp_rider_job(rider, W, M, k - 1, (int)blockIdx.x - nown, *reinterpret_cast<SgpRiderLds*>(hb_dyn_lds));
+// steps published by a diagonal wave: monotonic counter in LDS, release / acquire at workgroup scope
+__device__ __forceinline__ void c64_publish(int* flag, int steps) {
+  __hip_atomic_store(flag, steps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// `seen`: the largest count this wave has read so far.  The counters only grow and a follower usually runs a step or two
+// behind, so most waits are answered by the cached value and cost no LDS round trip.
+__device__ __forceinline__ void c64_wait(int* flag, int steps, int& seen) {
+  if (seen >= steps) return;
+  while ((seen = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < steps) __builtin_amdgcn_s_sleep(1);
+}
+
+// One 8-column in-panel step (columns [8 KB, 8 KB + 8) of the 64-column block) of one wave of a factor workgroup; every
+// index below is a compile-time constant, so the accumulators and the row entries stay in registers.
+template <int KB>
+__device__ __forceinline__ void c64_step(Mma<float>::Acc (&acc)[2], float (*Cs)[C64_LD], float (*L8s)[8][8], int* steps_done,
+                                         const int w, const int lane, int& fail, int (&seen)[2], const int k) {
+  (void)k;   // (the launch index: only the diagnostic stamps use it)
+  typedef float T;
+  typedef Mma<float> MM;
+  typedef float VT __attribute__((ext_vector_type(4)));
+  typedef float V3 __attribute__((ext_vector_type(3)));
+  typedef float V2 __attribute__((ext_vector_type(2)));
+  constexpr int J = KB >> 2, sub = KB & 3, c0 = 8 * KB;
+  const int li = lane & 31, h = lane >> 5;
+  auto bcast = [&](T v, int l) { return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+  // the 8 entries of this lane's row in columns [c0, c0+8): registers 4 sub .. 4 sub + 3 of both half-waves
+  T x[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // (a float temporary first: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 with this
+    // compiler; and the swap as inline asm with both operands tied: given the same value twice, the builtin form
+    // returned its first result for both -- tools/chol_debug.hip probes the instruction itself)
+    const T tq = acc[J][4 * sub + q];
+    unsigned lo = __builtin_bit_cast(unsigned, tq), hi = lo;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+    x[q] = __builtin_bit_cast(T, lo);      // [lower half's register | lower half's register]: columns c0 + q
+    x[4 + q] = __builtin_bit_cast(T, hi);  // [upper half's          | upper half's         ]: columns c0 + 4 + q
+  }
+  const bool pivot = (w == J);
+  if (pivot) {
+    // PIVOT wave: rows 8 sub .. 8 sub + 7 of this wave are the step's diagonal rows; the pivot and the multipliers
+    // L[c2][c] (= diagonal row c2's finished x[c]) reach every lane through v_readlane (uniform values in SGPRs) --
+    // the diagonal rows' own solves ARE the factorisation of the 8 x 8 sub-block
+    constexpr int dl0 = 8 * sub;
+    T pis[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const T d = bcast(x[c], dl0 + c);
+      T lcc, pi;
+      pivot_sqrt(d, lcc, pi);
+      (void)lcc;
+      pis[c] = pi;
+      x[c] *= pi;
+#pragma unroll
+      for (int c2 = c + 1; c2 < 8; ++c2) x[c2] = __builtin_fmaf(-x[c], bcast(x[c], dl0 + c2), x[c2]);
     }
+    // A pivot d <= 0 (or NaN) makes l_cc = d * rsq(d) a NaN, and a NaN column poisons every later pivot: the last
+    // diagonal entry of a wave's last pivot step is NaN exactly when some pivot of the wave (or an earlier one)
+    // failed.  One check per wave; the failing column is then the first NaN on the diagonal (LAPACK's info), which
+    // the wave reads back from its own rows of the LDS panel.
+    if (sub == 3) {
+      const T l77 = bcast(x[7], dl0 + 7);
+      if (!(l77 == l77)) fail = -1;   // located after the wave's last step (c64_locate_failure)
+    }
+    if (h == 0) {
+      const VT v0 = {x[0], x[1], x[2], x[3]}, v1 = {x[4], x[5], x[6], x[7]};
+      *reinterpret_cast<VT*>(&Cs[w * 32 + li][c0]) = v0;
+      *reinterpret_cast<VT*>(&Cs[w * 32 + li][c0 + 4]) = v1;
+      if (li >= dl0 && li < dl0 + 8) {
+        // the 8 x 8 sub-block, compact, for the followers: row c2 = (L[c2][0 .. c2-1], 1 / L[c2][c2], ...)
+        const int c2 = li - dl0;
+        VT s0 = v0, s1 = v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (c2 == e) s0[e] = pis[e];
+          if (c2 == 4 + e) s1[e] = pis[4 + e];
+        }
+        *reinterpret_cast<VT*>(&L8s[KB][c2][0]) = s0;
+        *reinterpret_cast<VT*>(&L8s[KB][c2][4]) = s1;
+      }
+    }
+  } else {
+    // FOLLOWER: substitution with the published 8 x 8 sub-block, same operation order as the pivot wave's.  Row c2 of
+    // the compact block is read with a load of exactly c2 + 1 elements (uniform addresses): every loaded register is
+    // used, so the twelve reads are in flight together (partly used 16-byte reads made the register allocator overlap
+    // their destinations, one LDS round trip per read).
+    c64_wait(&steps_done[J], KB + 1, seen[J]);
+    T l8[8][8];
+    {
+      const float(*B)[8] = L8s[KB];
+      l8[0][0] = B[0][0];
+      const V2 r1 = *reinterpret_cast<const V2*>(&B[1][0]);
+      l8[1][0] = r1[0], l8[1][1] = r1[1];
+      const V3 r2 = *reinterpret_cast<const V3*>(&B[2][0]);
+      l8[2][0] = r2[0], l8[2][1] = r2[1], l8[2][2] = r2[2];
+#pragma unroll
+      for (int c2 = 3; c2 < 8; ++c2) {
+        const VT a0 = *reinterpret_cast<const VT*>(&B[c2][0]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l8[c2][e] = a0[e];
+      }
+      l8[4][4] = B[4][4];
+      const V2 r5 = *reinterpret_cast<const V2*>(&B[5][4]);
+      l8[5][4] = r5[0], l8[5][5] = r5[1];
+      const V3 r6 = *reinterpret_cast<const V3*>(&B[6][4]);
+      l8[6][4] = r6[0], l8[6][5] = r6[1], l8[6][6] = r6[2];
+      const VT r7 = *reinterpret_cast<const VT*>(&B[7][4]);
+      l8[7][4] = r7[0], l8[7][5] = r7[1], l8[7][6] = r7[2], l8[7][7] = r7[3];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      x[c] *= l8[c][c];   // the diagonal of the compact block holds the reciprocal pivots
+#pragma unroll
+      for (int c2 = c + 1; c2 < 8; ++c2) x[c2] = __builtin_fmaf(-x[c], l8[c2][c], x[c2]);
+    }
+    if (h == 0) {
+      const VT v0 = {x[0], x[1], x[2], x[3]}, v1 = {x[4], x[5], x[6], x[7]};
+      *reinterpret_cast<VT*>(&Cs[w * 32 + li][c0]) = v0;
+      *reinterpret_cast<VT*>(&Cs[w * 32 + li][c0 + 4]) = v1;
+    }
+  }
+  HB_WSTAMP(w, lane, 2 * KB + 1);
+  // A diagonal wave publishes the step (its rows are the A operand of everybody's update of its column block) AFTER
+  // issuing the first MFMA of its own update: the LDS writes above complete under that MFMA instead of stalling the
+  // wave in front of it.
+  const bool publisher = w < 2;
+  bool published = false;
+  if (KB < 7) {
+    // rank-8 update of the columns to the right, transposed: T^T[c][i] -= sum_j D[c][c0 + j] X[i][c0 + j] with D the
+    // solved rows of the diagonal block (A operand) and X this wave's solved rows (B operand, its own registers)
+    const T xb[4] = {h ? x[1] : x[0], h ? x[3] : x[2], h ? x[5] : x[4], h ? x[7] : x[6]};
+#pragma unroll
+    for (int Jp = J; Jp < 2; ++Jp) {
+      if (w < 2 && Jp > w) continue;       // strict upper part of the diagonal block
+      const bool right = 32 * Jp + li >= 8 * (KB + 1);   // column 32 Jp + li is still to be factored
+      T a[4];
+      if (w < 2 && Jp == w) {
+        // the diagonal tile of a diagonal wave: both operands are its own solved entries
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = right ? xb[t] : T(0);
+      } else {
+        if (Jp != J) c64_wait(&steps_done[Jp], KB + 1, seen[Jp]);   // rows 32 Jp .. of the diagonal block, solved by diagonal wave Jp
+        const VT d0 = *reinterpret_cast<const VT*>(&Cs[32 * Jp + li][c0]);
+        const VT d1 = *reinterpret_cast<const VT*>(&Cs[32 * Jp + li][c0 + 4]);
+        a[0] = h ? d0[1] : d0[0];
+        a[1] = h ? d0[3] : d0[2];
+        a[2] = h ? d1[1] : d1[0];
+        a[3] = h ? d1[3] : d1[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = right ? a[t] : T(0);
+      }
+      acc[Jp] = MM::mma(-a[0], xb[0], acc[Jp]);
+      if (publisher && !published) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane == 0) c64_publish(&steps_done[w], KB + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        published = true;
+      }
+#pragma unroll
+      for (int t = 1; t < 4; ++t) acc[Jp] = MM::mma(-a[t], xb[t], acc[Jp]);
+    }
+  }
+  if (publisher && !published && lane == 0) c64_publish(&steps_done[w], KB + 1);
+  HB_WSTAMP(w, lane, 2 * KB + 2);
+}
+
+// First failed pivot of a diagonal wave whose last pivot step produced a NaN: the wave's own rows of the LDS panel
+// hold its diagonal (columns 32 w .. 32 w + 31 of rows 32 w ..); the first NaN on it, 1-based within the 64-column block.
+__device__ __forceinline__ int c64_locate_failure(float (*Cs)[C64_LD], int w, int lane) {
+  const int i = lane & 31;
+  const float dgl = Cs[32 * w + i][32 * w + i];
+  const unsigned long long nanmask = __ballot(!(dgl == dgl)) & 0xffffffffull;
+  return nanmask ? 32 * w + __builtin_ctzll(nanmask) + 1 : 32 * w + 32;
+}
+
+__global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict__ Ain, float* __restrict__ L, float* __restrict__ Y,
+                                                        float* __restrict__ W, int M, int k, int* __restrict__ info, int nown,
+                                                        HbSideJobs side) {
+  if ((int)blockIdx.x >= nown) {
+    // launch 0 of the chain keeps 8 workgroups busy: small independent launches of the step (minibatch draw +
+    // gather, the sample of q(u)) ride here as extra workgroups (side_jobs.cuh)
+    if (k == 0 && blockIdx.y == 0) hb_side_run(side, (int)blockIdx.x - nown);
     return;
   }
-  // a launch that carries riders has 512-thread workgroups (the riders' eight waves); the factorisation's own
-  // workgroups are 256 threads: the upper four waves leave before the first barrier
-  if (threadIdx.x >= 256) return;
   typedef float T;
   typedef Mma<float> MM;
   typedef float VT __attribute__((ext_vector_type(4)));
   constexpr int CK = 32;  // contraction entries per lane in the rank-64 update (128 bytes)
   __shared__ __attribute__((aligned(16))) T Cs[C64_ROWS][C64_LD];
   __shared__ __attribute__((aligned(16))) T Bs[C64_NB][C64_LD];  // panel rows of the column block (rank-64 update)
-  // Snapshot of the 8x8 diagonal sub-block of the current in-panel step.  potrf8 must not read it from Cs: the
-  // threads that own rows 8kb..8kb+7 write their SOLVED rows back to exactly those Cs entries with no barrier in
-  // between, so a wave that runs late (a shared GPU, a context switch) would factor a half-overwritten block.
-  __shared__ __attribute__((aligned(16))) T Dg[8][8];
+  __shared__ __attribute__((aligned(16))) T L8s[8][8][8];        // in-panel step kb: its 8 x 8 sub-block, compact (c64_step)
+  __shared__ int steps_done[2];                                   // in-panel steps published by diagonal wave 0 / 1
+  __shared__ int wave_fail[2];
 
   const long boff = (long)blockIdx.y * M * M;
   Ain += boff;
@@ -1170,7 +1345,7 @@ __global__ void __launch_bounds__(SGP_RIDER_THREADS) chol_rl64_kernel(const floa
     W += boff;
   }
   info += blockIdx.y;
-  const int nrt = M / 32, nblk = M / 64;
+  const int nrt = M / 32;
   // workgroup -> (column block j, strip s)
   int j = k, s = blockIdx.x;
   {
@@ -1206,65 +1381,143 @@ __global__ void __launch_bounds__(SGP_RIDER_THREADS) chol_rl64_kernel(const floa
   const int row0 = rt * 32, col0 = j * C64_NB;
   const bool adiag = !yt && (rt >> 1) == j;  // a row tile of column j's diagonal block
   const bool ydiag = yt && (rt >> 1) == j;   // rows of the identity that start in this column: no update yet
+  if (factor && tid < 2) steps_done[tid] = 0, wave_fail[tid] = 0;
 
   HB_STAMP(0);
+  // acc[sj]: update workgroups hold tile (rows, columns 32 sj ..) in the natural layout (column on the lane);
+  // factor workgroups hold its TRANSPOSE (row on the lane: lane (li, h) register r = column 32 sj + acc_row(lane, r)).
+  // Every global load of the launch -- the tile itself and the panel rows of the rank-64 update -- is ISSUED before
+  // any is consumed: tile, B rows and A rows used to be three dependent round trips (load -> select / LDS store ->
+  // next loads), ~2000 cycles each on data the previous launch has just written.
   typename MM::Acc acc[2];
+  const int pc = (k - 1) * C64_NB;
+  VT tileF[2][4];   // factor form: 16 bytes per lane and register group
+  T tileU[2][16];   // update form: one element per register
+  VT bstage[4], astage[8];
   {
     const T* src = yt ? Y : ((k <= 1) ? Ain : L);
     const int hrow0 = (adiag && k >= 2) ? row0 - C64_NB : row0;  // home of a diagonal-block tile: one block up
-    const bool fresh = yt && (ydiag || k == (rt >> 1) + 1);
-    const int doff = 32 * (rt - 2 * j);  // ydiag: the 1s sit at column (row + doff)
+    if (factor) {
+      // lane (li, h) reads columns 32 sj + 8 g + 4 h .. + 3 of row li
 #pragma unroll
-    for (int sj = 0; sj < 2; ++sj)
+      for (int sj = 0; sj < 2; ++sj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int tr = MM::acc_row(lane, r), tc = sj * 32 + li;
-        const T init = (ydiag && tc == tr + doff) ? T(1) : T(0);
-        // unconditional load + select (a fresh Y tile reads whatever its workspace holds and discards it): a
-        // conditional load compiles to a branch and an s_waitcnt vmcnt(0) PER ELEMENT, i.e. 32 serialised round trips
-        const T ld = src[(hrow0 + tr) * M + col0 + tc];
-        acc[sj][r] = fresh ? init : ld;
-      }
-  }
-
-  if (k > 0) {
-    // rank-64 update by panel k-1.  The panel rows come in with coalesced 16-byte loads (16 lanes per 256-byte
-    // row) and are re-read from LDS as MFMA fragments: a lane loading its own fragment row directly makes every
-    // load instruction touch 64 different cache lines, and the address unit -- not the memory -- becomes the bound
-    // (tools/chol_stamps.hip: the load phase scaled with the number of load instructions, ~190 cycles each).
-    const int pc = (k - 1) * C64_NB;
-    {
-      // B rows (the 64 rows of column block j), shared by the four waves
+        for (int g = 0; g < 4; ++g)
+          tileF[sj][g] = *reinterpret_cast<const VT*>(src + (hrow0 + li) * M + col0 + sj * 32 + 8 * g + 4 * h);
+    } else {
+      // unconditional loads (a fresh Y tile reads whatever its workspace holds and discards it): a conditional load
+      // compiles to a branch and an s_waitcnt vmcnt(0) PER ELEMENT, i.e. 32 serialised round trips
+#pragma unroll
+      for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tileU[sj][r] = src[(hrow0 + MM::acc_row(lane, r)) * M + col0 + sj * 32 + li];
+    }
+    if (k > 0) {
+      // the panel rows come in with coalesced 16-byte loads (16 lanes per 256-byte row) and are re-read from LDS as MFMA
+      // fragments: a lane loading its own fragment row directly makes every load instruction touch 64 different cache
+      // lines, and the address unit -- not the memory -- becomes the bound (tools/chol_stamps.hip: ~190 cycles each).
+      // B rows: the 64 rows of column block j, shared by the four waves; A rows: this wave's tile (ydiag tiles take no
+      // update: their loads are harmless reads of valid rows)
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int r = p * 16 + (tid >> 4), c4 = (tid & 15) * 4;
-        *reinterpret_cast<VT*>(&Bs[r][c4]) = *reinterpret_cast<const VT*>(L + (col0 + r) * M + pc + c4);
+        bstage[p] = *reinterpret_cast<const VT*>(L + (col0 + r) * M + pc + c4);
       }
-      // A rows of this wave's tile, staged in the wave's own rows of Cs
-      if (!ydiag) {
-        const T* ap = (yt ? Y : L) + row0 * M + pc;
+      const T* ap = ((yt && !ydiag) ? Y : L) + (ydiag ? col0 : row0) * M + pc;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          const int r = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-          *reinterpret_cast<VT*>(&Cs[w * 32 + r][c4]) = *reinterpret_cast<const VT*>(ap + r * M + c4);
-        }
+      for (int p = 0; p < 8; ++p) {
+        const int r = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+        astage[p] = *reinterpret_cast<const VT*>(ap + r * M + c4);
       }
     }
-    __syncthreads();
+  }
+  HB_PSTAMP(0);
+  {
+    const bool fresh = yt && (ydiag || k == (rt >> 1) + 1);
+    const int doff = 32 * (rt - 2 * j);  // ydiag: the 1s sit at column (row + doff)
+    if (factor) {
+#pragma unroll
+      for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int tc = sj * 32 + 8 * g + 4 * h + e;
+            const T init = (ydiag && tc == li + doff) ? T(1) : T(0);
+            acc[sj][4 * g + e] = fresh ? init : tileF[sj][g][e];
+          }
+    } else {
+#pragma unroll
+      for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tr = MM::acc_row(lane, r), tc = sj * 32 + li;
+          const T init = (ydiag && tc == tr + doff) ? T(1) : T(0);
+          acc[sj][r] = fresh ? init : tileU[sj][r];
+        }
+    }
+  }
+
+  HB_PSTAMP(1);
+  if (k > 0) {
+    // rank-64 update by panel k-1
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = p * 16 + (tid >> 4), c4 = (tid & 15) * 4;
+      *reinterpret_cast<VT*>(&Bs[r][c4]) = bstage[p];
+    }
     if (!ydiag) {
-      // lane (li, h) contracts over entries [32h, 32h+32) of the panel rows
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int r = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+        *reinterpret_cast<VT*>(&Cs[w * 32 + r][c4]) = astage[p];
+      }
+    }
+    HB_PSTAMP(2);
+    __syncthreads();
+    HB_PSTAMP(3);
+    if (!ydiag) {
+      // lane (li, h) contracts over entries [32h, 32h+32) of the panel rows.  All 24 fragment reads of the wave are
+      // issued before the first MFMA (a read -> wait -> 8 MFMAs loop left the matrix pipe idle for an LDS round trip
+      // per iteration: 134 cycles per MFMA instead of 64), and the three forms of the loop are separate straight-line
+      // code (branches inside it made the compiler shuffle accumulators between register sets).
+      VT va[CK / 4], vb0[CK / 4], vb1[CK / 4];
 #pragma unroll
       for (int q = 0; q < CK / 4; ++q) {
-        const VT va = *reinterpret_cast<const VT*>(&Cs[w * 32 + li][32 * h + 4 * q]);
-        const VT vb0 = *reinterpret_cast<const VT*>(&Bs[li][32 * h + 4 * q]);
-        const VT vb1 = *reinterpret_cast<const VT*>(&Bs[32 + li][32 * h + 4 * q]);
+        va[q] = *reinterpret_cast<const VT*>(&Cs[w * 32 + li][32 * h + 4 * q]);
+        vb0[q] = *reinterpret_cast<const VT*>(&Bs[li][32 * h + 4 * q]);
+        vb1[q] = *reinterpret_cast<const VT*>(&Bs[32 + li][32 * h + 4 * q]);
+      }
+      if (!factor) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[0] = MM::mma(-va[e], vb0[e], acc[0]);
-          acc[1] = MM::mma(-va[e], vb1[e], acc[1]);
-        }
+        for (int q = 0; q < CK / 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[0] = MM::mma(-va[q][e], vb0[q][e], acc[0]);
+            acc[1] = MM::mma(-va[q][e], vb1[q][e], acc[1]);
+          }
+      } else if (w == 0) {
+        // wave 0 of a factor workgroup owns rows 0..31 of the diagonal block: its second accumulator is the block's
+        // strict upper part, which nobody reads -- it is left alone (32 MFMAs fewer in front of the pivot wave's first step)
+#pragma unroll
+        for (int q = 0; q < CK / 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[0] = MM::mma(-vb0[q][e], va[q][e], acc[0]);
+      } else {
+        // transposed tiles: the column block's rows are the A operand.  Columns 0..31 first: a follower's first four
+        // in-panel steps read (and update) only that accumulator
+#pragma unroll
+        for (int q = 0; q < CK / 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[0] = MM::mma(-vb0[q][e], va[q][e], acc[0]);
+#pragma unroll
+        for (int q = 0; q < CK / 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[1] = MM::mma(-vb1[q][e], va[q][e], acc[1]);
       }
     }
+  } else if (factor) {
+    __syncthreads();  // steps_done / wave_fail are initialised before anybody polls them
   }
 
   HB_STAMP(1);
@@ -1280,103 +1533,32 @@ __global__ void __launch_bounds__(SGP_RIDER_THREADS) chol_rl64_kernel(const floa
     return;
   }
 
-  // ---- factor column block k: stacked panel rows [32w, 32w+32) belong to wave w; rows 0..63 are the diagonal block
-  int fail = 0;
-#pragma unroll
-  for (int kb = 0; kb < 8; ++kb) {
-    // publish columns [8kb, 8kb+8) of the accumulators
-    {
-      const int sj = kb >> 2;
-      if ((li >> 3) == (kb & 3)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Cs[w * 32 + MM::acc_row(lane, r)][sj * 32 + li] = sj == 0 ? acc[0][r] : acc[1][r];
-        // rows 8kb..8kb+7 live in wave kb/4, accumulator rows 8(kb%4) + 4h + (0..3) of its tile
-        if (w == sj) {
-          static_assert(Mma<float>::NACC == 16, "32x32 accumulator layout");
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            Dg[4 * h + rr][li & 7] = sj == 0 ? acc[0][4 * (kb & 3) + rr] : acc[1][4 * (kb & 3) + rr];
-        }
-      }
+  // ---- factor column block k.  Stacked panel rows [32w, 32w+32) belong to wave w (rows 0..63: the diagonal block);
+  // lane (li, h) of wave w holds row 32w + li, both halves of a wave work on the same 32 rows.
+  if (live) {
+    int fail = 0;
+    int seen[2] = {0, 0};
+    HB_WSTAMP(w, lane, 0);
+    c64_step<0>(acc, Cs, L8s, steps_done, w, lane, fail, seen, k);
+    c64_step<1>(acc, Cs, L8s, steps_done, w, lane, fail, seen, k);
+    c64_step<2>(acc, Cs, L8s, steps_done, w, lane, fail, seen, k);
+    c64_step<3>(acc, Cs, L8s, steps_done, w, lane, fail, seen, k);
+    if (w != 0) {   // diagonal wave 0 has finished its 32 rows
+      c64_step<4>(acc, Cs, L8s, steps_done, w, lane, fail, seen, k);
+      c64_step<5>(acc, Cs, L8s, steps_done, w, lane, fail, seen, k);
+      c64_step<6>(acc, Cs, L8s, steps_done, w, lane, fail, seen, k);
+      c64_step<7>(acc, Cs, L8s, steps_done, w, lane, fail, seen, k);
     }
-    __syncthreads();
-    if (w < 3) {
-      // The 8-column elimination step, one stacked row per LANE: a lane holds the 8 entries x[0..7] of its row; the
-      // rows of the 8x8 diagonal sub-block sit in lanes dl0 .. dl0+7 of the SAME wave, so the pivot and the
-      // multipliers L[c2][c] (= diagonal row c2's finished x[c]) reach every lane through v_readlane (uniform
-      // values in SGPRs) -- the diagonal rows' own solves ARE the factorisation of the sub-block.  ~80 VALU
-      // instructions per step; the previous form (potrf8 replicated in every lane's registers, then the row solve:
-      // ~175 instructions) was issue bound at ~1300 of the 2200 cycles of a step.
-      //   wave 0: lane l = stacked row l (the diagonal rows are lanes 8kb .. 8kb+7)
-      //   wave 1: lanes 0..55 = rows 64..119, lanes 56..63 = copies of the diagonal rows (from the snapshot Dg)
-      //   wave 2: lanes 0..7 = rows 120..127, lanes 56..63 = copies of the diagonal rows, the rest idle
-      const int dl0 = (w == 0) ? 8 * kb : 56;
-      const bool dup = (w != 0) && lane >= 56;
-      const bool owner = (w == 0) || (w == 1 && lane < 56) || (w == 2 && lane < 8);
-      const int row = (w == 0) ? lane : (w == 1 ? 64 + lane : 120 + (lane & 7));
-      T x[8];
-      {
-        const T* src = dup ? &Dg[lane - 56][0] : &Cs[row][8 * kb];
-        const VT v0 = *reinterpret_cast<const VT*>(src), v1 = *reinterpret_cast<const VT*>(src + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = v0[e], x[4 + e] = v1[e];
-      }
-      auto bcast = [&](T v, int l) { return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const T d = bcast(x[c], dl0 + c);
-        T lcc, pi;
-        pivot_sqrt(d, lcc, pi);
-        (void)lcc;
-        x[c] *= pi;
-#pragma unroll
-        for (int c2 = c + 1; c2 < 8; ++c2) x[c2] = __builtin_fmaf(-x[c], bcast(x[c], dl0 + c2), x[c2]);
-      }
-      // A pivot d <= 0 (or NaN) makes l_cc = d * rsq(d) a NaN, and a NaN column poisons every later pivot: the last
-      // diagonal entry is NaN exactly when some pivot of this step (or an earlier one) failed.  One compare per step;
-      // the failing column is then the first NaN on the diagonal (LAPACK's info).
-      if (w == 0) {
-        const T l77 = bcast(x[7], dl0 + 7);
-        if (fail == 0 && !(l77 == l77)) {
-          fail = 8 * kb + 8;
-#pragma unroll
-          for (int c = 6; c >= 0; --c) {
-            const T lc = bcast(x[c], dl0 + c);
-            if (!(lc == lc)) fail = 8 * kb + c + 1;
-          }
-        }
-      }
-      if (owner) {
-        VT v0, v1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v0[e] = x[e], v1[e] = x[4 + e];
-        *reinterpret_cast<VT*>(&Cs[row][8 * kb]) = v0;
-        *reinterpret_cast<VT*>(&Cs[row][8 * kb + 4]) = v1;
-      }
-    }
-    __syncthreads();
-    if (kb < 7) {
-      // rank-8 update of the columns to the right: acc -= X[:, 8kb:8kb+8] X_D[cols, 8kb:8kb+8]^T
-      const VT va = *reinterpret_cast<const VT*>(&Cs[w * 32 + li][8 * kb + 4 * h]);
-#pragma unroll
-      for (int sj = 0; sj < 2; ++sj) {
-        if (32 * (sj + 1) <= 8 * (kb + 1)) continue;  // every column of this half is finished (uniform)
-        const int dr = sj * 32 + li;  // row of the diagonal block = column of the panel
-        const VT vb = *reinterpret_cast<const VT*>(&Cs[dr][8 * kb + 4 * h]);
-        const bool right = dr >= 8 * (kb + 1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const T bb = right ? vb[e] : T(0);
-          if (sj == 0)
-            acc[0] = MM::mma(-va[e], bb, acc[0]);
-          else
-            acc[1] = MM::mma(-va[e], bb, acc[1]);
-        }
-      }
+    if (w < 2) {
+      // (a diagonal wave reads its own, completed, LDS rows: its LDS writes are ordered before its reads)
+      if (fail != 0) fail = c64_locate_failure(Cs, w, lane);
+      if (lane == 0) wave_fail[w] = fail;
     }
   }
+  __syncthreads();
   HB_STAMP(2);
   if (s == 0 && tid == 0) {
+    const int fail = wave_fail[0] != 0 ? wave_fail[0] : wave_fail[1];
     const int bad = fail != 0 ? k * C64_NB + fail : 0;
     if (k == 0)
       *info = bad;
@@ -1414,8 +1596,7 @@ __global__ void __launch_bounds__(SGP_RIDER_THREADS) chol_rl64_kernel(const floa
 }
 
 template <typename T>
-static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, long B, long M, int* info,
-                           hipStream_t stream, const SgpRider* rider = nullptr) {
+static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, long B, long M, int* info, hipStream_t stream) {
   HB_REQUIRE(!Wf || (W && M % 32 == 0), "hb_cholesky_inverse: the fragment-major copies need W and M %% 32 == 0");
   HB_REQUIRE(!bf16x3 || (Wf && sizeof(T) == 4), "hb_cholesky_inverse: bf16x3 images need Wfrag and fp32");
   HB_REQUIRE(B >= 0 && M >= 0, "hb_cholesky: negative extent");
@@ -1434,53 +1615,30 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, lon
   const int nblk = hb_cdiv(M, CR_B);
   const bool fast = ((uintptr_t)L % 16 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)ws % 16 == 0) && M % CR_B == 0;
   static const bool no64 = getenv("HB_CHOL_NO64") != nullptr;  // diagnostic A/B switch
-  SgpRider none = {};
   if (sizeof(T) == 4 && fast && M % C64_NB == 0 && !no64) {
     const int nrt = (int)(M / 32);
-    const bool ride = rider != nullptr;
-    HB_REQUIRE(!ride || (inv && B == 1 && M <= SGP_SM_MAX), "hb_cholesky_inverse_sgp: the forward rider needs W, one matrix and M <= %d",
-               SGP_SM_MAX);
-    const SgpRider rd = ride ? *rider : none;
-    const size_t dyn = ride ? sizeof(SgpRiderLds) : 0;
-    if (ride) {
-      static bool once = false;   // > 64 KB of dynamic LDS has to be allowed per kernel (once per process)
-      if (!once) {
-        HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_rl64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sizeof(SgpRiderLds)));
-        HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tril_inplace_kernel<float>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SgpRiderLds)));
-        once = true;
-      }
-    }
     HbSideJobs noside = {};
     for (int k = 0; k < nrt / 2; ++k) {
       const int nown = chol64_grid(nrt, k, inv);
       const HbSideJobs sj = k == 0 ? hb_side_take() : noside;   // pending side jobs of this thread ride on launch 0
-      dim3 grid((unsigned)(nown + ((ride && k > 0) ? rd.nS : 0) + (k == 0 ? sj.total : 0)), (unsigned)B);
-      hipLaunchKernelGGL(chol_rl64_kernel, grid, dim3(ride ? SGP_RIDER_THREADS : 256), dyn, stream, (const float*)A, (float*)L,
-                         inv ? (float*)ws : (float*)nullptr, (float*)W, (int)M, k, info, rd, nown, sj);
+      dim3 grid((unsigned)(nown + (k == 0 ? sj.total : 0)), (unsigned)B);
+      hipLaunchKernelGGL(chol_rl64_kernel, grid, dim3(256), 0, stream, (const float*)A, (float*)L,
+                         inv ? (float*)ws : (float*)nullptr, (float*)W, (int)M, k, info, nown, sj);
       HB_LAUNCH_CHECK();
     }
-    // with riders every workgroup holds ~95 KB of LDS (one per CU): the finishing pass then runs 256 grid-stride blocks
-    const int nown = ride ? 256 : hb_stream_grid(B * M * M, 256);
-    hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3((unsigned)(nown + (ride ? rd.nS : 0))), dim3(ride ? SGP_RIDER_THREADS : 256), dyn, stream, L, W, Wf, bf16x3,
-                       B, M, rd, nown);
-    HB_LAUNCH_CHECK();
-    return 0;
+  } else {
+    for (int k = 0; k < nblk; ++k) {
+      dim3 grid((unsigned)chol_rl_grid(nblk, k, inv), (unsigned)B);
+      if (fast)
+        hipLaunchKernelGGL((chol_rl_kernel<T, true>), grid, dim3(256), 0, stream, A, L, inv ? ws : (T*)nullptr, W, (int)M, k,
+                           info);
+      else
+        hipLaunchKernelGGL((chol_rl_kernel<T, false>), grid, dim3(256), 0, stream, A, L, inv ? ws : (T*)nullptr, W, (int)M,
+                           k, info);
+      HB_LAUNCH_CHECK();
+    }
   }
-  HB_REQUIRE(!rider, "hb_cholesky_inverse_sgp: the forward rider needs fp32, M %% 64 == 0 and 16-byte aligned operands");
-  for (int k = 0; k < nblk; ++k) {
-    dim3 grid((unsigned)chol_rl_grid(nblk, k, inv), (unsigned)B);
-    if (fast)
-      hipLaunchKernelGGL((chol_rl_kernel<T, true>), grid, dim3(256), 0, stream, A, L, inv ? ws : (T*)nullptr, W, (int)M, k,
-                         info);
-    else
-      hipLaunchKernelGGL((chol_rl_kernel<T, false>), grid, dim3(256), 0, stream, A, L, inv ? ws : (T*)nullptr, W, (int)M,
-                         k, info);
-    HB_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, bf16x3, B, M, none,
-                     hb_stream_grid(B * M * M, 256));
+  hipLaunchKernelGGL(tril_inplace_kernel<T>, dim3(hb_stream_grid(B * M * M, 256)), dim3(256), 0, stream, L, W, Wf, bf16x3, B, M);
   HB_LAUNCH_CHECK();
   return 0;
 }
@@ -1495,21 +1653,6 @@ extern "C" int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long 
                                        float* Wfrag, int frag_bf16x3, void* stream) {
   HB_REQUIRE(W, "hb_cholesky_inverse: NULL pointer");
   return cholesky_launch<float>(A, L, W, ws, Wfrag, frag_bf16x3, B, M, info, (hipStream_t)stream);
-}
-extern "C" int hb_cholesky_inverse_sgp_f32(const float* A, float* L, float* W, long M, int* info, float* ws, float* Wfrag,
-                                           int frag_bf16x3, const float* x, const float* z, const float* ell, long dl,
-                                           const float* u, long n, long d, long P, float* A_frag, float* sgp_ws,
-                                           void* stream) {
-  HB_REQUIRE(x && z && ell && A_frag && sgp_ws && W && ws, "hb_cholesky_inverse_sgp: NULL pointer");
-  HB_REQUIRE(M >= 64 && M % 64 == 0 && M <= SGP_SM_MAX, "hb_cholesky_inverse_sgp: M must be a multiple of 64 up to %d", SGP_SM_MAX);
-  HB_REQUIRE(n >= 1 && d >= 1 && d <= SGP_DREG_R && P >= 1 && P <= 4 && (dl == 1 || dl == d),
-             "hb_cholesky_inverse_sgp: needs n >= 1, 1 <= d <= %d, 1 <= P <= 4, dl in {1, d}", SGP_DREG_R);
-  HB_REQUIRE(((uintptr_t)W % 16) == 0 && ((uintptr_t)A_frag % 16) == 0, "hb_cholesky_inverse_sgp: W and A_frag must be 16-byte aligned");
-  SgpRider r;
-  r.x = x; r.z = z; r.ell = ell; r.u = u; r.Af = A_frag;
-  r.part = sgp_ws + n + M * d;   // where hb_sgp_fwd / hb_sgp_finish keep the column partials (E = 1)
-  r.n = n; r.d = (int)d; r.dl = (int)dl; r.P = (int)P; r.nS = (int)((n + SGP_SN - 1) / SGP_SN);
-  return cholesky_launch<float>(A, L, W, ws, Wfrag, frag_bf16x3, 1, M, info, (hipStream_t)stream, &r);
 }
 extern "C" int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info, double* ws,
                                        double* Wfrag, int frag_bf16x3, void* stream) {

@@ -18,7 +18,7 @@
 // E * M^2 * n (Kbar = W^T Abar), E * M^2 * n (Lbar = -tril(Kbar A^T)).
 // The roofline that bounds them is the f32 MFMA peak (v_mfma_f32_32x32x2_f32).
 #include "common.cuh"
-#include "sgp_rider.cuh"  // strip constants, sgp_store_frag_tile, the forward rider of the Cholesky launches
+#include "sgp_strip.cuh"  // strip constants, sgp_store_frag_tile
 #include <type_traits>
 #include "gemm_tile.cuh"
 #include "rng_pairs.cuh"
@@ -129,11 +129,15 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
   const int jcol = col0 + (threadIdx.x % SGP_BN);
   const bool jok = jcol < n;
   const int jc = jok ? jcol : n - 1;
-  T xs[D > 0 ? D : 1];
+  // coordinates are staged RAW and the difference is scaled (see hb_exp2_neg in sgp_strip.cuh)
+  T xs[D > 0 ? D : 1], scl[D > 0 ? D : 1];
   if (D > 0) {
 #pragma unroll
-    for (int q = 0; q < D; ++q) xs[q] = x[jc * D + q] * (T(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : q]);
-    for (int t = threadIdx.x; t < M * D; t += blockDim.x) zs[t] = z[t] * (T(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : (t % D)]);
+    for (int q = 0; q < D; ++q) {
+      xs[q] = x[jc * D + q];
+      scl[q] = T(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : q];
+    }
+    for (int t = threadIdx.x; t < M * D; t += blockDim.x) zs[t] = z[t];
     __syncthreads();
   }
 
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
       const int cl = (gq * 256 + (int)threadIdx.x) / GPR;
       const int cc = col0 + cl < n ? col0 + cl : n - 1;  // out-of-range columns compute garbage that is never stored
 #pragma unroll
-      for (int dd = 0; dd < DD; ++dd) xg[gq][dd] = x[cc * DD + dd] * (T(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd]);
+      for (int dd = 0; dd < DD; ++dd) xg[gq][dd] = x[cc * DD + dd];
     }
   }
 
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
       if (D > 0) {
 #pragma unroll
         for (int q = 0; q < D; ++q) {
-          const T t = zs[k * D + q] - xs[q];
+          const T t = (zs[k * D + q] - xs[q]) * scl[q];
           r2 += t * t;
         }
       } else {
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
           T r2 = T(0);
 #pragma unroll
           for (int dd = 0; dd < DD; ++dd) {
-            const T t = raw.z[q * DD + dd] - xc[dd];
+            const T t = (raw.z[q * DD + dd] - xc[dd]) * scl[dd];
             r2 += t * t;
           }
           v[q] = hb_exp2_neg<T>(r2);
@@ -366,7 +370,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) {
       sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
-      xs[dd] = x[cc * D + dd] * sc[dd];
+      xs[dd] = x[cc * D + dd];   // raw: the difference is taken first, then scaled (see hb_exp2_neg in sgp_strip.cuh)
     }
     // all staging loads are issued before any is consumed (a load -> LDS store loop would pay one dependent
     // round trip per iteration: five of them, ~5 us, in the first version of this prologue)
@@ -390,7 +394,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
 #pragma unroll
     for (int it = 0; it < ZIT; ++it) {
       const int i = tid + NTH * it;
-      if (i < M * D) zs[i] = zt[it] * sc[i % D];
+      if (i < M * D) zs[i] = zt[it];
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -415,7 +419,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
         float r2 = 0.f;
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) {
-          const float tt = zq[q * D + dd] - xs[dd];
+          const float tt = (zq[q * D + dd] - xs[dd]) * sc[dd];
           r2 += tt * tt;
         }
         v[q] = hb_exp2_neg<float>(r2);
@@ -659,7 +663,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) {
       sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
-      xs[dd] = x[cc * D + dd] * sc[dd];
+      xs[dd] = x[cc * D + dd];   // raw: the difference is taken first, then scaled (see hb_exp2_neg in sgp_strip.cuh)
     }
     constexpr int NTH = SGP_STRIP_THREADS;
     constexpr int ZIT = (SGP_SM_MAX * D) / NTH, UIT = SGP_SM_MAX / NTH;
@@ -680,7 +684,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs
 #pragma unroll
     for (int it = 0; it < ZIT; ++it) {
       const int i = tid + NTH * it;
-      if (i < M * D) zs[i] = zt[it] * sc[i % D];
+      if (i < M * D) zs[i] = zt[it];
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -705,7 +709,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs
         float r2 = 0.f;
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) {
-          const float tt = zq[q * D + dd] - xs[dd];
+          const float tt = (zq[q * D + dd] - xs[dd]) * sc[dd];
           r2 += tt * tt;
         }
         v[q] = hb_exp2_neg<float>(r2);
@@ -849,7 +853,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip3_kernel(SgpArgs
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) {
       sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
-      xs[dd] = x[cc * D + dd] * sc[dd];
+      xs[dd] = x[cc * D + dd];   // raw: the difference is taken first, then scaled (see hb_exp2_neg in sgp_strip.cuh)
     }
     constexpr int NTH = SGP_STRIP_THREADS;
     constexpr int ZIT = (SGP_SM_MAX * D) / NTH, UIT = SGP_SM_MAX / NTH;
@@ -870,7 +874,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip3_kernel(SgpArgs
 #pragma unroll
     for (int it = 0; it < ZIT; ++it) {
       const int i = tid + NTH * it;
-      if (i < M * D) zs[i] = zt[it] * sc[i % D];
+      if (i < M * D) zs[i] = zt[it];
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -889,7 +893,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip3_kernel(SgpArgs
         float r2 = 0.f;
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) {
-          const float tt = zs[(k8 + q) * D + dd] - xs[dd];
+          const float tt = (zs[(k8 + q) * D + dd] - xs[dd]) * sc[dd];
           r2 += tt * tt;
         }
         const float kv = hb_exp2_neg<float>(r2);
@@ -1202,26 +1206,6 @@ __global__ void __launch_bounds__(256) sgp_rng_fill_kernel(uint64_t* state, long
     if (2 * p + 1 < n) out[2 * p + 1] = (T)z1;
   }
   rng_store(state, nlanes, t, g);
-}
-
-// The finish pass alone: f, v (and the residual noise) from column partials that are already in the workspace -- the
-// ceil(M/64) slices per expert left by the forward riders of hb_cholesky_inverse_sgp.
-template <typename T>
-static int sgp_finish_only(const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* f, T* v, long E, long n, long M,
-                           long d, long P, int mode, T* ws, hipStream_t stream) {
-  HB_REQUIRE(f && v && ws && E >= 1 && n >= 0 && M >= 1 && P >= 1 && P <= 4, "hb_sgp_finish: bad arguments");
-  HB_REQUIRE(mode == HB_SGP_DIAGONAL || mode == HB_SGP_NEGLECTED, "hb_sgp_finish: mode must be diagonal or neglected");
-  const bool draw = mode == HB_SGP_DIAGONAL && !eps_in;
-  HB_REQUIRE(!draw || (rng && rng_lanes > 0), "hb_sgp_finish: eps_in or an RNG state is required for the diagonal residual");
-  if (E * n == 0) return 0;
-  const int gy = (int)((M + SGP_BM - 1) / SGP_BM);
-  const long total = E * n;
-  const int fgrid = draw ? hb_cdiv(rng_lanes, 256) : hb_stream_grid((total + 1) / 2, 256);
-  hipLaunchKernelGGL(sgp_finish_part_kernel<T>, dim3(fgrid), dim3(256), 0, stream, ws + E * n + E * M * d, gy,
-                     mode == HB_SGP_DIAGONAL ? eps_in : (const T*)nullptr, draw ? rng : (uint64_t*)nullptr, rng_lanes,
-                     mode == HB_SGP_DIAGONAL ? eps_out : (T*)nullptr, f, v, total, n, P, mode);
-  HB_LAUNCH_CHECK();
-  return 0;
 }
 
 extern "C" long hb_sgp_ws_elems(long E, long n, long M, long d, long P) {
@@ -1586,7 +1570,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
   const int nq = 2 * D + P;
   float* __restrict__ part = a.part + ((e * nS + bx) * (long)nq) * M;   // [2D + P][M] of this strip
 
-  // ---- stage z (scaled), the strip's x (scaled), u, the per-column residual coefficient and fbar
+  // ---- stage z, the strip's x (both raw: differences are scaled, not coordinates), u, the per-column residual coefficient and fbar
   float sc[D];
 #pragma unroll
   for (int dd = 0; dd < D; ++dd) sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
@@ -1614,12 +1598,12 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
 #pragma unroll
       for (int p = 0; p < 4; ++p) fbs[p][tid] = (ok && p < P) ? fbar[(long)p * n + cj] : 0.f;
 #pragma unroll
-      for (int dd = 0; dd < D; ++dd) xss[tid * D + dd] = x[cj * D + dd] * sc[dd];
+      for (int dd = 0; dd < D; ++dd) xss[tid * D + dd] = x[cj * D + dd];
     }
 #pragma unroll
     for (int it = 0; it < ZIT; ++it) {
       const int i = tid + NTH * it;
-      if (i < M * D) zs[i] = zt[it] * sc[i % D];
+      if (i < M * D) zs[i] = zt[it];
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -1815,7 +1799,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
       float tt[D], r2 = 0.f;
 #pragma unroll
       for (int dd = 0; dd < D; ++dd) {
-        tt[dd] = zr[dd] - xss[c * D + dd];
+        tt[dd] = (zr[dd] - xss[c * D + dd]) * sc[dd];   // difference first, then the exp2 scale (coordinates staged raw)
         r2 += tt[dd] * tt[dd];
       }
       const float gk = kb[i] * hb_exp2_neg<float>(r2);   // (columns past n hold zeros)
@@ -2658,13 +2642,4 @@ extern "C" int hb_sgp_bwd_f64(int kind, int mode, const double* x, long sx, cons
                               long E, long n, long M, long d, long P, double* ws, void* stream) {
   return sgp_bwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps, A, A_frag, v, fbar, Kbar, Kbar_frag, Lbar,
                          ubar, zbar, ellbar, xbar, E, n, M, d, P, ws, (hipStream_t)stream);
-}
-
-extern "C" int hb_sgp_finish_f32(const float* eps_in, uint64_t* rng, long rng_lanes, float* eps_out, float* f, float* v,
-                                 long E, long n, long M, long d, long P, int mode, float* ws, void* stream) {
-  return sgp_finish_only<float>(eps_in, rng, rng_lanes, eps_out, f, v, E, n, M, d, P, mode, ws, (hipStream_t)stream);
-}
-extern "C" int hb_sgp_finish_f64(const double* eps_in, uint64_t* rng, long rng_lanes, double* eps_out, double* f, double* v,
-                                 long E, long n, long M, long d, long P, int mode, double* ws, void* stream) {
-  return sgp_finish_only<double>(eps_in, rng, rng_lanes, eps_out, f, v, E, n, M, d, P, mode, ws, (hipStream_t)stream);
 }

@@ -1044,12 +1044,6 @@ def _cholesky_emit(plan, node):
             bf3 = str(getattr(_st.numerics, "contraction", "native")) == "bf16x3" and M <= 512
             frag = plan.scratch(((5 if bf3 else 2) * max(int(np.prod(node.outputs[0].shape)), 1),))
             plan._wfrag[inv_node.outputs[0]] = (frag, bf3)
-        rider = _chol_rider_target(plan, node, inv_node, users, frag, bf3)
-        if rider is not None:
-            # the factorisation is emitted where the sparse-GP op stands (all of that op's operands exist by then) and
-            # carries its forward contraction: see _sgp_emit and csrc/sgp_rider.cuh
-            plan._chol_rider[rider.id] = dict(a=a, out=out, inv=w, info=info, ws=ws, frag=frag, node=node)
-            return
         # launch 0 of the 64-column chain hosts pending side jobs (minibatch gather, the sample of q(u))
         host = plan.dtype == plan.torch.float32 and M % 64 == 0 and plan.attach_side(node)
         plan.steps.append(lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws, frag=frag, frag_bf16x3=bf3))
@@ -1069,44 +1063,6 @@ def _sgp_frag_exchange(plan, node, prec):
         return False
     users = list(plan._consumers.get(node.outputs[1], ()))
     return bool(users) and all(c.op == "sgp_grad" and not plan.needed(c.outputs[4]) for c in users)
-
-
-def _chol_rider_target(plan, node, inv_node, users, frag, bf3):
-    """The sparse-GP op whose forward contraction A = W K(z, x) can ride on this factorisation's launches
-    (hb_cholesky_inverse_sgp: one fp32 matrix, M a multiple of 64 up to 512, UnitRBF on 2-D x, d <= 4, P <= 4, A wanted
-    fragment-major only), or None.  Opt-in (`settings.runtime.chol_rider = True`): at cfg 2 the riders of the last
-    row blocks outlast their launches (256 riders for ~236 free CUs: two rounds) and the chain grows by what the
-    separate strip kernel took -- 0.2762 against 0.2769 ms per step."""
-    from ._settings import settings as _st
-
-    H = plan.H
-    if not bool(getattr(_st.runtime, "chol_rider", False)) or frag is None or bf3:
-        return None
-    L, W = node.outputs[0], inv_node.outputs[0]
-    if len(L.shape) != 2:
-        return None
-    M = L.shape[-1]
-    sgps = [c for c in users if c.op == "sgp"]
-    if len(sgps) != 1:
-        return None
-    sg = sgps[0]
-    xsh, zsh, ush = sg.inputs[0].shape, sg.inputs[1].shape, sg.inputs[5].shape
-    if len(xsh) != 2 or len(zsh) != 2 or len(ush) != 2 or sg.attrs["mode"] not in ("diagonal", "neglected"):
-        return None
-    n, d, P = xsh[0], xsh[1], ush[0]
-    if not H.sgp_rider_ok(1, M, n, d, P, plan.dtype) or sg.outputs[1] in plan.outputs:
-        return None
-    if not _sgp_frag_exchange(plan, sg, H.PREC_NATIVE):
-        return None
-    # nothing between the two ops in emission order may read L or W: the factorisation runs where the sgp op stands
-    guarded = {L, W} | {c.outputs[0] for c in users if c.op == "stop_gradient"}
-    lo, hi = plan._order_pos[node.id], plan._order_pos[sg.id]
-    for nd in plan._order[lo + 1:hi]:
-        if nd.op in ("trinv", "stop_gradient"):
-            continue
-        if any(t in guarded for t in nd.inputs):
-            return None
-    return sg
 
 
 def _cholesky_vjp(node, gs):
@@ -1499,21 +1455,6 @@ def _sgp_emit(plan, node):
         a_frag = plan.scratch((H.sgp_frag_elems(E, n, M, prec),))
         plan._afrag[node.outputs[1]] = (a_frag, prec)
         skip_a = node.outputs[1] not in plan.outputs
-    ride = plan._chol_rider.pop(node.id, None)
-    if ride is not None:
-        # the Cholesky + inverse chain that produces this op's W carries the contraction (one extra workgroup per 32
-        # data columns in each of its launches, on CUs the latency-bound chain leaves idle); only the finishing
-        # launch (f, v, residual noise from the column partials) is this op's own
-        assert a_frag is not None and skip_a and prec == H.PREC_NATIVE
-        sws = plan.scratch((H.sgp_rider_ws_elems(n, M, d),))
-        step = lambda: H.cholesky_inverse_sgp(ride["a"], x, z, ell, u, a_frag, sws, out=ride["out"], inv=ride["inv"],
-                                              info=ride["info"], ws=ride["ws"], frag=ride["frag"])
-        plan.steps.append(step)
-        plan.step_labels[id(step)] = "cholesky"
-        plan.step_nodes[id(step)] = ride["node"]
-        plan.steps.append(lambda: H.sgp_finish(sws, n, M, d, P, eps_in=eps_in, rng=rng, mode=mode,
-                                               out=(outs[0], outs[2], outs[3])))
-        return
     plan.steps.append(lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag,
                                         prec=prec, a_frag=a_frag, skip_a=skip_a))
 
@@ -1826,7 +1767,6 @@ class Plan:
         order = topo_order(self.outputs)
         self._order_pos = {n.id: i for i, n in enumerate(order)}
         self._order = order
-        self._chol_rider: Dict[int, object] = {}   # sgp node id -> deferred factorisation carrying its forward contraction
         self._needed = set()
         for n in order:
             for t in n.inputs:

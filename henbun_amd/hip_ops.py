@@ -655,59 +655,6 @@ def cholesky_inverse(A, out=None, inv=None, info=None, ws=None, frag=None, frag_
     return out, inv, info
 
 
-def sgp_rider_ok(B, M, n, d, P, dtype):
-    """Shapes the forward rider of the Cholesky chain handles (hb_cholesky_inverse_sgp_f32)."""
-    return (dtype == torch.float32 and B == 1 and M >= 64 and M % 64 == 0 and M <= 512 and n >= 1 and 1 <= d <= 4
-            and 1 <= P <= 4)
-
-
-def sgp_rider_ws_elems(n, M, d):
-    """Elements of the private partials buffer shared by cholesky_inverse_sgp and sgp_finish (one expert)."""
-    return n + M * d + 5 * ((M + 63) // 64) * n
-
-
-def cholesky_inverse_sgp(A, x, z, ell, u, a_frag, sgp_ws, out=None, inv=None, info=None, ws=None, frag=None,
-                         frag_bf16x3=False):
-    """cholesky_inverse of ONE fp32 matrix whose launches also compute A = W K(z, x) (fragment-major, into `a_frag`) and
-    the column partials of sum A^2 / sum u A (into `sgp_ws`): hb_cholesky_inverse_sgp_f32.  Follow with sgp_finish."""
-    for t in (A, x, z, ell, u, a_frag, sgp_ws):
-        _chk(t)
-    M, d = z.shape[-2], z.shape[-1]
-    n, P = x.shape[-2], u.shape[-2]
-    assert A.numel() == M * M and sgp_rider_ok(1, M, n, d, P, A.dtype)
-    assert sgp_ws.numel() >= sgp_rider_ws_elems(n, M, d) and a_frag.numel() >= sgp_frag_elems(1, n, M)
-    if out is None:
-        out = _empty_like(A)
-    if inv is None:
-        inv = _empty_like(A)
-    if info is None:
-        info = _empty(1, dtype=torch.int32, device=A.device)
-    if ws is None:
-        ws = workspace(A.dtype, A.device, M * M)
-    if frag is not None:
-        assert frag.numel() >= (5 if frag_bf16x3 else 2) * M * M and frag.dtype == A.dtype
-    _lib.lib().call("hb_cholesky_inverse_sgp_f32", _p(A), _p(out), _p(inv), M, _p(info), _p(ws), _p(frag),
-                    int(bool(frag_bf16x3 and frag is not None)), _p(x), _p(z), _p(ell), ell.numel(), _p(u), n, d, P,
-                    _p(a_frag), _p(sgp_ws), stream())
-    return out, inv, info
-
-
-def sgp_finish(sgp_ws, n, M, d, P, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None, E=1):
-    """(f, v, eps) from the column partials in `sgp_ws` (hb_sgp_finish): the finishing launch of sgp_fwd on its own."""
-    dev, dt = sgp_ws.device, sgp_ws.dtype
-    lead = (E,) if E > 1 else ()
-    if out is None:
-        f = _empty(lead + (P, n), dtype=dt, device=dev)
-        v = _empty(lead + (n,), dtype=dt, device=dev)
-        eps = _empty(lead + (n,), dtype=dt, device=dev)
-    else:
-        f, v, eps = out
-    rp, rl = _rng_args(rng)
-    _lib.lib().call("hb_sgp_finish" + _suf(sgp_ws), _p(eps_in), rp, rl, _p(eps), _p(f), _p(v), E, n, M, d, P, mode, _p(sgp_ws),
-                    stream())
-    return f, v, eps
-
-
 def trinv(L, out=None):
     """W = L^{-1} for lower-triangular L, batched."""
     _chk(L)

@@ -342,17 +342,6 @@ int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long B, long M, 
                             float* Wfrag, int frag_bf16x3, void* stream);
 int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info,
                             double* ws, double* Wfrag, int frag_bf16x3, void* stream);
-/* hb_cholesky_inverse for ONE fp32 matrix with the forward sparse-GP contraction riding along (UnitRBF kernel, 2-D x):
- * besides L, W (and the fragment-major images) the chain's launches leave A = W K(z, x) in fragment-major form
- * (A_frag, as hb_sgp_fwd would) and the column partials of sum_m A^2 and sum_m u_pm A_mj in `sgp_ws` (the hb_sgp_*
- * workspace, hb_sgp_ws_elems elements): launch k+1 of the factorisation carries one extra workgroup per 32 data
- * columns that computes rows [64k, 64k+64) of A from the row block of W launch k has just finished -- the M^2 n
- * contraction runs on the CUs the latency-bound chain leaves idle (csrc/sgp_rider.cuh).  Follow with
- * hb_sgp_finish_* for f and v.  Replaces tf.cholesky + tf.matrix_triangular_solve(Lm, Kmn) of SparseGP.samples /
- * _effective_LT (reference gp/gp.py:135,162) in one chain.  M % 64 == 0, M <= 512, d <= 4, P <= 4, dl in {1, d}. */
-int hb_cholesky_inverse_sgp_f32(const float* A, float* L, float* W, long M, int* info, float* ws, float* Wfrag,
-                                int frag_bf16x3, const float* x, const float* z, const float* ell, long dl,
-                                const float* u, long n, long d, long P, float* A_frag, float* sgp_ws, void* stream);
 /* W = L^{-1} (lower triangular inverse), batched.  Used in place of
  * tf.matrix_triangular_solve(Lm, .) (reference gp/gp.py:162,169): the
  * reference's own batched branch forms the explicit inverse the same way.
@@ -425,13 +414,6 @@ int hb_sgp_bwd_f64(int kind, int mode, const double* x, long sx, const double* z
                    const double* fbar, double* Kbar, double* Kbar_frag, double* Lbar, double* ubar,
                    double* zbar, double* ellbar, double* xbar, long E, long n, long M, long d, long P,
                    double* ws, void* stream);
-
-/* f, v (and the residual noise) from column partials already in `ws` (ceil(M/64) slices per expert, as left by
- * hb_cholesky_inverse_sgp's riders): the finishing launch of hb_sgp_fwd on its own.  Arguments as in hb_sgp_fwd. */
-int hb_sgp_finish_f32(const float* eps_in, uint64_t* rng, long rng_lanes, float* eps_out, float* f, float* v, long E,
-                      long n, long M, long d, long P, int mode, float* ws, void* stream);
-int hb_sgp_finish_f64(const double* eps_in, uint64_t* rng, long rng_lanes, double* eps_out, double* f, double* v,
-                      long E, long n, long M, long d, long P, int mode, double* ws, void* stream);
 
 /* ---- K9: flat-buffer Adam, TensorFlow-1 formula (reference model.py:206,220
  *      tf.train.AdamOptimizer via optimizer.minimize) --------
