@@ -46,6 +46,11 @@ _SIGS = {
     "hb_side_pending": [],
     "hb_side_flush": [P],
     "hb_side_discard": [],
+    "hb_chain_begin": [],
+    "hb_chain_end": [P],
+    "hb_chain_discard": [],
+    "hb_chain_source": [P, L],
+    "hb_chain_compile_dry": [],
     "hb_comm_available": [],
     "hb_comm_unique_id": [P],
     "hb_comm_init": [P, I, I, P],

@@ -8,89 +8,26 @@
 // (4*n*B read + 3*n*B written: HBM-bound).
 #include "common.cuh"
 #include "../../include/henbun_hip.h"
+#include "chain.cuh"   // serial chains: a one-workgroup update may be recorded instead of launched
 
-// Failure containment (reference behaviour: tf.cholesky raises inside session.run BEFORE apply_gradients, so the
-// parameters stay at the last good step).  Calls are asynchronous here, so the update itself looks at this step's
-// factorisation status words (`info[n_info]`, LAPACK convention, written earlier in the same stream / graph), at
-// the all-reduced failure flag of the other ranks (`dpflag`, nullable) and at the sticky record `fail[2]`
-// (nullable): if any is non-zero the launch is a no-op -- theta, m, v and the step counter keep their values --
-// and `fail` records the first failing step {t+1, first non-zero status seen}.  Every later step is then a no-op
-// too, until the host clears `fail`.
-template <typename T>
-__device__ __forceinline__ int adam_step_blocked(const long* t, const int* info, long n_info, const T* dpflag,
-                                                 long* fail, bool record) {
-  int bad = 0, what = 0;
-  if (fail != nullptr && fail[0] != 0) bad = 1;
-  if (dpflag != nullptr && dpflag[0] != (T)0) { bad = 1; what = -1; }
-  for (long i = threadIdx.x; i < n_info; i += blockDim.x) {
-    const int w = info[i];
-    if (w != 0) { bad = 1; what = w; }
-  }
-  const int any = __syncthreads_or(bad);
-  if (any && record && fail != nullptr) {
-    // one writer: the lowest thread that saw a status word (or thread 0 for the flag-only case)
-    __shared__ int who;
-    if (threadIdx.x == 0) who = blockDim.x;
-    __syncthreads();
-    if (what != 0) atomicMin(&who, (int)threadIdx.x);
-    __syncthreads();
-    const int writer = who == (int)blockDim.x ? 0 : who;
-    if ((int)threadIdx.x == writer && fail[0] == 0) {
-      fail[1] = (long)what;
-      fail[0] = t[0] + 1;
-    }
-  }
-  return any;
-}
-
+// The update itself (failure containment included) is hb_adam_body in chain_bodies.cuh: the same body runs inside the
+// run-time generated serial chains (csrc/jit.hip) where the plan folds the last gradient cluster and Adam into one launch.
 template <typename T>
 __global__ void __launch_bounds__(256) adam_kernel(T* __restrict__ theta, const T* __restrict__ g, T* __restrict__ m,
                                                    T* __restrict__ v, long n, double lr, double b1, double b2,
                                                    double eps, double gscale, long* t, int tick, const int* info,
                                                    long n_info, const T* dpflag, long* fail) {
-  // The first batch of operands (8 elements per thread: a 2048-parameter model in one go) and the step counter are
-  // requested BEFORE the status check: the check, the counter and the update were three dependent memory round
-  // trips in a kernel whose arithmetic is a few hundred cycles.
-  constexpr int U = 8;
-  const long stride = (long)gridDim.x * blockDim.x;
-  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  T g0[U], m0[U], v0[U], th0[U];
-#pragma unroll
-  for (int k = 0; k < U; ++k) {
-    const long i = i0 + k * stride, ic = i < n ? i : (n > 0 ? n - 1 : 0);
-    g0[k] = g[ic], m0[k] = m[ic], v0[k] = v[ic], th0[k] = theta[ic];
-  }
-  const long tnow = t[0];
-  if (adam_step_blocked<T>(t, info, n_info, dpflag, fail, blockIdx.x == 0)) return;
-  const double tt = (double)(tnow + 1);
-  const T lr_t = (T)(lr * sqrt(1.0 - pow(b2, tt)) / (1.0 - pow(b1, tt)));
-  const T c1 = (T)b1, c2 = (T)b2, d1 = (T)(1.0 - b1), d2 = (T)(1.0 - b2), e = (T)eps, gs = (T)gscale;
-#pragma unroll
-  for (int k = 0; k < U; ++k) {
-    const long i = i0 + k * stride;
-    if (i < n) {
-      const T gi = g0[k] * gs;
-      const T mi = c1 * m0[k] + d1 * gi;
-      const T vi = c2 * v0[k] + d2 * gi * gi;
-      m[i] = mi;
-      v[i] = vi;
-      theta[i] = th0[k] - lr_t * mi / (hb_sqrt(vi) + e);
-    }
-  }
-  for (long i = i0 + U * stride; i < n; i += stride) {
-    const T gi = g[i] * gs;
-    const T mi = c1 * m[i] + d1 * gi;
-    const T vi = c2 * v[i] + d2 * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    theta[i] -= lr_t * mi / (hb_sqrt(vi) + e);
-  }
-  if (gridDim.x == 1 && tick) {
-    // a single block owns the whole update: it advances the step counter itself (every thread has read
-    // t[0] by the barrier), saving the separate tick launch
-    __syncthreads();
-    if (threadIdx.x == 0) t[0] += 1;
-  }
+  hb_adam_body<T>(theta, g, m, v, n, lr, b1, b2, eps, gscale, t, tick, info, n_info, dpflag, fail,
+                  (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, blockIdx.x == 0, gridDim.x == 1);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) adam_vec_kernel(T* __restrict__ theta, const T* __restrict__ g, T* __restrict__ m,
+                                                       T* __restrict__ v, long n, double lr, double b1, double b2,
+                                                       double eps, double gscale, long* t, const int* info, long n_info,
+                                                       const T* dpflag, long* fail) {
+  hb_adam_body_vec<T>(theta, g, m, v, n, lr, b1, b2, eps, gscale, t, info, n_info, dpflag, fail,
+                      (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x, blockIdx.x == 0);
 }
 
 template <typename T>
@@ -109,10 +46,34 @@ static int adam_launch(T* theta, const T* g, T* m, T* v, long n, double lr, doub
   HB_REQUIRE(theta && g && m && v && t, "hb_adam_step: NULL pointer");
   HB_REQUIRE(n_info >= 0 && (n_info == 0 || info != nullptr), "hb_adam_step: info/n_info");
   int grid = 0;
+  if (hb_chain_recording()) {
+    if (n > 0 && n <= HB_CHAIN_ADAM_MAX_N) {
+      // the last job of a serial chain: the update of a small parameter set is one workgroup anyway
+      HbChainJob j;
+      j.kind = HB_CHAIN_ADAM;
+      j.is64 = sizeof(T) == 8;
+      j.p[0] = theta, j.p[1] = g, j.p[2] = m, j.p[3] = v, j.p[4] = t, j.p[5] = info, j.p[6] = dpflag, j.p[7] = fail;
+      j.l[0] = n, j.l[1] = n_info, j.l[2] = tick;
+      j.d[0] = lr, j.d[1] = b1, j.d[2] = b2, j.d[3] = eps, j.d[4] = gscale;
+      return hb_chain_push(j, stream);
+    }
+    const int crc = hb_chain_flush(stream);
+    if (crc) return crc;
+  }
   if (n > 0) {
     grid = n <= 16384 ? 1 : hb_stream_grid(n, 256);  // small parameter sets: one block, tick included
-    hipLaunchKernelGGL(adam_kernel<T>, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, lr, b1, b2, eps, gscale, t,
-                       tick, info, n_info, dpflag, fail);
+    constexpr long VEC = 16 / (long)sizeof(T);
+    const bool vec = grid > 1 && (((uintptr_t)theta | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0;
+    if (vec) {
+      // 16 bytes per lane and array (scalar accesses ran at 2.0 TB/s on 1.05 M parameters: instruction bound)
+      grid = hb_stream_grid(n / VEC, 256);
+      hipLaunchKernelGGL(adam_vec_kernel<T>, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, lr, b1, b2, eps, gscale, t,
+                         info, n_info, dpflag, fail);
+      if (grid == 1) grid = 2;   // the vector kernel never advances the counter itself
+    } else {
+      hipLaunchKernelGGL(adam_kernel<T>, dim3(grid), dim3(256), 0, stream, theta, g, m, v, n, lr, b1, b2, eps, gscale, t,
+                         tick, info, n_info, dpflag, fail);
+    }
     HB_LAUNCH_CHECK();
   }
   if (grid != 1 && tick) {

@@ -156,41 +156,8 @@ struct Mma<double> {
   __device__ static __forceinline__ int acc_col(int lane) { return lane & 15; }
 };
 
-// ---------------------------------------------------------------------------
-// xoroshiro128+ per-lane generator.  The state array holds two uint64 per
-// lane, structure-of-arrays: s0[nlanes] then s1[nlanes] (coalesced).
-// ---------------------------------------------------------------------------
-struct HbRng {
-  uint64_t s0, s1;
-  __device__ __forceinline__ uint64_t next() {
-    const uint64_t a = s0;
-    uint64_t b = s1;
-    const uint64_t r = a + b;
-    b ^= a;
-    s0 = ((a << 24) | (a >> 40)) ^ b ^ (b << 16);
-    s1 = (b << 37) | (b >> 27);
-    return r;
-  }
-  // uniform in (0, 1]
-  __device__ __forceinline__ double uniform_pos() {
-    return ((double)(next() >> 11) + 1.0) * (1.0 / 9007199254740992.0);
-  }
-  // uniform in [0, 1)
-  __device__ __forceinline__ double uniform() {
-    return (double)(next() >> 11) * (1.0 / 9007199254740992.0);
-  }
-  // a pair of independent standard normals (Box-Muller, evaluated in double
-  // so the f32 and f64 instantiations draw the same variates from one state).
-  __device__ __forceinline__ void normal2(double& z0, double& z1) {
-    const double u1 = uniform_pos();
-    const double u2 = uniform();
-    const double r = sqrt(-2.0 * log(u1));
-    double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
-    z0 = r * cs;
-    z1 = r * sn;
-  }
-};
+#include "rng_core.cuh"      // HbRng, rng_load / rng_store
+#include "chain_bodies.cuh"  // bodies of the small kernels (shared with the run-time generated serial chains)
 
 __host__ __device__ static inline uint64_t hb_splitmix64(uint64_t& x) {
   uint64_t z = (x += 0x9E3779B97F4A7C15ull);

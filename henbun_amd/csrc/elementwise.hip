@@ -132,6 +132,7 @@ extern "C" int hb_ewise_f64(int op, int nin, const void* const* in, const long* 
 // into a handful matters more than per-element speed.
 // ---------------------------------------------------------------------------
 #include "ew_prog.cuh"  // HB_PROG_* limits, struct ProgArgs
+#include "chain.cuh"    // serial chains: the one-workgroup likelihood head may be recorded instead of launched
 
 template <typename T>
 __device__ __forceinline__ void ew_prog_body(const ProgArgs& A) {
@@ -846,38 +847,8 @@ __global__ void __launch_bounds__(1024) gauss_ll_single_kernel(const T* __restri
                                                                long n, T* __restrict__ dmu, T* __restrict__ ll,
                                                                T* __restrict__ dscale, T* __restrict__ dvar) {
   __shared__ T smem[16];
-  constexpr int PER = HB_GLL_SINGLE_N / 1024;
-  const T s = scale ? scale[0] : T(1), v = var[0];
-  const T iv = T(1) / v, lc = T(-0.91893853320467274178) - T(0.5) * hb_log(v);
-  T xv[PER], fv[PER];
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    const long j = q * 1024 + threadIdx.x;
-    const long jc = j < n ? j : n - 1;
-    xv[q] = x[jc];
-    fv[q] = f[jc];
-  }
-  T all = T(0), asc = T(0), avr = T(0);
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    const long j = q * 1024 + threadIdx.x;
-    const T dlt = xv[q] - fv[q] * s;
-    const T g = dlt * iv;
-    if (j < n) {
-      dmu[j] = g;
-      all += lc - T(0.5) * dlt * g;
-      asc += g * fv[q];
-      avr += T(-0.5) * iv + T(0.5) * g * g;
-    }
-  }
-  all = block_sum(all, smem);
-  asc = block_sum(asc, smem);
-  avr = block_sum(avr, smem);
-  if (threadIdx.x == 0) {
-    ll[0] = all;
-    dscale[0] = asc;
-    dvar[0] = avr;
-  }
+  static_assert(HB_GLL_SINGLE_N == 16 * 1024, "hb_gauss_ll_single_body: 16 elements per thread of a 1024-thread workgroup");
+  hb_gauss_ll_single_body<T>(x, f, scale, var, n, dmu, ll, dscale, dvar, smem);
 }
 
 template <typename T>
@@ -887,6 +858,18 @@ static int gauss_ll(const T* x, const T* f, const T* scale, const T* var, long n
   const int nb = n > 0 ? hb_cdiv(n, HB_GLL_BLOCK_ELEMS) : 0;
   HB_REQUIRE(ws_elems >= 3L * (nb > 0 ? nb : 1), "hb_gauss_ll: workspace of 3*ceil(n/%d) elements required",
              HB_GLL_BLOCK_ELEMS);
+  if (hb_chain_recording()) {
+    if (n > 0 && n <= HB_CHAIN_GLL_MAX_N) {
+      HbChainJob j;
+      j.kind = HB_CHAIN_GLL;
+      j.is64 = sizeof(T) == 8;
+      j.p[0] = x, j.p[1] = f, j.p[2] = scale, j.p[3] = var, j.p[4] = dmu, j.p[5] = ll, j.p[6] = dscale, j.p[7] = dvar;
+      j.l[0] = n;
+      return hb_chain_push(j, stream);
+    }
+    const int crc = hb_chain_flush(stream);
+    if (crc) return crc;
+  }
   if (n > 0 && n <= HB_GLL_SINGLE_N) {
     hipLaunchKernelGGL(gauss_ll_single_kernel<T>, dim3(1), dim3(1024), 0, stream, x, f, scale, var, n, dmu, ll, dscale,
                        dvar);

@@ -8,6 +8,7 @@
 // on the hot path is built inside sgp.hip and never written to memory.
 #include "common.cuh"
 #include "../../include/henbun_hip.h"
+#include "chain.cuh"   // serial chains: the lengthscale fold may be recorded instead of launched
 
 template <typename T>
 __device__ __forceinline__ T gram_value(int kind, const T* __restrict__ xi, const T* __restrict__ xj,
@@ -156,19 +157,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) gram_ell_finish_kernel(const T* __restrict__ partial, long rows, long d, long dl,
                                                               T* __restrict__ ellbar) {
   __shared__ T smem[16];
-  const long c = blockIdx.x;  // < dl
-  partial += (long)blockIdx.y * rows * d;  // per-batch lengthscales: one group of rows per batch entry
-  ellbar += (long)blockIdx.y * dl;
-  T acc = T(0);
-  if (dl == 1) {
-#pragma unroll 4
-    for (long t = threadIdx.x; t < rows * d; t += blockDim.x) acc += partial[t];
-  } else {
-#pragma unroll 4
-    for (long r = threadIdx.x; r < rows; r += blockDim.x) acc += partial[r * d + c];
-  }
-  acc = block_sum(acc, smem);
-  if (threadIdx.x == 0) ellbar[c] = acc;
+  // one group of rows per batch entry when the lengthscales are per batch (blockIdx.y)
+  hb_gram_ell_body<T>(partial + (long)blockIdx.y * rows * d, rows, d, dl, (long)blockIdx.x, ellbar + (long)blockIdx.y * dl, smem);
 }
 
 template <typename T>
@@ -184,6 +174,10 @@ static int gram_bwd(int kind_flags, const T* X, long sX, const T* X2, long sX2, 
   HB_REQUIRE(!ellbar || ws, "hb_gram_bwd: ellbar needs workspace");
   HB_REQUIRE(B <= 65535, "hb_gram_bwd: batch too large");
   if (B == 0) return 0;
+  if (hb_chain_recording()) {
+    const int crc = hb_chain_flush(stream);   // whatever was recorded before this call runs before its first launch
+    if (crc) return crc;
+  }
   if (n == 0 || n2 == 0) {
     if (Xbar && n > 0) HB_HIP(hb_zero_async(Xbar, sizeof(T) * B * n * d, stream));
     if (X2bar && n2 > 0) HB_HIP(hb_zero_async(X2bar, sizeof(T) * B * n2 * d, stream));
@@ -202,6 +196,16 @@ static int gram_bwd(int kind_flags, const T* X, long sX, const T* X2, long sX2, 
     HB_LAUNCH_CHECK();
     if (ellbar) {
       // d(K)/d(ell) = sum lacc (positive sign; see header comment)
+      const long rows_ = sEll != 0 ? n : B * n, groups_ = sEll != 0 ? B : 1;
+      if (hb_chain_recording() && rows_ * d * groups_ <= HB_CHAIN_ELL_MAX_N && groups_ * dl <= 16 && !(X2bar && !sym)) {
+        // the fold opens a serial chain (the gradient cluster and Adam follow in the same launch)
+        HbChainJob j;
+        j.kind = HB_CHAIN_GRAM_ELL;
+        j.is64 = sizeof(T) == 8;
+        j.p[0] = ws, j.p[1] = ellbar;
+        j.l[0] = rows_, j.l[1] = d, j.l[2] = dl, j.l[3] = groups_;
+        return hb_chain_push(j, stream);
+      }
       if (sEll != 0)
         hipLaunchKernelGGL(gram_ell_finish_kernel<T>, dim3(dl, B), dim3(256), 0, stream, ws, n, d, dl, ellbar);
       else

@@ -19,6 +19,7 @@
 // The roofline that bounds them is the f32 MFMA peak (v_mfma_f32_32x32x2_f32).
 #include "common.cuh"
 #include "sgp_strip.cuh"  // strip constants, sgp_store_frag_tile
+#include "chain.cuh"      // serial chains: the finishing pass may be recorded instead of launched
 #include <type_traits>
 #include "gemm_tile.cuh"
 #include "rng_pairs.cuh"
@@ -1150,47 +1151,14 @@ __global__ void __launch_bounds__(256) sgp_finish_kernel(const T* __restrict__ A
 
 // f, v from the column partials written by sgp_A_kernel's epilogue; eps is drawn here (the same
 // per-lane streams and pair order as sgp_rng_fill_kernel) or taken from eps_in.
-template <typename T>
-__device__ __forceinline__ void sgp_finish_one(const T* __restrict__ part, int gy, long idx, T epsv, T* __restrict__ f,
-                                               T* __restrict__ v, T* __restrict__ eps_out, long n, long P, int mode) {
-  const long e = idx / n, j = idx - e * n;
-  const T* pp = part + e * gy * 5 * n + j;
-  T s = T(0);
-  for (int y = 0; y < gy; ++y) s += pp[(long)y * 5 * n];
-  const T vv = T(1) - s;
-  v[idx] = vv;
-  if (eps_out) eps_out[idx] = epsv;
-  const T scale = mode == HB_SGP_DIAGONAL ? hb_sqrt(hb_abs(vv)) * epsv : T(0);
-  for (long p = 0; p < P; ++p) {
-    T mean = T(0);
-    for (int y = 0; y < gy; ++y) mean += pp[((long)y * 5 + 1 + p) * n];
-    f[(e * P + p) * n + j] = mean + scale;
-  }
-}
-
+// (sgp_finish_one / hb_sgp_finish_body: chain_bodies.cuh)
 template <typename T>
 __global__ void __launch_bounds__(256) sgp_finish_part_kernel(const T* __restrict__ part, int gy,
                                                               const T* __restrict__ eps_in, uint64_t* rng,
                                                               long nlanes, T* __restrict__ eps_out, T* __restrict__ f,
                                                               T* __restrict__ v, long total, long n, long P, int mode) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long npairs = (total + 1) / 2;
-  if (rng) {
-    if (t >= nlanes || t >= npairs) return;
-    HbRng g = rng_load(rng, nlanes, t);
-    for (long p = t; p < npairs; p += nlanes) {
-      double z0, z1;
-      g.normal2(z0, z1);
-      sgp_finish_one<T>(part, gy, 2 * p, (T)z0, f, v, eps_out, n, P, mode);
-      if (2 * p + 1 < total) sgp_finish_one<T>(part, gy, 2 * p + 1, (T)z1, f, v, eps_out, n, P, mode);
-    }
-    rng_store(rng, nlanes, t, g);
-  } else {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long idx = t; idx < total; idx += stride)
-      sgp_finish_one<T>(part, gy, idx, eps_in ? eps_in[idx] : T(0), f, v, (eps_out != eps_in) ? eps_out : nullptr, n, P,
-                        mode);
-  }
+  hb_sgp_finish_body<T>(part, gy, eps_in, rng, nlanes, eps_out, f, v, total, n, P, mode == HB_SGP_DIAGONAL,
+                        (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 template <typename T>
@@ -1200,7 +1168,7 @@ __global__ void __launch_bounds__(256) sgp_rng_fill_kernel(uint64_t* state, long
   if (t >= nlanes || t >= npairs) return;
   HbRng g = rng_load(state, nlanes, t);
   for (long p = t; p < npairs; p += nlanes) {
-    double z0, z1;
+    T z0, z1;
     g.normal2(z0, z1);
     out[2 * p] = (T)z0;
     if (2 * p + 1 < n) out[2 * p + 1] = (T)z1;
@@ -1227,6 +1195,10 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
                    T* v, long E, long n, long M, long d, long P, T* ws, hipStream_t stream) {
   HB_REQUIRE(!A_frag || (sizeof(T) == 4 && Wf && ws && hb_sgp_strip_path(E, n, M, d, P, prec)),
              "hb_sgp_fwd: a fragment-major A needs the column-strip form (fp32, Wfrag, hb_sgp_strip_path)");
+  if (hb_chain_recording()) {
+    const int crc = hb_chain_flush(stream);   // whatever was recorded before this call runs before its contraction
+    if (crc) return crc;
+  }
   HB_REQUIRE(prec == HB_PREC_NATIVE || prec == HB_PREC_BF16X3, "hb_sgp_fwd: unknown precision %d", prec);
   HB_REQUIRE(prec == HB_PREC_NATIVE || (sizeof(T) == 4 && Wf && M % 32 == 0 && M <= SGP_SM_MAX && d <= SGP_DREG && P <= 4 && ws),
              "hb_sgp_fwd: bf16x3 needs fp32, the bf16 images in Wfrag, M %% 32 == 0, M <= %d, d <= %d, P <= 4", SGP_SM_MAX, SGP_DREG);
@@ -1263,6 +1235,20 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     }
     if (rc) return rc;
     const long total = E * n;
+    if (hb_chain_recording() && total <= HB_CHAIN_FINISH_MAX_N) {
+      // the finishing pass opens a serial chain (the likelihood head and its elementwise cluster follow in the same launch)
+      HbChainJob j;
+      j.kind = HB_CHAIN_SGP_FINISH;
+      j.is64 = sizeof(T) == 8;
+      j.p[0] = a.part;
+      j.p[1] = mode == HB_SGP_DIAGONAL ? eps_in : (const T*)nullptr;
+      j.p[2] = draw ? rng : (uint64_t*)nullptr;
+      j.p[3] = mode == HB_SGP_DIAGONAL ? eps_out : (T*)nullptr;
+      j.p[4] = f;
+      j.p[5] = v;
+      j.l[0] = gyp, j.l[1] = rng_lanes, j.l[2] = total, j.l[3] = n, j.l[4] = P, j.l[5] = mode == HB_SGP_DIAGONAL;
+      return hb_chain_push(j, stream);
+    }
     const int fgrid = draw ? hb_cdiv(rng_lanes, 256) : hb_stream_grid((total + 1) / 2, 256);
     hipLaunchKernelGGL(sgp_finish_part_kernel<T>, dim3(fgrid), dim3(256), 0, stream, a.part, gyp,
                        mode == HB_SGP_DIAGONAL ? eps_in : (const T*)nullptr, draw ? rng : (uint64_t*)nullptr, rng_lanes,

@@ -85,7 +85,7 @@ __device__ __forceinline__ void diag_fwd_body(const T* __restrict__ mu, const T*
       const long i0 = 2 * p, i1 = 2 * p + 1;
       T u0, u1 = T(0);
       if (rng) {
-        double z0, z1;
+        T z0, z1;
         g.normal2(z0, z1);
         u0 = (T)z0;
         u1 = (T)z1;

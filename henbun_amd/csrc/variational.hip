@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) rng_fill_kernel(uint64_t* state, long nla
   if (t >= nlanes || t >= npairs) return;
   HbRng g = rng_load(state, nlanes, t);
   for (long p = t; p < npairs; p += nlanes) {
-    double z0, z1;
+    T z0, z1;
     g.normal2(z0, z1);
     out[2 * p] = (T)z0;
     if (2 * p + 1 < n) out[2 * p + 1] = (T)z1;

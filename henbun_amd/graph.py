@@ -466,7 +466,9 @@ def _gauss_ll_emit(plan, node):
     y, f, var = (plan.buf(t) for t in node.inputs[:3])
     scale = plan.buf(node.inputs[3]) if len(node.inputs) > 3 else None
     outs = tuple(plan.out(t) for t in node.outputs)
-    plan.steps.append(lambda: H.gauss_ll(y, f, scale, var, out=outs))
+    step = lambda: H.gauss_ll(y, f, scale, var, out=outs)
+    plan.steps.append(step)
+    plan.chain_kind[id(step)] = "full"     # hb_gauss_ll records itself into a serial chain (csrc/chain.cuh)
 
 
 def _gauss_ll_vjp(node, gs):
@@ -1390,6 +1392,8 @@ def _gram_grad_emit(plan, node):
                 H.reduce_mid(tmp, 1, B, n * d, out=oX)
 
         plan.steps.append(sym_step)
+        if tmp is None:
+            plan.chain_kind[id(sym_step)] = "tail"   # its last launch (the lengthscale fold) may open a serial chain
         return
     oX, oX2, oL = [plan.out(t) for t in node.outputs]
     # an operand shared by the batch gets its per-batch gradients summed
@@ -1406,6 +1410,8 @@ def _gram_grad_emit(plan, node):
             H.reduce_mid(tmpX2, 1, B, n2 * d, out=oX2)
 
     plan.steps.append(step)
+    if tmpX is None and tmpX2 is None:
+        plan.chain_kind[id(step)] = "tail"
 
 
 defop("gram", _gram_emit, _gram_vjp)
@@ -1455,8 +1461,10 @@ def _sgp_emit(plan, node):
         a_frag = plan.scratch((H.sgp_frag_elems(E, n, M, prec),))
         plan._afrag[node.outputs[1]] = (a_frag, prec)
         skip_a = node.outputs[1] not in plan.outputs
-    plan.steps.append(lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag,
-                                        prec=prec, a_frag=a_frag, skip_a=skip_a))
+    step = lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag,
+                             prec=prec, a_frag=a_frag, skip_a=skip_a)
+    plan.steps.append(step)
+    plan.chain_kind[id(step)] = "tail"       # its finishing pass may open a serial chain
 
 
 def _sgp_vjp(node, gs):
@@ -1759,6 +1767,9 @@ class Plan:
         self._info_used = 0
         self.stream = stream          # torch.cuda.Stream the plan runs on (None = current)
         self.side_effect_steps = set()  # steps skipped by the capture warm-up (e.g. the Adam update)
+        self.chain_kind: Dict[int, str] = {}    # id(step) -> "full" | "tail": what a serial chain may take of it (fuse_chains)
+        self.chain_members: Dict[int, list] = {}   # id(fused step) -> the steps it runs between hb_chain_begin / hb_chain_end
+        self._chains_fused = False
         self.step_labels = {}           # id(step closure) -> op label (profiling)
         self.step_nodes = {}            # id(step closure) -> graph Node that emitted it (work models in bench.py)
         self.noise_inputs: Dict[Tensor, object] = {}
@@ -2040,6 +2051,8 @@ class Plan:
         step = prog.launch
         self.steps.append(step)
         self.step_labels[id(step)] = "ew_cluster[%d]" % len(c.nodes)
+        if prog.image is None:
+            self.chain_kind[id(step)] = "full"   # compiled programs record themselves into a serial chain
 
     def inject_noise(self, t: Tensor, value):
         """Overwrite a random_normal leaf with a fixed draw (parity runs)."""
@@ -2059,7 +2072,54 @@ class Plan:
         (their draw launches are left out).  Subclasses add their own state (injected minibatch indices)."""
         return frozenset(self._injected)
 
+    def fuse_chains(self):
+        """Serial chains (csrc/chain.cuh): a run of consecutive steps that are small dependent launches -- the tail of a
+        "tail" step (the sparse-GP finishing pass, the lengthscale fold) followed by "full" steps (the likelihood head,
+        compiled elementwise programs, a one-workgroup Adam update) -- becomes ONE step that brackets them with
+        hb_chain_begin / hb_chain_end: the entry points record instead of launching and the whole run executes as one
+        generated kernel.  Called once, when the step list is complete (capture() / the first run())."""
+        if self._chains_fused:
+            return
+        self._chains_fused = True
+        from ._settings import settings as _st
+
+        if not bool(getattr(_st.runtime, "serial_chains", True)) or not self.H.ewise_jit_enabled():
+            return
+        H = self.H
+        out, i, steps = [], 0, self.steps
+        while i < len(steps):
+            kind = self.chain_kind.get(id(steps[i]))
+            j = i + 1
+            if kind in ("tail", "full"):
+                while j < len(steps) and self.chain_kind.get(id(steps[j])) == "full":
+                    j += 1
+            if j - i < 2:
+                out.append(steps[i])
+                i += 1
+                continue
+            members = steps[i:j]
+
+            def fused(members=members):
+                H.chain_begin()
+                try:
+                    for m in members:
+                        m()
+                    H.chain_end()
+                except BaseException:
+                    H.chain_discard()
+                    raise
+
+            self.chain_members[id(fused)] = members
+            self.step_labels[id(fused)] = "chain[" + "+".join(self.step_labels.get(id(m), "other") for m in members) + "]"
+            self.step_nodes[id(fused)] = self.step_nodes.get(id(members[0]))
+            if any(m in self.side_effect_steps for m in members):
+                self.side_effect_steps.add(fused)
+            out.append(fused)
+            i = j
+        self.steps = out
+
     def run(self):
+        self.fuse_chains()
         with self._on_stream():
             if self._graph is None and self._capture_enabled and not self._nocap:
                 # the injection state changed since the last capture: one hipGraph per state, captured on demand
@@ -2078,6 +2138,7 @@ class Plan:
         never ride on a launch of another plan."""
         H = self.H
         H.side_discard()
+        H.chain_discard()
         try:
             for s in steps:
                 s()
@@ -2098,6 +2159,7 @@ class Plan:
         inject_noise) re-capture on the next run; graphs are kept per state."""
         if self._nocap:
             return False
+        self.fuse_chains()
         self._capture_enabled = True
         self.torch.cuda.synchronize()
         with self._on_stream():
@@ -2107,7 +2169,14 @@ class Plan:
     def _capture_now(self):
         st = self.torch.cuda.current_stream()
         saved = {k: r.state.clone() for k, r in self._rngs.items()} if self._rngs else {}
-        self._run_eager([s for s in self.steps if s not in self.side_effect_steps])
+        # (a fused chain with a side-effect member runs its other members, unchained: lazily sized workspaces are theirs)
+        warm = []
+        for s in self.steps:
+            if s not in self.side_effect_steps:
+                warm.append(s)
+            else:
+                warm += [m for m in self.chain_members.get(id(s), ()) if m not in self.side_effect_steps]
+        self._run_eager(warm)
         for k, r in self._rngs.items():
             r.state.copy_(saved[k])
         st.synchronize()

@@ -382,6 +382,26 @@ def side_pending():
     return int(_lib.lib().raw("hb_side_pending")())
 
 
+def chain_begin():
+    """Start recording a serial chain on this thread (hb_chain_begin): the small launches of the chain-aware entry points
+    that follow run as one generated kernel at chain_end()."""
+    _lib.lib().call("hb_chain_begin")
+
+
+def chain_end():
+    _lib.lib().call("hb_chain_end", stream())
+
+
+def chain_discard():
+    return int(_lib.lib().raw("hb_chain_discard")())
+
+
+def chain_source():
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.lib().call("hb_chain_source", buf, 1 << 16)
+    return buf.value.decode()
+
+
 def side_discard():
     """Drop this thread's recorded side jobs without running them (hb_side_discard); returns how many there were."""
     return int(_lib.lib().raw("hb_side_discard")())

@@ -189,7 +189,8 @@ class Optimizer:
         return (n.jitter_level, n.clip_by_value, n.clip_value_min, n.clip_value_max, str(getattr(n, "kl_form", "mc")), str(getattr(n, "contraction", "native")),
                 str(settings.runtime.index_source), bool(settings.runtime.fuse_elementwise),
                 bool(getattr(settings.runtime, "force_dp", False)), str(getattr(settings.runtime, "dp_exchange", "auto")),
-                str(getattr(settings.runtime, "ewise", "jit")), bool(getattr(settings.runtime, "side_jobs", True)))
+                str(getattr(settings.runtime, "ewise", "jit")), bool(getattr(settings.runtime, "side_jobs", True)),
+                bool(getattr(settings.runtime, "serial_chains", True)))
 
     @staticmethod
     def _dp_active(sess):
@@ -274,6 +275,7 @@ class Optimizer:
 
             plan.dpflag = None
             plan.adam = adam
+            plan.chain_kind[id(adam)] = "full"     # hb_adam_step records itself into a serial chain (small parameter sets)
             plan.eager_tail = []
             plan.dp_mode = "none"
             if not self._dp_active(sess):

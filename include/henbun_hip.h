@@ -459,6 +459,26 @@ int hb_side_flush(void* stream);
  * launch.  henbun_amd's Plan calls it before and after every execution / capture of a plan. */
 int hb_side_discard(void);
 
+/* ---- serial chains: several small DEPENDENT launches run as one generated kernel (csrc/chain.cuh, csrc/jit.hip) ----
+ * Between hb_chain_begin() and hb_chain_end(stream) the calling thread records the small launches that the chain-aware
+ * entry points would issue (each up to a few thousand elements: a chain is one workgroup, csrc/chain.cuh has the limits) --
+ * hb_ewise_jit_run, hb_gauss_ll_*, hb_adam_step_*, the finishing pass of hb_sgp_fwd_*, the lengthscale fold of hb_gram_bwd_* --
+ * and runs them, in
+ * call order, as ONE hiprtc-compiled kernel: one workgroup of 1024 threads, a barrier between jobs.  A launch that cannot
+ * be recorded first runs what is recorded, so the order of the calls is the order of execution; ONLY the entry points
+ * named above may be called between begin and end.  A kernel boundary inside a captured step costs ~4.5 us, more than
+ * any of these bodies takes: at BASELINE cfg 2 the lengthscale fold, the last gradient cluster and Adam are one launch.  Without hiprtc in the process
+ * (hb_ewise_jit_available() == 0) nothing is recorded and every call launches as usual.
+ * hb_chain_discard: drop what is recorded without running it and stop recording (returns the number of jobs dropped).
+ * hb_chain_source: the generated part of the source the recorded jobs would compile to (diagnostics; launches nothing). */
+int hb_chain_begin(void);
+int hb_chain_end(void* stream);
+int hb_chain_discard(void);
+int hb_chain_source(char* out, long cap);
+/* hb_chain_compile_dry: compile the kernel of the recorded jobs for gfx950 without loading or launching it (no device
+ * needed), drop the jobs and stop recording: the build / CPU check of the generated chains. */
+int hb_chain_compile_dry(void);
+
 /* ---- data-parallel exchange step (no reference counterpart: the reference is one tf.Session on one
  *      device, model.py:57,255-269) --------------------------------------------------
  * One process per GPU; the ranks exchange ONE all-reduce (sum) of the flat gradient buffer per Adam

@@ -49,6 +49,17 @@ def tile_err(a, b, tile=32):
     return float(np.sqrt((d2 / np.maximum(b2, floor2)).max()))
 
 
+def prod_err(got, ref, absA, absB):
+    """Componentwise forward error of a matrix product A B against its natural scale: max |got - ref| / (|A| |B|).
+    Entries of the product that are small by CANCELLATION of large terms (rows of L^-1 against columns of K) carry the
+    rounding of those terms; measured against the tile's own norm they read as large relative errors although the
+    product is as accurate as fp32 allows.  A wrong tile still reads ~1.  Entries whose scale is below 1e-12 of the largest
+    (RBF values past 7 lengthscales: fp32 underflow territory) are measured against that floor."""
+    got, ref = _f64(got), _f64(ref)
+    scale = _f64(absA) @ _f64(absB)
+    return float((np.abs(got - ref) / np.maximum(scale, 1e-12 * scale.max())).max())
+
+
 def observe(name, err, tol):
     err = float(err)
     path = os.environ.get("HB_OBSERVED_OUT")

@@ -22,7 +22,7 @@ import henbun_amd as hb
 import henbun_oracle as O
 
 from henbun_amd.models import ExpertsGPR, svgp_data
-from parity import observe, rel_err, tile_err
+from parity import observe, prod_err, rel_err, tile_err
 
 pytestmark = pytest.mark.gpu
 tf = hb.tf
@@ -72,8 +72,9 @@ def test_fp32_cholesky_inverse_chain_against_fp64(H, B, M):
     Wr = np.linalg.inv(Lr)
     Lh, Wh = host(L).reshape(B, M, M), host(W).reshape(B, M, M)
     assert np.all(np.triu(Lh, 1) == 0) and np.all(np.triu(Wh, 1) == 0)
-    observe("chol_inverse_f32/L[%d,%d]" % (B, M), tile_err(Lh, Lr), 1e-5)       # OBS?
-    observe("chol_inverse_f32/W[%d,%d]" % (B, M), tile_err(Wh, Wr), 1e-5)       # OBS?
+    # observed on MI355X (round 3): L 6.1e-8 .. 1.9e-7, W 9.5e-8 .. 3.3e-7
+    observe("chol_inverse_f32/L[%d,%d]" % (B, M), tile_err(Lh, Lr), 2e-6)
+    observe("chol_inverse_f32/W[%d,%d]" % (B, M), tile_err(Wh, Wr), 3e-6)
     # plain factorisation: same kernels without the inverse rows
     L2, info2 = H.cholesky(dev(K))
     assert not info2.cpu().numpy().any() and torch.equal(L2.reshape(L.shape), L)
@@ -116,21 +117,26 @@ def test_fp32_strip_contractions_against_fp64(H, M, n, d, P, prec):
     args = (dev(x), dev(z), dev(ell), W.reshape(M, M), dev(u))
     f, A, v, _ = H.sgp_fwd(*args, eps_in=dev(eps), wfrag=frag, prec=pr)
     tag = "strip_%s[M%d,n%d,d%d,P%d]/" % (prec, M, n, d, P)
-    # W = L^-1 is the kernels' operand, so the forward error carries cond(L) ~ 3 times the fp32 rounding of W
-    observe(tag + "A", tile_err(host(A), Ar), 1e-5)                  # OBS?
-    observe(tag + "v", rel_err(host(v), vr), 1e-5)                   # OBS?
-    observe(tag + "f", rel_err(host(f), fr), 1e-5)                   # OBS?
+    # A = W K(z, x): componentwise against (|W| |K|)_ij -- entries of A far from the diagonal band are small by cancellation
+    # and carry the rounding of the O(1) terms that cancel (per-tile relative error there reads 3e-5 for ANY fp32 product).
+    # Observed on MI355X (round 3), native / bf16x3 alike: A 4.1e-6 .. 6.3e-6 (512-term fp32 dot products), v 3.1e-7 .. 9.0e-7, f 2.1e-7 .. 5.3e-7
+    Wr = np.linalg.inv(Lr)
+    Kzx = O.rbf_K(torch.as_tensor(z), torch.as_tensor(x), torch.as_tensor(ell)).numpy()
+    observe(tag + "A", prod_err(host(A), Ar, np.abs(Wr), np.abs(Kzx)), 2e-5)
+    observe(tag + "v", rel_err(host(v), vr), 8e-6)
+    observe(tag + "f", rel_err(host(f), fr), 5e-6)
     a_frag = torch.zeros(H.sgp_frag_elems(1, n, M, pr), dtype=F32, device="cuda")
     f2, _, v2, _ = H.sgp_fwd(*args, eps_in=dev(eps), wfrag=frag, a_frag=a_frag, skip_a=True, prec=pr)
     assert torch.equal(f2, f) and torch.equal(v2, v)
     Lb, ub, zb, lb, _ = H.sgp_bwd(*(args + (dev(eps), None, v, dev(fbar))), wfrag=frag, a_frag=a_frag, prec=pr)
-    observe(tag + "Lbar", tile_err(host(Lb).reshape(M, M), gr[0]), 2e-5)      # OBS?
-    observe(tag + "ubar", tile_err(host(ub), gr[1]), 1e-5)                    # OBS?
-    observe(tag + "zbar", tile_err(host(zb), gr[2]), 2e-5)                    # OBS?
+    # observed: Lbar 2.8e-7 .. 1.2e-6 (n-deep fp32 sums), ubar 1.6e-7 .. 2.0e-7, zbar 2.8e-7 .. 7.5e-7
+    observe(tag + "Lbar", tile_err(host(Lb).reshape(M, M), gr[0]), 1e-5)
+    observe(tag + "ubar", tile_err(host(ub), gr[1]), 2e-6)
+    observe(tag + "zbar", tile_err(host(zb), gr[2]), 7e-6)
     # ellbar is one number per dimension summed over all M n entries of Kbar o dK/dell with heavy cancellation:
     # measured against the sum of absolute terms' scale max(1, |ellbar|)
     e_ell = np.abs(host(lb).reshape(-1) - gr[3].reshape(-1)).max() / max(1.0, np.abs(gr[3]).max())
-    observe(tag + "ellbar", e_ell, 1e-4 if bf3 else 5e-5)                     # OBS?
+    observe(tag + "ellbar", e_ell, 5e-5 if bf3 else 1e-5)     # observed: native 1.8e-7 .. 1.6e-6, bf16x3 1.2e-6 .. 8.1e-6
 
 
 @pytest.mark.parametrize("tA,tB", [(False, False), (True, False), (False, True)])
@@ -144,13 +150,14 @@ def test_fp32_in_workgroup_split_k_gemm_against_fp64(H, tA, tB):
         sq = (lambda t: t if batch > 1 else t[0])
         A_, B_ = dev(sq(a)), dev(sq(b))
         tag = "matmul_wgk[%d,%d,tA%d,tB%d]/" % (batch, m, tA, tB)
-        observe(tag + "plain", tile_err(host(H.matmul(A_, B_, transA=tA, transB=tB)), sq(full)), 1e-5)   # OBS?
+        # observed (plain / Phi / symmetrised alike): 1.2e-7 .. 4.7e-7
+        observe(tag + "plain", tile_err(host(H.matmul(A_, B_, transA=tA, transB=tB)), sq(full)), 4e-6)
         phi = np.tril(full, -1) + 0.5 * np.einsum("bii->bi", full)[:, :, None] * np.eye(m)
-        observe(tag + "phi", tile_err(host(H.matmul(A_, B_, transA=tA, transB=tB, epilogue=H.MM_PHI_OUT)), sq(phi)), 1e-5)
+        observe(tag + "phi", tile_err(host(H.matmul(A_, B_, transA=tA, transB=tB, epilogue=H.MM_PHI_OUT)), sq(phi)), 4e-6)
         symlow = 0.5 * (np.tril(full) + np.transpose(np.tril(full, -1), (0, 2, 1)))
         out = torch.full(tuple(sq(full).shape), float("nan"), dtype=F32, device="cuda")
         observe(tag + "symlow", tile_err(host(H.matmul(A_, B_, transA=tA, transB=tB, out=out, epilogue=H.MM_SYMLOW_OUT)),
-                                         sq(symlow)), 1e-5)
+                                         sq(symlow)), 4e-6)
 
 
 # ------------------------------------------------------------------------------------------------ 2. cfg 5, bf16x3
@@ -182,14 +189,18 @@ def test_cfg5_bf16x3_kernels_full_batched_size_against_the_oracle(H):
         Lr = host(L[e])
         fr, vr, _, gr = _sgp_reference(Lr, z[e], ells[e], x, u[e], eps[e], fbar[e], "diagonal")
         tag = "cfg5_bf16x3_kernels[gp%d]/" % e
-        # cond(L) ~ 3e1 at this jitter: the forward carries ~cond(L) x fp32 rounding of W
-        observe(tag + "f", rel_err(host(f[e]), fr), 2e-4)                        # OBS?
-        observe(tag + "v", np.abs(host(v[e]) - vr).max(), 2e-4)                 # OBS?
-        observe(tag + "Lbar", tile_err(host(Lb[e]), gr[0]), 5e-4)                # OBS?
-        observe(tag + "ubar", tile_err(host(ub[e]), gr[1]), 2e-4)                # OBS?
-        observe(tag + "zbar", tile_err(host(zb[e]), gr[2]), 5e-4)                # OBS?
+        # inducing points 0.5 (expert 0: 0.83; gate 7: 0.36) lengthscales apart, jitter 1e-3: cond(K) ~ 1e3 (gp 0) .. 1e5
+        # (gp 7), and W = L^-1 -- rounded to fp32 -- is the kernels' operand: the errors below scale with cond(L), not with
+        # the kernels.  Observed on MI355X (round 3), gp 0 / gp 7:
+        #   f 7.0e-6 / 4.7e-5   v 6.1e-7 / 2.2e-6   Lbar 5.9e-5 / 5.9e-4   ubar 1.2e-6 / 3.0e-5   zbar 6.9e-5 / 5.8e-4
+        #   ellbar 3.7e-4 / 2.6e-3
+        observe(tag + "f", rel_err(host(f[e]), fr), 3e-4)
+        observe(tag + "v", np.abs(host(v[e]) - vr).max(), 2e-5)
+        observe(tag + "Lbar", tile_err(host(Lb[e]), gr[0]), 4e-3)
+        observe(tag + "ubar", tile_err(host(ub[e]), gr[1]), 2.5e-4)
+        observe(tag + "zbar", tile_err(host(zb[e]), gr[2]), 4e-3)
         e_ell = np.abs(host(lb[e]).reshape(-1) - gr[3].reshape(-1)).max() / max(1.0, np.abs(gr[3]).max())
-        observe(tag + "ellbar", e_ell, 1e-3)                                     # OBS?
+        observe(tag + "ellbar", e_ell, 1.5e-2)
 
 
 def test_cfg5_bf16x3_model_full_size_against_the_fp64_path():
@@ -226,6 +237,10 @@ def test_cfg5_bf16x3_model_full_size_against_the_fp64_path():
             del m, opt
             torch.cuda.empty_cache()
     (v3, g3), (v64, g64) = res["bf16x3"], res["f64"]
-    observe("cfg5_bf16x3_model/ELBO", abs(v3 - v64) / abs(v64), 1e-3)            # OBS?
+    # observed on MI355X (round 3): ELBO 4.1e-6; worst 32-entry tile of z 4.6e-3, lengthscales 1.6e-3, q_mu 1.3e-3,
+    # q_sqrt 1.4e-3, k_var 2.7e-5, k_var_r 1.6e-5, var 4.0e-5 (cond(Kmm + 1e-4 I) ~ 1e4 .. 1e6 over the eight GPs)
+    observe("cfg5_bf16x3_model/ELBO", abs(v3 - v64) / abs(v64), 4e-5)
+    bound = {"model.gp.z": 3e-2, "model.gp.kern.lengthscales": 1e-2, "model.u.q_mu": 1e-2, "model.u.q_sqrt": 1e-2,
+             "model.k_var": 2.5e-4, "model.k_var_r": 1.5e-4, "model.var": 3e-4}
     for k in sorted(g64):
-        observe("cfg5_bf16x3_model/" + k, tile_err(g3[k], g64[k]), 5e-2)
+        observe("cfg5_bf16x3_model/" + k, tile_err(g3[k], g64[k]), bound[k])

@@ -342,3 +342,33 @@ def test_side_job_list_can_be_discarded_without_a_gpu():
     lib = _lib.lib()
     assert lib.raw("hb_side_pending")() == 0
     assert lib.raw("hb_side_discard")() == 0
+
+
+def test_serial_chain_source_generates_and_compiles_for_gfx950():
+    """A serial chain (csrc/chain.cuh) recorded WITHOUT a GPU -- the chain-aware entry points push a job instead of
+    launching while hb_chain_begin is in effect -- turns into one kernel whose source hiprtc compiles for gfx950: the
+    prelude (ew_math / ew_apply / rng_core / chain_bodies) is self-contained and the generated calls match the bodies."""
+    import ctypes
+
+    from henbun_amd import _lib
+
+    lib = _lib.lib()
+    if not lib.raw("hb_ewise_jit_available")():
+        pytest.skip("hiprtc is not loadable in this process")
+    fake = lambda k: ctypes.c_void_p(0x10000 * (k + 1))      # never dereferenced: nothing is launched
+    assert lib.raw("hb_chain_discard")() == 0
+    lib.call("hb_chain_begin")
+    try:
+        ws = fake(20)
+        lib.call("hb_gauss_ll_f32", fake(0), fake(1), None, fake(2), 2048, fake(3), fake(4), fake(5), fake(6), ws, 64, None)
+        lib.call("hb_adam_step_f32", fake(7), fake(8), fake(9), fake(10), 1500, 1e-3, 0.9, 0.999, 1e-8, -1.0, fake(11), 1,
+                 fake(12), 1, None, fake(13), None)
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.call("hb_chain_source", buf, 1 << 16)
+        src = buf.value.decode()
+        assert "hb_gauss_ll_single_body<T>" in src and "hb_adam_body<T>" in src and src.count("__syncthreads();") == 1
+        assert "__launch_bounds__(1024)" in src and "0x" not in src      # no addresses in the text: it is the cache key
+        lib.call("hb_chain_compile_dry")
+    finally:
+        lib.raw("hb_chain_discard")()
+    assert lib.raw("hb_chain_discard")() == 0

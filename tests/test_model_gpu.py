@@ -96,10 +96,13 @@ def test_svgp_fp32_tracks_fp64():
         val, grads = opt.gradients(minibatch_size=1024, indices=data[5])
         fn, params = oracle_svgp(m, data, 1e-5, "diagonal")
         ref_val, ref = O.grads_of(fn, params)
-    observe("svgp_fp32_tracks_fp64/ELBO", abs(val - ref_val.item()) / abs(ref_val.item()), 2e-3)      # OBS?
+    # observed on MI355X (round 3): ELBO 6.3e-6; worst 32-entry tile of z 4.9e-3, lengthscales 8.0e-4, q_mu 6.9e-4,
+    # q_sqrt 6.4e-4, k_var 8.6e-6, var 8.8e-6 (jitter 1e-5: cond(Kmm) ~ 1e5, fp32 unit roundoff 6e-8)
+    observe("svgp_fp32_tracks_fp64/ELBO", abs(val - ref_val.item()) / abs(ref_val.item()), 5e-5)
+    bound = {"model.gp.z": 4e-2, "model.gp.kern.lengthscales": 8e-3, "model.u.q_mu": 6e-3, "model.u.q_sqrt": 6e-3}
     for mine, theirs in NAMES:
         # worst 32-entry tile of every leaf gradient (tests/parity.py), not max-norm over the whole leaf
-        observe("svgp_fp32_tracks_fp64/" + mine, tile_err(grads[mine], ref[theirs].numpy()), 5e-2)    # OBS?
+        observe("svgp_fp32_tracks_fp64/" + mine, tile_err(grads[mine], ref[theirs].numpy()), bound.get(mine, 8e-5))
 
 
 @pytest.mark.parametrize("capture,fuse", [(True, True), (False, True), (True, False)])
@@ -444,9 +447,13 @@ def test_cfg2_full_size_properties_fp32():
         assert v1 == v2 and all(np.array_equal(g1[k], g2[k]) for k in g1), "same inputs must give the same bits"
         fn, params = oracle_svgp(m, data, 1e-4, "diagonal")
         ref_val, ref = O.grads_of(fn, params)
-    observe("cfg2_fullsize_fp32/ELBO", abs(v1 - ref_val.item()) / abs(ref_val.item()), 2e-3)           # OBS?
+    # observed on MI355X (round 3): ELBO 6.5e-6 (inside the 1e-5 bar in fp32); worst 32-entry tile of z 1.3e-3,
+    # lengthscales 8.4e-5, q_mu 2.0e-4, q_sqrt 2.0e-4, k_var 2.7e-7, var 1.0e-5
+    observe("cfg2_fullsize_fp32/ELBO", abs(v1 - ref_val.item()) / abs(ref_val.item()), 5e-5)
+    bound = {"model.gp.z": 1e-2, "model.gp.kern.lengthscales": 6e-4, "model.u.q_mu": 1.9e-3, "model.u.q_sqrt": 1.9e-3,
+             "model.k_var": 2.5e-6, "model.var": 1e-4}
     for mine, theirs in NAMES:
-        observe("cfg2_fullsize_fp32/" + mine, tile_err(g1[mine], ref[theirs].numpy()), 5e-2)           # OBS?
+        observe("cfg2_fullsize_fp32/" + mine, tile_err(g1[mine], ref[theirs].numpy()), bound[mine])
     # kernel identities at the same size
     H = m._session.H
     rng = np.random.RandomState(0)
