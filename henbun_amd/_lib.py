@@ -82,6 +82,7 @@ _TYPED = {
     "hb_gram_fwd": [I, P, L, P, L, P, L, L, P, L, L, L, L, D, P],
     "hb_gram_bwd": [I, P, L, P, L, P, L, L, P, P, P, P, L, L, L, L, P, P],
     "hb_matmul": [P, P, P, L, L, L, L, L, L, L, L, L, L, I, I, D, D, P, L, I, I, P, L, P],
+    "hb_matmul_colsum": [P, P, P, P, L, L, L, L, L, L, P, L, P],
     "hb_cholesky": [P, P, L, L, P, P],
     "hb_cholesky_inverse": [P, P, P, L, L, P, P, P, I, P],
     "hb_trinv": [P, P, L, L, P, P],

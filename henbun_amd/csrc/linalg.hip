@@ -27,6 +27,11 @@ struct MmArgs {
   int to_ws;  // results go to the workspace slabs and the finish kernel writes C (split-K, or SYM_OUT)
   int bfast;  // batch index fastest in blockIdx.x (batch % 8 == 0), see matmul_kernel
   T* ws;
+  // HB_MM_COLSUM_B (hb_matmul_colsum: the bias gradient of a MatBias layer next to its weight gradient): the column
+  // sums of op(B) = B[K][N] are accumulated by the workgroups of the first tile row while B streams through them;
+  // colsum_ws: per-slab partials [S][N] (split-K), colsum: the result [N]
+  T* colsum;
+  T* colsum_ws;
 };
 
 template <typename T>
@@ -134,8 +139,40 @@ __global__ void __launch_bounds__(256) matmul_kernel(MmArgs<T> a) {
       if (TB) return *reinterpret_cast<const VT*>(&Bb[(c < N ? c : Nm1) * ldb + k]);
       return *reinterpret_cast<const VT*>(&Bb[k * ldb + (c < N ? c : N - VEC)]);
     };
-    auto fb4 = [&](VT raw, int k, int n) -> VT { return col0 + n < N ? raw : zero; };
+    // column sums of B on the way (HB_MM_COLSUM_B; TA, !TB only): a thread's B groups always sit on the same VEC columns
+    // (group index = g * 256 + tid, BN / VEC groups per k row, 256 % (BN / VEC) == 0), so it keeps ONE running vector; the
+    // engine stashes every tile of [kbeg, kend) exactly once, in order, and then re-stashes the last one as a look-ahead
+    // that is never consumed: only the first (kend - kbeg) / BK * groups-per-thread stashes count.
+    VT colacc = zero;
+    int cs_left = 0;
+    if (TA && !TB && (a.flags & HB_MM_COLSUM_B) && row0 == 0) cs_left = ((kend - kbeg) / G::BK) * ((BT * G::BK / VEC) / 256);
+    auto fb4 = [&](VT raw, int k, int n) -> VT {
+      const VT v = col0 + n < N ? raw : zero;
+      if (TA && !TB) {
+        if (cs_left > 0) {
+          colacc += v;
+          --cs_left;
+        }
+      }
+      return v;
+    };
     g.template run_vec<(TA ? HB_MC : HB_KC), (TB ? HB_KC : HB_MC)>(kbeg, kend, la4, fa4, lb4, fb4, lds);
+    if (TA && !TB && (a.flags & HB_MM_COLSUM_B) && row0 == 0) {
+      // 256 / (BT / VEC) threads hold partial sums of the same VEC columns: fold them through LDS (free after run_vec)
+      constexpr int GPR = BT / VEC, ROWS = 256 / GPR;
+      T* red = lds;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) red[(threadIdx.x / GPR) * BT + (threadIdx.x % GPR) * VEC + e] = colacc[e];
+      __syncthreads();
+      if ((int)threadIdx.x < BT && col0 + (int)threadIdx.x < N) {
+        T sum = T(0);
+#pragma unroll 4
+        for (int r = 0; r < ROWS; ++r) sum += red[r * BT + threadIdx.x];   // fixed order
+        T* dst = a.to_ws ? a.colsum_ws + (long)s * N : a.colsum;
+        dst[col0 + threadIdx.x] = sum;
+      }
+      __syncthreads();
+    }
   } else {
     g.template run<!TA, TB>(kbeg, kend, la, fa, lb, fb, lds);
   }
@@ -196,6 +233,26 @@ template <typename T>
 __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) {
   const long total = a.batch * a.M * a.N;
   const long stride = (long)gridDim.x * blockDim.x;
+  if ((a.flags & HB_MM_COLSUM_B) && a.colsum) {
+    // the column sums of B ride along: S <= 64 slab partials per column.  16 lanes per column, every lane's (at most
+    // four) loads independent, then a fixed-order fold across the 16 lanes: one memory round trip (a serial loop over the
+    // slabs is one dependent round trip PER SLAB -- it tripled the duration of this launch)
+    const int sl = threadIdx.x & 15;
+    for (long cb = blockIdx.x; cb * 16 < a.N; cb += gridDim.x) {
+      const long c = cb * 16 + (threadIdx.x >> 4);
+      const long cc = c < a.N ? c : a.N - 1;
+      T v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int s = sl + 16 * q;
+        v[q] = s < a.S ? a.colsum_ws[(long)s * a.N + cc] : T(0);
+      }
+      T acc = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+      if (sl == 0 && c < a.N) a.colsum[c] = acc;
+    }
+  }
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const long b = t / (a.M * a.N);
     const long rem = t - b * a.M * a.N;
@@ -460,7 +517,8 @@ int matmul_wgk_launch<float>(const MmArgs<float>& a, int transA, int transB, hip
 template <typename T>
 static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long N, long K, long lda, long ldb,
                          long ldc, long sA, long sB, long sC, int transA, int transB, double alpha, double beta,
-                         const T* bias, long sBias, int act, int flags, T* ws, long ws_elems, hipStream_t stream) {
+                         const T* bias, long sBias, int act, int flags, T* ws, long ws_elems, hipStream_t stream,
+                         T* colsum = nullptr) {
   HB_REQUIRE(batch >= 0 && M >= 0 && N >= 0 && K >= 0, "hb_matmul: negative extent");
   HB_REQUIRE(A && B && C, "hb_matmul: NULL pointer");
   HB_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "hb_matmul: leading dimension too small");
@@ -479,6 +537,14 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   a.bias = bias; a.sBias = sBias;
   a.act = act; a.flags = flags;
   a.ws = ws;
+  a.colsum = nullptr;
+  a.colsum_ws = nullptr;
+  if (colsum) {
+    // the slab partials of the column sums sit at the end of the workspace (64 slabs at most)
+    HB_REQUIRE(ws && ws_elems > 64 * N, "hb_matmul_colsum: workspace too small");
+    ws_elems -= 64 * N;
+    a.colsum_ws = ws + ws_elems;
+  }
   // Tile / split choice.  These are latency-and-occupancy problems more often than throughput ones: a
   // 128x128 tile (64x64 per wave: 4 MFMAs per fragment pair) has the lowest staging cost per MFMA but
   // only pays when there are enough of them to cover the 256 CUs; otherwise 64x64 tiles, and the
@@ -547,7 +613,8 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
     constexpr long VEC0 = 16 / sizeof(T);
     const bool aligned0 = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % VEC0 == 0 && ldb % VEC0 == 0 &&
                           sA % VEC0 == 0 && sB % VEC0 == 0;
-    if (a.to_ws && matmul_wgk_ok<T>(a, M, N, K, batch, flags, aligned0)) return matmul_wgk_launch<T>(a, transA, transB, stream);
+    if (!colsum && a.to_ws && matmul_wgk_ok<T>(a, M, N, K, batch, flags, aligned0))
+      return matmul_wgk_launch<T>(a, transA, transB, stream);
   }
   const long tiles_final = (long)hb_cdiv(M, BT) * hb_cdiv(N, BT);
   HB_REQUIRE(tiles_final * S * batch < 2147483647L, "hb_matmul: grid too large");
@@ -557,6 +624,16 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % VEC == 0 && ldb % VEC == 0 &&
                        sA % VEC == 0 && sB % VEC == 0;
   const bool fast = aligned && K % 16 == 0 && K > 0 && (!transA || M % VEC == 0) && (transB || N % VEC == 0);
+  // column sums inside the GEMM: the vector path of the A^T B form, 64-tiles, every slab a whole number of k-steps
+  bool colsum_fused = false;
+  if (colsum) {
+    const long kchunk = (((K + S - 1) / S + 15) / 16) * 16;
+    colsum_fused = fast && transA && !transB && batch == 1 && BT == 64 && K % 16 == 0 && (K % kchunk) % 16 == 0;
+    if (colsum_fused) {
+      a.flags |= HB_MM_COLSUM_B;
+      a.colsum = colsum;
+    }
+  }
 #define HB_MM_LAUNCH2(TA_, TB_, F_)                                                                 \
   do {                                                                                              \
     if (BT == 128)                                                                                  \
@@ -587,7 +664,26 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
                        a);
     HB_LAUNCH_CHECK();
   }
+  if (colsum && !colsum_fused) {
+    // shapes the fused form does not take: a reduction launch of its own (sequential on the stream: ws is free again)
+    if (sizeof(T) == 4)
+      return hb_reduce_f32(HB_RED_SUM, (const float*)B, (float*)colsum, 1, K, N, (float*)ws, ws_elems, stream);
+    return hb_reduce_f64(HB_RED_SUM, (const double*)B, (double*)colsum, 1, K, N, (double*)ws, ws_elems, stream);
+  }
   return 0;
+}
+
+extern "C" int hb_matmul_colsum_f32(const float* A, const float* B, float* C, float* colsum, long M, long N, long K, long lda,
+                                    long ldb, long ldc, float* ws, long ws_elems, void* stream) {
+  HB_REQUIRE(colsum && ldb == N, "hb_matmul_colsum: colsum is NULL or B is not contiguous (ldb != N)");
+  return matmul_launch<float>(A, B, C, 1, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, 0, 1.0, 0.0, nullptr, 0, HB_ACT_NONE, 0, ws,
+                              ws_elems, (hipStream_t)stream, colsum);
+}
+extern "C" int hb_matmul_colsum_f64(const double* A, const double* B, double* C, double* colsum, long M, long N, long K,
+                                    long lda, long ldb, long ldc, double* ws, long ws_elems, void* stream) {
+  HB_REQUIRE(colsum && ldb == N, "hb_matmul_colsum: colsum is NULL or B is not contiguous (ldb != N)");
+  return matmul_launch<double>(A, B, C, 1, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, 0, 1.0, 0.0, nullptr, 0, HB_ACT_NONE, 0, ws,
+                               ws_elems, (hipStream_t)stream, colsum);
 }
 
 extern "C" int hb_matmul_f32(const float* A, const float* B, float* C, long batch, long M, long N, long K, long lda,
@@ -1390,6 +1486,7 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
   // any is consumed: tile, B rows and A rows used to be three dependent round trips (load -> select / LDS store ->
   // next loads), ~2000 cycles each on data the previous launch has just written.
   typename MM::Acc acc[2];
+  HB_PSTAMP(4);
   const int pc = (k - 1) * C64_NB;
   VT tileF[2][4];   // factor form: 16 bytes per lane and register group
   T tileU[2][16];   // update form: one element per register
@@ -1412,6 +1509,7 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) tileU[sj][r] = src[(hrow0 + MM::acc_row(lane, r)) * M + col0 + sj * 32 + li];
     }
+    HB_PSTAMP(5);
     if (k > 0) {
       // the panel rows come in with coalesced 16-byte loads (16 lanes per 256-byte row) and are re-read from LDS as MFMA
       // fragments: a lane loading its own fragment row directly makes every load instruction touch 64 different cache
@@ -1423,6 +1521,7 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
         const int r = p * 16 + (tid >> 4), c4 = (tid & 15) * 4;
         bstage[p] = *reinterpret_cast<const VT*>(L + (col0 + r) * M + pc + c4);
       }
+      HB_PSTAMP(6);
       const T* ap = ((yt && !ydiag) ? Y : L) + (ydiag ? col0 : row0) * M + pc;
 #pragma unroll
       for (int p = 0; p < 8; ++p) {

@@ -516,6 +516,9 @@ def reduce_mean(x, axis=None, keepdims=False, keep_dims=None) -> Tensor:
 
 def _reduce_emit(plan, node):
     H = plan.H
+    if node.id in plan._fused_colsum:
+        plan.out(node.outputs[0])    # written by the weight-gradient GEMM that streams the same operand (hb_matmul_colsum)
+        return
     x, out = plan.buf(node.inputs[0]), plan.out(node.outputs[0])
     a = node.attrs
     op = H.RED_SUM if a["kind"] == "sum" else H.RED_MAX
@@ -885,6 +888,11 @@ def _matmul_emit(plan, node):
         plan._fused_matutil.add(cons[0].id)
     else:
         out = plan.out(y)
+    csn = plan._colsum_of.get(node.id)
+    if csn is not None and not epi:
+        cout = plan.out(csn.outputs[0])
+        plan.steps.append(lambda: H.matmul_colsum(a, b, out=out, colsum=cout))
+        return
     if at.get("actgrad"):
         # third input = the activation output Y: C = (op(A) op(B)) * act'(Y)
         plan.steps.append(lambda: H.matmul(a, b, transA=at["ta"], transB=at["tb"], act=at["actgrad"], actgrad=bias, out=out))
@@ -1805,6 +1813,30 @@ class Plan:
             for t in n.inputs:
                 consumers.setdefault(t, []).append(n)
         self._consumers = consumers
+        # Weight gradient + bias gradient of a MatBias layer from one pass over the incoming gradient G: a 2-D product
+        # X^T G whose right operand is also column-summed (reduce over axis 0) becomes hb_matmul_colsum -- the GEMM folds
+        # the columns of G while it streams them, and the stand-alone reduction launches (two per layer) disappear.
+        self._colsum_of: Dict[int, Node] = {}    # matmul node id -> the reduce node it absorbs
+        self._fused_colsum = set()               # ids of absorbed reduce nodes
+        for n in order:
+            if (n.op != "matmul" or not n.attrs["ta"] or n.attrs["tb"] or n.attrs.get("actgrad") or len(n.inputs) != 2
+                    or n.attrs["act"] != "none" or len(n.inputs[0].shape) != 2 or len(n.inputs[1].shape) != 2):
+                continue
+            gmat = n.inputs[1]
+            for r in consumers.get(gmat, []):
+                ra = r.attrs if r.op == "reduce" else None
+                if (ra is None or r.id in self._fused_colsum or ra["kind"] != "sum" or ra["K1"] != 1
+                        or ra["R"] != gmat.shape[0] or ra["K2"] != gmat.shape[1]):
+                    continue
+                cl = self._clusters.get(r.id)
+                if cl is not None and len(cl.nodes) > 1:
+                    continue       # the reduction is part of a fused elementwise program
+                rout = r.outputs[0]
+                if any(self._order_pos[c.id] < self._order_pos[n.id] for c in consumers.get(rout, [])):
+                    continue       # somebody reads the sums before the GEMM has run
+                self._colsum_of[n.id] = r
+                self._fused_colsum.add(r.id)
+                break
         self._emitted: List[Node] = []      # nodes in emission order
         self._side_cands: List[dict] = []   # small independent steps that may ride on a later host launch (side jobs)
         # minibatch gathers first: they depend on nothing, and emitted early they can ride on the first launch of the

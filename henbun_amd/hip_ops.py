@@ -630,6 +630,24 @@ def matmul(A, B, transA=False, transB=False, alpha=1.0, bias=None, act="none", l
     return out
 
 
+def matmul_colsum(A, B, out=None, colsum=None):
+    """(A^T B, column sums of B) for A [K, M], B [K, N]: the weight and bias gradients of a MatBias layer from one pass over
+    the incoming gradient (hb_matmul_colsum)."""
+    _chk(A), _chk(B)
+    K, M = A.shape[-2], A.shape[-1]
+    N = B.shape[-1]
+    assert A.dim() == 2 and B.dim() == 2 and B.shape[0] == K
+    if out is None:
+        out = _empty((M, N), dtype=A.dtype, device=A.device)
+    if colsum is None:
+        colsum = _empty((N,), dtype=A.dtype, device=A.device)
+    assert colsum.numel() == N and colsum.is_contiguous()
+    ws = workspace(A.dtype, A.device, 1 << 22)
+    _lib.lib().call("hb_matmul_colsum" + _suf(A), _p(A), _p(B), _p(out), _p(colsum), M, N, K, M, N, N, _p(ws), ws.numel(),
+                    stream())
+    return out, colsum
+
+
 def cholesky(A, out=None, info=None):
     """L = chol(A) (lower), batched over leading dims.  Returns (L, info[B] int32 device tensor)."""
     _chk(A)

@@ -299,8 +299,9 @@ enum {
                           being differentiated, [batch, M, N] contiguous (sBias = M*N or 0), and `act` names the
                           activation: y(1-y), [y > 0], 1-y^2.  The MLP backward's "dx GEMM, then activation-gradient
                           pass" in one launch; beta must be 0 and no other flag may be set */,
-  HB_MM_SYMLOW_OUT = 32 /* C[i][j] = C[j][i] = 0.5 * result[max(i,j)][min(i,j)] (hb_matutil mode 4 as an epilogue): only the
+  HB_MM_SYMLOW_OUT = 32, /* C[i][j] = C[j][i] = 0.5 * result[max(i,j)][min(i,j)] (hb_matutil mode 4 as an epilogue): only the
                           tiles touching the lower triangle are computed; square result, no bias / activation / beta */
+  HB_MM_COLSUM_B = 64   /* (set by hb_matmul_colsum_*) the column sums of op(B) are produced next to C */
 };
 enum { HB_ACT_NONE = 0, HB_ACT_SIGMOID = 1, HB_ACT_RELU = 2, HB_ACT_TANH = 3 };
 /* C[b] = act(alpha * op(A[b]) op(B[b]) + bias[b]) + beta * C[b], op = transpose if trans?.
@@ -317,6 +318,17 @@ int hb_matmul_f64(const double* A, const double* B, double* C, long batch, long 
                   long lda, long ldb, long ldc, long sA, long sB, long sC, int transA, int transB,
                   double alpha, double beta, const double* bias, long sBias, int act, int flags,
                   double* ws, long ws_elems, void* stream);
+
+/* C = A^T B together with colsum[n] = sum_k B[k][n]: the weight gradient dW = X^T G of a MatBias layer AND its bias
+ * gradient db = sum of the rows of G (reference nn.py:31-32 backward: tf.gradients of x @ w + b) from ONE pass over
+ * G -- the workgroups of the first tile row fold the columns of B while it streams through them, the split-K finish
+ * launch folds the slab partials; no stand-alone reduction launches.  A: [K, M] (lda), B: [K, N] (ldb), C: [M, N]; one
+ * matrix; ws as in hb_matmul plus 64*N elements.  Shapes the fused form does not take (unaligned operands, K % 16 != 0)
+ * fall back to hb_matmul followed by hb_reduce: same results up to summation order. */
+int hb_matmul_colsum_f32(const float* A, const float* B, float* C, float* colsum, long M, long N, long K, long lda, long ldb,
+                         long ldc, float* ws, long ws_elems, void* stream);
+int hb_matmul_colsum_f64(const double* A, const double* B, double* C, double* colsum, long M, long N, long K, long lda,
+                         long ldb, long ldc, double* ws, long ws_elems, void* stream);
 
 /* K4: L = chol(A), lower, batched [B,M,M]; the strict upper triangle of L is
  * zeroed; info[B] (device) receives 0 or k+1.  Replaces tf.cholesky

@@ -65,6 +65,7 @@ int main() {
       long long ps_[64];
       (void)hipMemcpyFromSymbol(ps_, HIP_SYMBOL(hb_pstamps), sizeof(ps_));
       for (int k : {0, 1, 5})
+        printf("  launch k=%d, wave 0: before loads %lld, tile loads issued %lld, B loads issued %lld |", k, ps_[k * 8 + 4] - st[k * 8], ps_[k * 8 + 5] - st[k * 8], ps_[k * 8 + 6] - st[k * 8]),
         printf("  launch k=%d, wave 0 of factor workgroup 0, cycles since kernel entry: loads issued %lld, tile in registers %lld, staged in LDS %lld, past the barrier %lld, update done %lld\n",
                k, ps_[k * 8 + 0] - st[k * 8], ps_[k * 8 + 1] - st[k * 8], ps_[k * 8 + 2] - st[k * 8], ps_[k * 8 + 3] - st[k * 8], st[k * 8 + 1] - st[k * 8]);
       for (int k : {1, 5}) {
