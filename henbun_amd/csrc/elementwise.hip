@@ -728,12 +728,20 @@ static int gather_rows_multi_draw(int narr, const T* const* srcs, const long* ro
   }
   if (n == 0) return 0;
   const uint64_t range = (uint64_t)(hi - lo);
+  // rows of whole 16-byte groups at aligned addresses: a lane moves 16 bytes (group size counted in 16-byte units,
+  // passed NEGATIVE to the body)
+  constexpr long VEC = 16 / (long)sizeof(T);
+  bool vec16 = true;
+  for (int a = 0; a < narr; ++a)
+    vec16 = vec16 && rows[a] % VEC == 0 && ((uintptr_t)srcs[a] % 16) == 0 && ((uintptr_t)dsts[a] % 16) == 0;
+  const long wsel = vec16 ? wmax / VEC : wmax;
+  const int Gsel = wsel <= 2 ? 1 : (wsel <= 8 ? 4 : (wsel <= 32 ? 16 : 64));
   if constexpr (sizeof(T) == 4) {
     if (defer) {   // recorded for the next host launch (side_jobs.cuh)
       HbSideJob j;
       j.kind = HB_SIDE_GATHER_DRAW;
-      j.gather.G = wmax <= 2 ? 1 : (wmax <= 8 ? 4 : (wmax <= 32 ? 16 : 64));
-      j.nblocks = hb_cdiv(n * j.gather.G, 256);
+      j.gather.G = vec16 ? -Gsel : Gsel;
+      j.nblocks = hb_cdiv(n * Gsel, 256);
       if (j.nblocks <= 1024) {
         memcpy(&j.gather.g, &g, sizeof(g));
         j.gather.state = state; j.gather.nlanes = nlanes; j.gather.lo = lo; j.gather.range = range;
@@ -743,13 +751,22 @@ static int gather_rows_multi_draw(int narr, const T* const* srcs, const long* ro
     }
   }
 #define HB_GDRAW(G_)                                                                                                   \
-  hipLaunchKernelGGL((gather_rows_multi_draw_kernel<T, G_>), dim3((unsigned)hb_cdiv(n * G_, 256)), dim3(256), 0, stream, g, \
-                     state, nlanes, lo, range, idx_out, perm, n, nsrc, err)
-  if (wmax <= 2)
+  hipLaunchKernelGGL((gather_rows_multi_draw_kernel<T, G_>), dim3((unsigned)hb_cdiv(n * (G_ < 0 ? -(G_) : (G_)), 256)), dim3(256), 0, \
+                     stream, g, state, nlanes, lo, range, idx_out, perm, n, nsrc, err)
+  if (vec16) {
+    if (Gsel == 1)
+      HB_GDRAW(-1);
+    else if (Gsel == 4)
+      HB_GDRAW(-4);
+    else if (Gsel == 16)
+      HB_GDRAW(-16);
+    else
+      HB_GDRAW(-64);
+  } else if (Gsel == 1)
     HB_GDRAW(1);
-  else if (wmax <= 8)
+  else if (Gsel == 4)
     HB_GDRAW(4);
-  else if (wmax <= 32)
+  else if (Gsel == 16)
     HB_GDRAW(16);
   else
     HB_GDRAW(64);

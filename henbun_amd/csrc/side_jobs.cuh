@@ -30,7 +30,9 @@ struct GatherMultiArgs {
 template <typename T>
 __device__ __forceinline__ void gather_draw_body(const GatherMultiArgs<T>& g, uint64_t* __restrict__ state, long nlanes, long lo,
                                                  uint64_t range, long* __restrict__ idx_out, const long* __restrict__ perm,
-                                                 long n, long nsrc, int* __restrict__ err, int G, long vblock) {
+                                                 long n, long nsrc, int* __restrict__ err, int Gs, long vblock) {
+  const bool vec16 = Gs < 0;
+  const int G = vec16 ? -Gs : Gs;
   const long t = vblock * 256 + threadIdx.x;
   const long r = t / G;
   const int sub = (int)(t % G);
@@ -51,6 +53,22 @@ __device__ __forceinline__ void gather_draw_body(const GatherMultiArgs<T>& g, ui
   if (perm) j = perm[j];
   const bool bad = j < 0 || j >= nsrc;
   if (bad && sub == 0 && err) *err = 1;
+  // G < 0: every array has rows of whole 16-byte groups at 16-byte aligned addresses -- a lane moves 16 bytes per trip
+  // (one float per lane made this launch instruction bound: 13.6 us for 2 x 8.4 MB at cfg 4 against 7.5 us for the plain
+  // gather)
+  if (vec16) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(VEC)));
+    const VT zero = {};
+#pragma unroll
+    for (int a = 0; a < HB_GATHER_MAX; ++a) {
+      if (a >= g.narr) break;
+      const long w = g.row[a] / VEC;
+      for (long c = sub; c < w; c += G)
+        reinterpret_cast<VT*>(g.dst[a])[r * w + c] = bad ? zero : reinterpret_cast<const VT*>(g.src[a])[j * w + c];
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < HB_GATHER_MAX; ++a) {
     if (a >= g.narr) break;
