@@ -435,11 +435,11 @@ def main():
         shapes = "" if node is None else " ".join("x".join(str(d) for d in t.shape) or "scalar" for t in node.inputs[:4])
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
             rec = pmc.get(args.config, {}).get(lab)
             if rec:
-                traffic, traffic_src = rec["traffic_bytes"], "profiles/r02_pmc_traffic.json (%s)" % rec.get("kernel", lab)
+                traffic, traffic_src = rec["traffic_bytes"], "profiles/r03_pmc_traffic.json (%s)" % rec.get("kernel", lab)
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"kernel": "%s [%s]" % (lab, shapes), "bound": bound, "achieved": achieved, "peak": pk, "unit": unit,

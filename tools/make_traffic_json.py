@@ -7,7 +7,8 @@ import json, sys
 GROUPS = {  # plan label -> (once-per-step kernel, kernel-name fragments of the chain)
     "cholesky": ("tril_inplace_kernel", ["chol_", "tril_inplace_kernel"]),
     "sgp": ("sgp_finish_part_kernel", ["sgp_A_", "sgp_finish_part_kernel", "sgp_fwd"]),
-    "sgp_grad": ("sgp_lbar_finish_kernel", ["sgp_kbar", "sgp_strip_finish", "sgp_lbar", "sgp_bwd", "sgp_rowgrad"]),
+    "sgp_grad": ("sgp_bwd_finish_kernel", ["sgp_kbar", "sgp_strip_finish", "sgp_lbar", "sgp_bwd", "sgp_rowgrad"]),
+    "matmul": ("matmul_kernel<float, false, false", ["matmul_kernel", "matmul_splitk_finish", "matmul_wgk"]),
 }
 out = {}
 for spec in sys.argv[1:]:
