@@ -815,6 +815,207 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Column-strip contraction, third form (round 3): transposed accumulators, two workgroups per CU.
+//
+// The second form keeps a 4.6 KB transpose buffer per wave (fragment-major store of a finished tile) and the staged u
+// rows: 113 KB of LDS and 169 registers, i.e. ONE workgroup per CU -- while a workgroup synthesises its K block or
+// retires tiles the matrix pipe of its CU idles, and a stalled wave has one partner on its SIMD.  Measured on the
+// second form with a (racy) shared buffer, two resident workgroups alone are worth 12 % at cfg-5 size (1521 -> 1342 us).
+// Here the tile product is computed transposed (sgp_strip.cuh: the row-per-lane view is eight permlane swaps, no LDS),
+// the column statistics are kept per lane in accumulator order (row li of the tile on the lane: u_m is one register per
+// tile) and folded across lanes and waves ONCE, through the K block's LDS after the last MFMA: 68 KB of LDS and
+// <= 128 registers, so two workgroups (four waves per SIMD) share a CU.  Every A element keeps the bits of the second
+// form; the column sums are taken in another (fixed) order.  Handles P <= 1 column means (the registers of more would
+// not fit): the launcher keeps the second form for the rest.
+// ---------------------------------------------------------------------------------------------------------------
+#define SGP_RED_LD 260   // floats per (quantity, column) in the end-of-kernel fold: 8 waves x 32 lanes + 4 (bank skew)
+template <int D>
+__global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(SgpArgs<float> a) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef Mma<float> MM;
+  constexpr int KS_FLOATS = SGP_SN * SGP_SLD, RED_FLOATS = 2 * SGP_SN * SGP_RED_LD;
+  __shared__ __attribute__((aligned(16))) float lds_raw[KS_FLOATS > RED_FLOATS ? KS_FLOATS : RED_FLOATS];
+  __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
+  float (*Ks)[SGP_SLD] = reinterpret_cast<float (*)[SGP_SLD]>(lds_raw);
+  long e;
+  int bx;
+  sgp_block(a.efast, e, bx);
+  const float* __restrict__ x = a.x + e * a.sx;
+  const float* __restrict__ z = a.z + e * a.M * D;
+  const float* __restrict__ ell = a.ell + e * a.dl;
+  const float* __restrict__ Wf = a.Wf + e * a.M * a.M;
+  float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
+  const int M = (int)a.M, n = (int)a.n;
+  const int col0 = bx * SGP_SN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int nT = M / 32;
+  const int t1 = nT - 1 - w, t0 = w;
+  const int d0 = w < t1 ? w + 1 : 0;      // the middle tile of an odd count is taken once, as t1
+  const int d1 = w <= t1 ? t1 + 1 : 0;
+  const int nts = d0 + d1;
+  const bool means = a.part && a.P > 0;
+  // this lane's u_m for its two tiles (row li of each), requested before anything else
+  float u0 = 0.f, u1 = 0.f;
+  if (means) {
+    const float* up = a.u + e * a.P * a.M;
+    if (d0) u0 = up[32 * t0 + li];
+    if (d1) u1 = up[32 * t1 + li];
+  }
+
+  // ---- K(z, x[strip]) -> LDS (as in the other forms: difference first, then the exp2 scale)
+  {
+    const int c = tid & 31, kq = tid >> 5;
+    const int cc = col0 + c < n ? col0 + c : n - 1;
+    float sc[D], xs[D];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
+      xs[dd] = x[cc * D + dd];
+    }
+    constexpr int NTH = SGP_STRIP_THREADS;
+    constexpr int ZIT = (SGP_SM_MAX * D) / NTH;
+    float zt[ZIT];
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + NTH * it;
+      zt[it] = z[i < M * D ? i : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + NTH * it;
+      if (i < M * D) zs[i] = zt[it];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k4 = kq * 4; k4 < M; k4 += NTH / 8) {
+      float zq[4 * D];
+#pragma unroll
+      for (int q = 0; q < 4 * D; q += 4) {
+        const V4 zz = *reinterpret_cast<const V4*>(&zs[k4 * D + q]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) zq[q + s] = zz[s];
+      }
+      V4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float r2 = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          const float tt = (zq[q * D + dd] - xs[dd]) * sc[dd];
+          r2 += tt * tt;
+        }
+        v[q] = hb_exp2_neg<float>(r2);
+      }
+      *reinterpret_cast<V4*>(&Ks[c][k4]) = v;
+    }
+  }
+  __syncthreads();
+
+  // per-lane column statistics in ACCUMULATOR order: register r of lane (li, h) is column (r & 3) + 8 (r >> 2) + 4 h
+  float csq[16], cu[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) csq[r] = 0.f, cu[r] = 0.f;
+  typename MM::Acc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nS = (n + SGP_SN - 1) / SGP_SN;
+
+  auto load = [&](V4 (&f)[4], int ts) {
+    const int tc = ts < nts ? ts : nts - 1;            // past the end: re-read the last step (never used)
+    const int tile = tc < d0 ? t0 : t1, Q = tc < d0 ? tc : tc - d0;
+    const float* p = Wf + ((long)(tile * nT + Q) << 10) + 4 * lane;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) f[v] = *reinterpret_cast<const V4*>(p + 256 * v);
+  };
+  auto compute = [&](const V4 (&f)[4], int ts) {
+    if (ts >= nts) return;                               // (uniform) the odd tail of the two-step loop
+    const int tile = ts < d0 ? t0 : t1, Q = ts < d0 ? ts : ts - d0;
+    V4 bv[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bv[v] = *reinterpret_cast<const V4*>(&Ks[li][32 * Q + 16 * h + 4 * v]);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = MM::mma(bv[v][s], f[v][s], acc);   // transposed tile: rows on the lanes
+    if (ts == d0 - 1 || ts == nts - 1) {
+      // the tile is complete: statistics from the registers as they stand, then the row-per-lane view
+      if (a.part) {
+        const float um = ts < d0 ? u0 : u1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          csq[r] += acc[r] * acc[r];
+          cu[r] += um * acc[r];
+        }
+      }
+      sgp_acc_t_settle(acc);
+      float row16[16];
+      sgp_acc_t_rows(acc, row16);
+      if (a.Af) sgp_store_frag_rows(a.Af, row16, e, nT, nS, tile, bx, col0, n, lane);
+      if (A) {
+        float* ap = A + (long)(32 * tile + li) * n + col0 + 16 * h;
+        if ((n & 3) == 0 && col0 + SGP_SN <= n) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            V4 q;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) q[s2] = row16[4 * v + s2];
+            *reinterpret_cast<V4*>(ap + 4 * v) = q;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (col0 + 16 * h + i < n) ap[i] = row16[i];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+  };
+  if (nts > 0) {
+    V4 fa[4], fb[4];
+    load(fa, 0);
+#pragma nounroll
+    for (int ts = 0; ts < nts; ts += 2) {
+      load(fb, ts + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fa, ts);
+      __builtin_amdgcn_sched_barrier(0);
+      load(fa, ts + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fb, ts + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: fold the per-lane statistics over the 256 (wave, row-lane) contributions of every column
+  if (a.part) {
+    __syncthreads();  // every wave is done reading the K block
+    float* red = lds_raw;   // [2 quantities][32 columns][SGP_RED_LD]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
+      red[(0 * SGP_SN + c) * SGP_RED_LD + 32 * w + li] = csq[r];
+      if (means) red[(1 * SGP_SN + c) * SGP_RED_LD + 32 * w + li] = cu[r];
+    }
+    __syncthreads();
+    // 8 threads per (quantity, column): 32 contributions each in a fixed order, then a fixed 3-level tree
+    const int pair = tid >> 3, g = tid & 7;           // pair = quantity * 32 + column
+    const float* rp = red + pair * SGP_RED_LD + 32 * g;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const V4 q = *reinterpret_cast<const V4*>(rp + 4 * i);
+      sum += (q[0] + q[1]) + (q[2] + q[3]);
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    const int q = pair >> 5, c = pair & 31;
+    if (g == 0 && col0 + c < n && (q == 0 || means)) a.part[e * 5 * a.n + (long)q * n + col0 + c] = sum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Column-strip contraction with bf16x3 operands ("fp16-in / fp32-accumulate" variant of BASELINE cfg 5, made usable).
 // Plain 16-bit operands are NOT usable for the whitened solve: entries of W = L^-1 reach +-30 and cancel, a single
 // bf16 rounding of W and K leaves a 27 % error in A = W K (profiles/r01_bf16_split_study.txt).  Each fp32 operand
@@ -1044,10 +1245,15 @@ extern "C" int hb_sgp_strip_path(long E, long n, long M, long d, long P, int pre
 
 static int sgp_A_strip_launch(SgpArgs<float> a, long E, hipStream_t stream) {
   dim3 grid = sgp_grid(hb_cdiv(a.n, SGP_SN), 1, E, a.efast);
+  // third form (transposed accumulators, two workgroups per CU) whenever its one column mean suffices;
+  // HB_SGP_STRIP_FORM2=1 keeps the second form (diagnostic: A/B timing, the two forms agree bit for bit in A)
+  const bool form3 = (!a.part || a.P <= 1) && !getenv("HB_SGP_STRIP_FORM2");
 #define HB_STRIP(D_)                                                                                          \
   do {                                                                                                        \
     if (a.W3)                                                                                                 \
       hipLaunchKernelGGL((sgp_A_strip3_kernel<D_>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);             \
+    else if (a.Wf && form3)                                                                                   \
+      hipLaunchKernelGGL((sgp_A_strip2t_kernel<D_>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);            \
     else if (a.Wf)                                                                                            \
       hipLaunchKernelGGL((sgp_A_strip2_kernel<D_>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);             \
     else                                                                                                      \
@@ -1528,13 +1734,13 @@ __device__ __forceinline__ float hb_half_wave_sum_dpp(float v) {
 // full read of Kbar and A (33.5 MB) disappears; the strips' partial sums are folded by sgp_strip_finish_kernel.
 // ---------------------------------------------------------------------------------------------------------------
 template <int D, bool BF3>
-__global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBwdArgs<float> a) {
+__global__ void __launch_bounds__(SGP_STRIP_THREADS, (BF3 || D >= 3) ? 2 : 4) sgp_kbar_strip_kernel(SgpBwdArgs<float> a) {
   typedef float V4 __attribute__((ext_vector_type(4)));
   typedef __bf16 B8 __attribute__((ext_vector_type(8)));
   typedef Mma<float> MM;
   constexpr int KS_BYTES = BF3 ? 3 * SGP_SN * SGP_S3LD * 2 : SGP_SN * SGP_SLD * 4;
   __shared__ __attribute__((aligned(16))) unsigned char ks_raw[KS_BYTES];
-  __shared__ __attribute__((aligned(16))) float Tw[SGP_STRIP_THREADS / 64][32][SGP_TLD];
+  __shared__ float lred[(SGP_STRIP_THREADS / 64) * D];
   __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
   __shared__ __attribute__((aligned(16))) float xss[SGP_SN * D];
   __shared__ float us[4][SGP_SM_MAX];
@@ -1751,28 +1957,34 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
 #pragma unroll
   for (int dd = 0; dd < D; ++dd) lwave[dd] = 0.f;
 
-  // fold a finished tile (in `acc`, column-per-lane) into the outputs
+  // fold a finished tile into the outputs.  The tile product is computed TRANSPOSED (sgp_strip.cuh): `acc` holds row
+  // li of the tile on the lane, so the row-per-lane view -- lane (li, h): row li, columns 16h .. 16h+15 -- is eight
+  // permlane swaps away (the first form went through a per-wave LDS transpose: 16 stores + 4 loads per tile and 36.8 KB
+  // of LDS that kept a second workgroup off the CU)
   auto retire = [&](int tile) {
-    // Kbar, row-major (accumulator layout: two 128-byte row segments per store)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * tile + MM::acc_row(lane, r);
-      if (a.Kbar && gc < n) Kbar[(long)row * n + gc] = acc[r];
-      Tw[w][MM::acc_row(lane, r)][li] = acc[r];
-    }
-    // row-per-lane view: lane (li, h) takes row li, columns 16h .. 16h+15 of the tile
+    sgp_acc_t_settle(acc);
     float kb[16];
-    float* kfblk = (a.Kf && !BF3) ? a.Kf + ((((long)e * nT + tile) * nS + bx) << 10) + 4 * lane : nullptr;
+    sgp_acc_t_rows(acc, kb);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      V4 q = *reinterpret_cast<const V4*>(&Tw[w][li][16 * h + 4 * v]);
+    for (int i = 0; i < 16; ++i)
+      if (col0 + 16 * h + i >= n) kb[i] = 0.f;
+    if (a.Kbar) {   // row-major Kbar (not requested by the fragment-major pipeline): 64 contiguous bytes per lane
+      float* kp = Kbar + (long)(32 * tile + li) * n + col0 + 16 * h;
+      if ((n & 3) == 0 && col0 + SGP_SN <= n) {
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        if (col0 + 16 * h + 4 * v + s2 >= n) q[s2] = 0.f;
-        kb[4 * v + s2] = q[s2];
+        for (int v = 0; v < 4; ++v) {
+          V4 q;
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) q[s2] = kb[4 * v + s2];
+          *reinterpret_cast<V4*>(kp + 4 * v) = q;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (col0 + 16 * h + i < n) kp[i] = kb[i];
       }
-      if (kfblk) *reinterpret_cast<V4*>(kfblk + 256 * v) = q;   // fragment-major Kbar: one contiguous KB per store
     }
+    if (a.Kf && !BF3) sgp_store_frag_rows(a.Kf, kb, e, nT, nS, tile, bx, col0, n, lane);   // one contiguous KB per store
     if (BF3 && a.Kf)   // ... as three bf16 planes for the bf16x3 Lbar contraction
       sgp_store_frag3_row(reinterpret_cast<__bf16*>(a.Kf), (long)a.plane3 / a.M * 32 * nS, kb, e, nT, nS, tile, bx, lane);
     const int row = 32 * tile + li;
@@ -1823,7 +2035,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
 #pragma unroll
       for (int v = 0; v < 4; ++v)
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) acc = MM::mma(f[v][s2], bv[v][s2], acc);
+        for (int s2 = 0; s2 < 4; ++s2) acc = MM::mma(bv[v][s2], f[v][s2], acc);   // transposed tile
       if (ts == d0 - 1 || ts == nts - 1) retire(tile_of(ts));
     };
     if (nts > 0) {
@@ -1862,12 +2074,13 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
         B8 b[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const B8*>(&K3[t][li][32 * Q + 16 * q + 8 * h]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[2][q], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[1][q], b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[1][q], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.f[0][q], b[0], acc, 0, 0, 0);
+        // (operands swapped against the forward: the tile comes out transposed, see retire)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], fr.f[2][q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2], fr.f[0][q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], fr.f[1][q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], fr.f[1][q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], fr.f[0][q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], fr.f[0][q], acc, 0, 0, 0);
       }
       if (ts == d0 - 1 || ts == nts - 1) retire(tile_of(ts));
     };
@@ -1889,7 +2102,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_kbar_strip_kernel(SgpBw
   }
   // ---- the strip's lengthscale partial: sum over all rows (lanes, waves) in a fixed order
   __syncthreads();
-  float* red = &Tw[0][0][0];
+  float* red = lred;
 #pragma unroll
   for (int dd = 0; dd < D; ++dd) {
     const float t = wave_sum(lwave[dd]);

@@ -43,4 +43,55 @@ __device__ __forceinline__ void sgp_store_frag_tile(float* __restrict__ Xf, floa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Transposed accumulators (round 3).  With the operands of the tile product swapped -- mma(K fragment, W fragment)
+// instead of mma(W fragment, K fragment): the same products summed in the same order, so every element keeps its
+// bits -- the 32 x 32 accumulator holds the tile TRANSPOSED: lane (li, h) owns tile ROW li and its 16 registers are
+// the columns (r & 3) + 8 (r >> 2) + 4 h.  The row-per-lane view the fragment-major image and the row gradients want
+// (lane (li, h): columns 16h .. 16h + 15) is then eight v_permlane32_swap with the half-wave partner -- no LDS
+// transpose, no per-wave tile buffer (36.8 KB of LDS per workgroup in the first form, which also kept a second
+// workgroup off the CU).
+//
+// sgp_acc_t_settle: the accumulator was written by MFMAs and is about to be read by inline asm, which the
+// compiler's hazard recogniser does not look into: 19 wait states cover a 16-pass MFMA result (the count the compiler
+// itself inserts in front of a VALU read).  The accumulator is an operand so that the MFMAs stay in front of it.
+__device__ __forceinline__ void sgp_acc_t_settle(Mma<float>::Acc& acc) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));
+}
+// After the call row16[4 v + s] = X[row li][16 h + 4 v + s] (acc is consumed).
+__device__ __forceinline__ void sgp_acc_t_rows(Mma<float>::Acc& acc, float (&row16)[16]) {
+  float lo[8], hi[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    lo[r] = acc[r], hi[r] = acc[8 + r];
+    // lo's upper half-wave <-> hi's lower half-wave
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo[r]), "+v"(hi[r]));
+  }
+  // lane (li, h): lo[0..3] -> columns 16h + 0..3, hi[0..3] -> 16h + 4..7, lo[4..7] -> 16h + 8..11, hi[4..7] -> 16h + 12..15
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    row16[s] = lo[s];
+    row16[4 + s] = hi[s];
+    row16[8 + s] = lo[4 + s];
+    row16[12 + s] = hi[4 + s];
+  }
+}
+// fragment-major store of a row-per-lane tile (see sgp_store_frag_tile for the layout); columns past n as zeros
+__device__ __forceinline__ void sgp_store_frag_rows(float* __restrict__ Xf, float (&row16)[16], long e, int nT, int nS,
+                                                    int tile, int strip, int col0, int n, int lane) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  const int h = lane >> 5;
+  float* blk = Xf + ((((long)e * nT + tile) * nS + strip) << 10) + 4 * lane;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    V4 q;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      if (col0 + 16 * h + 4 * v + s2 >= n) row16[4 * v + s2] = 0.f;
+      q[s2] = row16[4 * v + s2];
+    }
+    *reinterpret_cast<V4*>(blk + 256 * v) = q;
+  }
+}
+
 #endif  // HB_SGP_STRIP_CUH

@@ -4,6 +4,7 @@ fp64 runs must match the oracle to ~1e-10 (north star: 1e-5 relative on fp64
 inputs); fp32 runs are checked at fp32-appropriate tolerances.  Gradient
 kernels are checked against torch autograd of the oracle's forward.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -677,8 +678,19 @@ def test_fragment_major_copies_of_the_inverse(H):
             Wd = W
         a = H.sgp_fwd(x, zz, ell, Wd, u, eps_in=eps)
         b_ = H.sgp_fwd(x, zz, ell, Wd, u, eps_in=eps, wfrag=frag)
-        for p_, q_ in zip(a, b_):
-            assert torch.equal(p_, q_)
+        # A = W K keeps its bits (same products, same order, whichever operand sits on the lanes); the column sums
+        # behind f and v are folded in another fixed order by the transposed-accumulator strip form (observed 2.4e-7 / 6e-7)
+        assert torch.equal(a[1], b_[1]) and (a[3] is None or torch.equal(a[3], b_[3]))
+        # (v = 1 - sum A^2 is ~1e-3 here, so f = mean + sqrt|v| eps magnifies a rounding of v ~16 times)
+        assert float((a[2] - b_[2]).abs().max()) <= 4e-6, float((a[2] - b_[2]).abs().max())     # observed 1.2e-6
+        assert float((a[0] - b_[0]).abs().max()) <= 6e-5, float((a[0] - b_[0]).abs().max())     # observed 9.0e-6
+        os.environ["HB_SGP_STRIP_FORM2"] = "1"   # the second strip form (kept for P > 1) sums like the row-major one
+        try:
+            b2 = H.sgp_fwd(x, zz, ell, Wd, u, eps_in=eps, wfrag=frag)
+        finally:
+            del os.environ["HB_SGP_STRIP_FORM2"]
+        for p_, q_ in zip(a, b2):
+            assert p_ is None or torch.equal(p_, q_)
         assert torch.equal(H.sgp_A(x, zz, ell, Wd), H.sgp_A(x, zz, ell, Wd, wfrag=frag))
 
 
