@@ -18,8 +18,11 @@ def t(fn, iters=50):
 
 
 switches = [a.split("=", 1) for a in sys.argv[1:] if "=" in a]
+only = [a for a in sys.argv[1:] if "=" not in a]   # e.g. `cfg5`: that size only
 rng = np.random.RandomState(0)
 for name, E, M, n in (("cfg2", 1, 512, 8192), ("cfg5", 8, 512, 65536)):
+    if only and name not in only:
+        continue
     z = np.broadcast_to(np.linspace(0, M / 2.0, M)[None, :, None], (E, M, 1)).copy()
     ell = torch.ones(E, 1, device="cuda")
     zz = torch.as_tensor(z, dtype=torch.float32).cuda()
