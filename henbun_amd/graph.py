@@ -20,6 +20,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from ._lib import HipBackendError as _HipBackendError
+
 _uid = itertools.count()
 
 # ------------------------------------------------------------------------------
@@ -813,8 +815,10 @@ def _concat_emit(plan, node):
         shp = list(t.shape)
         istr = _contig_strides(shp)
         o = off * ostr[axis]
-        plan.steps.append(lambda src=src, istr=istr, shp=shp, o=o: H.copy_nd(src, istr, out, ostr, shp, dst_off=o))
         off += t.shape[axis]
+        if src.data_ptr() == out.data_ptr() + o * out.element_size() and all(d == 1 for d in node.outputs[0].shape[:axis]):
+            continue   # written in place by its producer (Plan._place)
+        plan.steps.append(lambda src=src, istr=istr, shp=shp, o=o: H.copy_nd(src, istr, out, ostr, shp, dst_off=o))
 
 
 def _concat_vjp(node, gs):
@@ -1537,30 +1541,39 @@ def topo_order(outputs: Sequence[Tensor]) -> List[Node]:
 
 
 def _scatter_partition(ts):
-    """The gradients of last-axis slices that tile their source exactly (an encoder output split into mean and
-    log-std halves, reference variationals.py:70-80): their sum is the concatenation, not N zero-filled buffers added up."""
+    """The gradients of slices along ONE axis that tile their source exactly -- an encoder output split into mean and
+    log-std halves (last axis; reference variationals.py:70-80), the experts / gates halves of a batched GP draw
+    (leading axis; notebooks/Expert_GPR.ipynb:139-147): their sum is the concatenation, not N zero-filled buffers added up."""
     if len(ts) < 2 or any(t.node.op != "scatter_strided" for t in ts):
         return None
     xshape = tuple(ts[0].node.attrs["xshape"])
     if len(xshape) < 1:
         return None
     cst = tuple(_contig_strides(xshape))
-    parts = []
+    parts, axis = [], None
     for t in ts:
         a = t.node.attrs
-        if (tuple(a["xshape"]) != xshape or len(a["shape"]) != len(xshape) or tuple(a["shape"][:-1]) != xshape[:-1]
-                or tuple(a["strides"]) != cst or not 0 <= a["offset"] < xshape[-1]):
+        if tuple(a["xshape"]) != xshape or len(a["shape"]) != len(xshape) or tuple(a["strides"]) != cst:
             return None
-        parts.append((a["offset"], a["shape"][-1], t.node.inputs[0]))
+        diff = [i for i in range(len(xshape)) if a["shape"][i] != xshape[i]]
+        if len(diff) != 1 or (axis is not None and diff[0] != axis):
+            return None
+        axis = diff[0]
+        if a["offset"] % cst[axis] != 0:
+            return None
+        start = a["offset"] // cst[axis]
+        if not 0 <= start or start + a["shape"][axis] > xshape[axis]:
+            return None
+        parts.append((start, a["shape"][axis], t.node.inputs[0]))
     parts.sort(key=lambda p: p[0])
     pos = 0
     for off, w, _ in parts:
         if off != pos:
             return None
         pos += w
-    if pos != xshape[-1]:
+    if pos != xshape[axis]:
         return None
-    return concat([p[2] for p in parts], len(xshape) - 1)
+    return concat([p[2] for p in parts], axis)
 
 
 def add_n(ts: List[Tensor]) -> Tensor:
@@ -1678,7 +1691,7 @@ class _Cluster:
         self.nodes, self.space, self.sealed, self.ninstr, self.reduced = [], (), False, 0, set()
 
 
-def cluster_elementwise(order, enabled=True, max_elems=EW_CLUSTER_MAX_ELEMS):
+def cluster_elementwise(order, enabled=True, max_elems=EW_CLUSTER_MAX_ELEMS, skip=()):
     """Greedy clustering over a topological order.  A node joins the cluster of one of its
     elementwise producers (or, failing that, any open cluster with a compatible iteration
     space); a cluster is sealed as soon as a non-member consumes one of its values, so the
@@ -1689,7 +1702,7 @@ def cluster_elementwise(order, enabled=True, max_elems=EW_CLUSTER_MAX_ELEMS):
     open_clusters = []
     for n in order:
         joined = None
-        if _fusable(n) and len(_squeeze_shape(n.outputs[0].shape)) <= 4 and n.outputs[0].size <= max_elems:
+        if n.id not in skip and _fusable(n) and len(_squeeze_shape(n.outputs[0].shape)) <= 4 and n.outputs[0].size <= max_elems:
             cands = []
             for t in n.inputs:
                 c = member.get(t.node.id)
@@ -1718,7 +1731,7 @@ def cluster_elementwise(order, enabled=True, max_elems=EW_CLUSTER_MAX_ELEMS):
             joined.nodes.append(n)
             joined.ninstr += 1
             member[n.id] = joined
-        elif _full_sum(n):
+        elif n.id not in skip and _full_sum(n):
             # reduce_sum of a cluster value over the cluster's whole space: becomes a sum-reduced program output
             t = n.inputs[0]
             c = member.get(t.node.id)
@@ -1734,6 +1747,166 @@ def cluster_elementwise(order, enabled=True, max_elems=EW_CLUSTER_MAX_ELEMS):
             c = member.get(t.node.id)
             if c is not None and c is not joined:
                 c.sealed = True
+    return member
+
+
+# ------------------------------------------------------------------------------
+# column clusters: fused programs over a short-and-wide space [R, n] with reductions over the ROW axis inside
+# (hb_ewise_colprog_build: one thread per column, row loops unrolled in the thread).  The softmax gate of the expert
+# mixture (notebooks/Expert_GPR.ipynb:139-147) and its VJP are chains of elementwise ops on [E, n] arrays broken up by
+# tf.reduce_max / tf.reduce_sum over axis 0 and by row-block slices of the batched GP draw: op by op that is ~20 launches
+# of 4-60 us on [4, 65536] arrays at cfg 5; as column programs it is one launch forward and one backward.
+# ------------------------------------------------------------------------------
+EW_COL_MAX_ROWS = 8
+EW_COL_MIN_COLS = 512
+EW_COL_MAX_NODES = 44
+EW_COL_MAX_IN = 12
+EW_COL_MAX_OUT = 12
+
+
+def _colform(shape, R, n):
+    """How a tensor of `shape` sits in the column space [R, n]: 'full' ([R, n] up to unit dims), 'row' ([1, n]),
+    'scalar' (one element), or None."""
+    sq = tuple(int(d) for d in shape if d != 1)
+    if sq == (R, n):
+        return "full"
+    if sq == (n,):
+        return "row"
+    if sq == ():
+        return "scalar"
+    return None
+
+
+def _col_space_of(shape):
+    sq = tuple(int(d) for d in shape if d != 1)
+    if len(sq) == 2 and 2 <= sq[0] <= EW_COL_MAX_ROWS and sq[1] >= EW_COL_MIN_COLS:
+        return sq
+    return None
+
+
+def _col_strided_view(node, R, n):
+    """(form, element offset, row stride) when a strided node reads a row block [R, n] (or one row) of its source."""
+    a = node.attrs
+    nz = [(int(d), int(st)) for d, st in zip(a["shape"], a["strides"]) if d != 1]
+    if len(nz) == 2 and nz[0][0] == R and nz[1] == (n, 1) and nz[0][1] >= n:
+        return ("full", int(a["offset"]), nz[0][1])
+    if len(nz) == 1 and nz[0] == (n, 1):
+        return ("row", int(a["offset"]), 0)
+    return None
+
+
+class _ColCluster:
+    __slots__ = ("nodes", "R", "n", "sealed", "absorbed")
+
+    def __init__(self, R, n):
+        self.nodes, self.R, self.n, self.sealed, self.absorbed = [], R, n, False, {}
+
+
+def cluster_columns(order, outputs=(), enabled=True):
+    """Greedy clustering over a topological order, like cluster_elementwise, of the nodes a column program can hold:
+    elementwise ops whose operands are [R, n], [1, n] or single elements, reductions over the row axis, reshapes /
+    broadcasts between those forms, and row-block slices of a taller source (read in place).  Only clusters that contain
+    a row reduction or a slice are kept -- the rest is plain elementwise work for cluster_elementwise.
+    Returns {node id: cluster}."""
+    member = {}
+    if not enabled:
+        return member
+    consumers = {}
+    for nd in order:
+        for t in nd.inputs:
+            consumers.setdefault(t, []).append(nd)
+    outputs = set(outputs)
+    open_clusters = []
+
+    def can_join(nd, c):
+        R, n = c.R, c.n
+        if len(c.nodes) >= EW_COL_MAX_NODES:
+            return False
+        fo = _colform(nd.outputs[0].shape, R, n)
+        if nd.op == "ew":
+            if nd.attrs["f"] == "GAUSS_LOGPDF_GRAD" or len(nd.outputs) != 1 or len(nd.inputs) > 3 or fo is None:
+                return False
+            forms = [_colform(t.shape, R, n) for t in nd.inputs]
+            if any(f is None for f in forms):
+                return False
+            # the broadcast of the operand forms must be the output's form
+            best = "full" if "full" in forms else ("row" if "row" in forms else "scalar")
+            return best == fo
+        if nd.op == "reduce":
+            a = nd.attrs
+            return (a["kind"] in ("sum", "max") and a["K1"] == 1 and a["R"] == R and a["K2"] == n
+                    and _colform(nd.inputs[0].shape, R, n) == "full")
+        if nd.op == "reshape":
+            return member.get(nd.inputs[0].node.id) is c and fo is not None and fo == _colform(nd.inputs[0].shape, R, n)
+        if nd.op == "bcast":
+            return member.get(nd.inputs[0].node.id) is c and fo == "full" and _colform(nd.inputs[0].shape, R, n) in ("row", "scalar")
+        if nd.op == "strided":
+            return member.get(nd.inputs[0].node.id) is not c and _col_strided_view(nd, R, n) is not None
+        return False
+
+    def seed_space(nd):
+        if nd.op == "ew" and nd.attrs["f"] != "GAUSS_LOGPDF_GRAD" and len(nd.outputs) == 1:
+            return _col_space_of(nd.outputs[0].shape)
+        if nd.op == "strided":
+            sp = _col_space_of(nd.outputs[0].shape)
+            return sp if sp and _col_strided_view(nd, sp[0], sp[1]) is not None else None
+        if nd.op == "reduce" and nd.attrs["K1"] == 1 and nd.attrs["kind"] in ("sum", "max"):
+            sp = _col_space_of(nd.inputs[0].shape)
+            return sp if sp and sp == (nd.attrs["R"], nd.attrs["K2"]) else None
+        return None
+
+    for nd in order:
+        joined = None
+        if nd.op in ("ew", "reduce", "reshape", "bcast", "strided"):
+            cands = []
+            for t in nd.inputs:
+                c = member.get(t.node.id)
+                if c is not None and not c.sealed and c not in cands:
+                    cands.append(c)
+            cands += [c for c in reversed(open_clusters) if not c.sealed and c not in cands]
+            for c in cands:
+                if can_join(nd, c):
+                    joined = c
+                    break
+            if joined is None:
+                sp = seed_space(nd)
+                if sp is not None:
+                    joined = _ColCluster(sp[0], sp[1])
+                    open_clusters.append(joined)
+                    if not can_join(nd, joined):
+                        open_clusters.pop()
+                        joined = None
+            if joined is not None:
+                joined.nodes.append(nd)
+                member[nd.id] = joined
+        for t in nd.inputs:
+            c = member.get(t.node.id)
+            if c is not None and c is not joined:
+                c.sealed = True
+    # post-pass: slices whose value somebody outside needs are ordinary copies again; clusters without a row reduction
+    # or an in-place slice, or with too many operands, dissolve
+    for c in open_clusters:
+        changed = True
+        while changed:
+            changed = False
+            for nd in list(c.nodes):
+                if nd.op != "strided":
+                    continue
+                o = nd.outputs[0]
+                if o in outputs or any(member.get(x.id) is not c for x in consumers.get(o, [])) or not consumers.get(o):
+                    c.nodes.remove(nd)
+                    del member[nd.id]
+                    changed = True
+        ids = {nd.id for nd in c.nodes}
+        ext_in = {t for nd in c.nodes for t in nd.inputs if t.node.id not in ids}
+        outs = [o for nd in c.nodes for o in nd.outputs if nd.op != "strided"
+                and (o in outputs or any(x.id not in ids for x in consumers.get(o, [])))]
+        keep = (any(nd.op in ("reduce", "strided") for nd in c.nodes) and sum(1 for nd in c.nodes if nd.op in ("ew", "reduce")) >= 2
+                and len(ext_in) <= EW_COL_MAX_IN and 1 <= len(outs) <= EW_COL_MAX_OUT)
+        if not keep:
+            for nd in c.nodes:
+                del member[nd.id]
+            c.nodes = []
     return member
 
 
@@ -1806,13 +1979,37 @@ class Plan:
         from ._settings import settings as _st
 
         fuse = bool(getattr(_st.runtime, "fuse_elementwise", True))
-        self._clusters = cluster_elementwise(order, enabled=fuse,
+        # column programs first (short-and-wide spaces with row reductions inside: they need the compiled form), then
+        # the plain elementwise clusters over what is left
+        self._colclusters = cluster_columns(order, outputs=self.outputs,
+                                            enabled=fuse and hip_ops.ewise_jit_enabled() and bool(getattr(_st.runtime, "column_programs", True)))
+        self._clusters = cluster_elementwise(order, enabled=fuse, skip=self._colclusters,
                                              max_elems=EW_CLUSTER_MAX_ELEMS_JIT if hip_ops.ewise_jit_enabled() else EW_CLUSTER_MAX_ELEMS)
         consumers = {}
         for n in order:
             for t in n.inputs:
                 consumers.setdefault(t, []).append(n)
         self._consumers = consumers
+        # Concatenation in place: the parts of a concat along its leading non-unit axis are contiguous blocks of the
+        # result, so a part that a fused program (or a single elementwise launch) produces is WRITTEN there -- the
+        # gradient of a batched GP draw whose expert / gate halves come out of one column program needs no
+        # scatter + add (three launches over [2E, n] arrays at cfg 5).  _concat_emit copies whatever did not land in place.
+        self._place: Dict[Tensor, object] = {}
+        for n in order:
+            if n.op != "concat":
+                continue
+            o, ax = n.outputs[0], n.attrs["axis"]
+            if any(d != 1 for d in o.shape[:ax]):
+                continue
+            dst, off = None, 0
+            for t in n.inputs:
+                tgt = self._place_target(t)
+                if (tgt is not None and tgt not in self._bind and tgt not in self._place and tgt not in self.outputs
+                        and len(consumers.get(tgt, [])) == 1):
+                    if dst is None:
+                        dst = self.out(o).reshape(-1)
+                    self._place[tgt] = dst[off:off + t.size].view(tgt.shape)
+                off += t.size
         # Weight gradient + bias gradient of a MatBias layer from one pass over the incoming gradient G: a 2-D product
         # X^T G whose right operand is also column-summed (reduce over axis 0) becomes hb_matmul_colsum -- the GEMM folds
         # the columns of G while it streams them, and the stand-alone reduction launches (two per layer) disappear.
@@ -1850,6 +2047,11 @@ class Plan:
         for n in order:
             if n.id in hoisted:
                 continue
+            cc = self._colclusters.get(n.id)
+            if cc is not None:
+                if n is cc.nodes[-1] and self._emit_colcluster(cc):
+                    self._emitted.extend(cc.nodes)
+                continue
             c = self._clusters.get(n.id)
             if c is None or len(c.nodes) < 2:
                 self._emit(n)
@@ -1875,6 +2077,18 @@ class Plan:
         else:
             self._bind[t] = b
 
+    def _place_target(self, t):
+        """The tensor whose buffer a concat part really is: looks through reshapes (views) down to a value that a fused
+        program or a single elementwise launch writes through Plan.out; None when the producer keeps its own buffer."""
+        n = t.node
+        if n.id in self._colclusters:
+            return t if n.op != "strided" else None
+        if n.op == "reshape":
+            return self._place_target(n.inputs[0])
+        if n.op == "ew":
+            return t
+        return None
+
     def needed(self, t):
         return t in self._needed
 
@@ -1887,7 +2101,9 @@ class Plan:
     def out(self, t):
         b = self._buf.get(t)
         if b is None:
-            if t in self._bind and t.node.op not in ("reshape", "stop_gradient") and not t.node.op.startswith("leaf:"):
+            if t in self._place:
+                b = self._place[t]     # a part of a concatenation, written in place
+            elif t in self._bind and t.node.op not in ("reshape", "stop_gradient") and not t.node.op.startswith("leaf:"):
                 b = self._bind[t]
             else:
                 b = self.torch.empty(t.shape, dtype=self.dtype, device=self.device)
@@ -2085,6 +2301,92 @@ class Plan:
         self.step_labels[id(step)] = "ew_cluster[%d]" % len(c.nodes)
         if prog.image is None:
             self.chain_kind[id(step)] = "full"   # compiled programs record themselves into a serial chain
+
+    def _emit_colcluster(self, c):
+        """One hb_ewise_colprog launch for a column cluster (falls back to one launch per node when the program
+        cannot be built)."""
+        H = self.H
+        R, n = c.R, c.n
+        ids = {m.id for m in c.nodes}
+        steps_before = len(self.steps)
+        try:
+            inputs, in_reg = [], {}
+
+            def ext_operand(t):
+                r = in_reg.get(t)
+                if r is not None:
+                    return r
+                if t.node.id in ids:          # an absorbed row-block slice: its source is read in place
+                    form, off, rs = _col_strided_view(t.node, R, n)
+                    src_t = t.node.inputs[0]
+                    src = self.buf(src_t)
+                    if src.numel() != src_t.size or not src.is_contiguous():
+                        raise ValueError("slice of a lazily broadcast operand")
+                    entry = (src, off, rs if form == "full" else 0, 1)
+                else:
+                    b = self.buf(t)
+                    form = _colform(tuple(b.shape), R, n)    # (buffer shape: a lazy broadcast aliases the small operand)
+                    if form is None or not b.is_contiguous():
+                        raise ValueError("operand %s does not fit the column space" % (tuple(b.shape),))
+                    entry = (b, 0, n, 1) if form == "full" else ((b, 0, 0, 1) if form == "row" else (b, 0, 0, 0))
+                in_reg[t] = len(inputs)
+                inputs.append(entry)
+                return in_reg[t]
+
+            for m in c.nodes:
+                if m.op == "strided":
+                    ext_operand(m.outputs[0])
+                else:
+                    for t in m.inputs:
+                        if t.node.id not in ids:
+                            ext_operand(t)
+            reg_of, code, params = {}, [], []
+            next_reg = len(inputs)
+
+            def operand(t):
+                if t.node.id in ids and t.node.op != "strided":
+                    return reg_of[t]
+                return ext_operand(t)
+
+            for m in c.nodes:
+                o = m.outputs[0]
+                if m.op == "strided":
+                    continue
+                if m.op in ("reshape", "bcast"):
+                    reg_of[o] = operand(m.inputs[0])
+                    continue
+                if m.op == "reduce":
+                    code.append([H.COLPROG_SUM if m.attrs["kind"] == "sum" else H.COLPROG_MAX, next_reg, operand(m.inputs[0]), -1, -1])
+                    params.append([0.0, 0.0])
+                else:
+                    ops = ([operand(t) for t in m.inputs] + [-1, -1, -1])[:3]
+                    pp = list(m.attrs["p"]) + [0.0, 0.0]
+                    code.append([H.EW[m.attrs["f"]], next_reg] + ops)
+                    params.append([pp[0], pp[1]])
+                reg_of[o] = next_reg
+                next_reg += 1
+            outs, out_regs = [], []
+            for m in c.nodes:
+                if m.op == "strided":
+                    continue
+                for o in m.outputs:
+                    if o in self.outputs or any(x.id not in ids for x in self._consumers.get(o, [])):
+                        form = _colform(o.shape, R, n)
+                        b = self.out(o)
+                        outs.append((b, 0, n, 1) if form == "full" else ((b, 0, 0, 1) if form == "row" else (b, 0, 0, 0)))
+                        out_regs.append(reg_of[o])
+            if not code or not outs or len(inputs) > EW_COL_MAX_IN + 4 or len(outs) > EW_COL_MAX_OUT:
+                raise ValueError("column program too wide")
+            prog = H.ColProgram(code, params, inputs, outs, out_regs, R, n)
+        except (ValueError, _HipBackendError):
+            del self.steps[steps_before:]
+            for m in c.nodes:   # one launch per node, as without column programs
+                self._emit(m)
+            return False
+        step = prog.launch
+        self.steps.append(step)
+        self.step_labels[id(step)] = "col_cluster[%d]" % len(c.nodes)
+        return True
 
     def inject_noise(self, t: Tensor, value):
         """Overwrite a random_normal leaf with a fixed draw (parity runs)."""

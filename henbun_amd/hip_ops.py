@@ -241,6 +241,53 @@ class EwiseProgram:
                 pass
 
 
+COLPROG_SUM, COLPROG_MAX = -1, -2   # row reductions of a column program (HB_COLPROG_* in include/henbun_hip.h)
+
+
+class ColProgram:
+    """A prepared column program (hb_ewise_colprog_build): a fused program over an [R, n] space, one thread per
+    column, reductions over the row axis as ordinary instructions.
+
+    `inputs` / `outputs`: lists of (tensor, element offset, row stride, column stride); code rows are
+    [op, dst, a, b, c] with -1 for an unused operand slot."""
+
+    def __init__(self, code, params, inputs, outputs, out_regs, R, n, dry=False):
+        from ctypes import c_int
+
+        ref = (outputs[0][0] if outputs else inputs[0][0])
+        self.suf = _suf(ref)
+        isz = ref.element_size()
+        self.ninstr = len(code)
+        self.code = (c_int * (5 * len(code)))(*[int(v) for ins in code for v in ins])
+        self.params = (c_double * (2 * len(code)))(*[float(v) for pr in params for v in pr])
+        self.nin, self.nout = len(inputs), len(outputs)
+        self.inputs = (c_void_p * max(self.nin, 1))(*[t.data_ptr() + int(off) * isz for t, off, _, _ in inputs])
+        self.istr = _larr([v for _, _, rs, cs in inputs for v in (rs, cs)] or [0])
+        self.outputs = (c_void_p * self.nout)(*[t.data_ptr() + int(off) * isz for t, off, _, _ in outputs])
+        self.ostr = _larr([v for _, _, rs, cs in outputs for v in (rs, cs)])
+        self.out_regs = (c_int * self.nout)(*[int(r) for r in out_regs])
+        self._keep = (inputs, outputs)
+        self.R, self.n = int(R), int(n)
+        src = ctypes.create_string_buffer(EWISE_JIT_SOURCE_BYTES)
+        handle = c_void_p(None)
+        _lib.lib().call("hb_ewise_colprog_build" + self.suf, self.ninstr, self.code, self.params, self.nin, self.inputs, self.istr,
+                        self.nout, self.outputs, self.out_regs, self.ostr, self.R, self.n,
+                        None if dry else ctypes.byref(handle), src, EWISE_JIT_SOURCE_BYTES)
+        self.handle = None if dry else handle
+        self.source = src.value.decode()
+
+    def launch(self):
+        _lib.lib().call("hb_ewise_jit_run", self.handle, stream())
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().raw("hb_ewise_jit_destroy")(h)
+            except Exception:
+                pass
+
+
 def gauss_ll(x, f, scale, var, out=None):
     """(ll[1], dmu[like x], dscale[1], dvar[1]) of sum_j log N(x_j | f_j*scale, var)  (hb_gauss_ll; scale may be None)."""
     _chk(x), _chk(f), _chk(var)

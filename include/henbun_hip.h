@@ -141,6 +141,28 @@ int hb_ewise_jit_build_f64(int ninstr, const int* code, const double* params, in
                            int* reduces_out, char* source_out, long source_cap);
 int hb_ewise_jit_run(void* handle, void* stream);
 int hb_ewise_jit_destroy(void* handle);
+/* Column programs (round 3): a fused program over a SHORT-AND-WIDE space [R, n] (R <= 16 rows, e.g. the E experts of a
+ * softmax gate over a minibatch of n points) in which reductions over the ROW axis are ordinary instructions.  One
+ * thread owns one column: a register is R values (operands [R, n]) or one value (operands [1, n], scalars, and the
+ * result of a row reduction), every row loop is unrolled in the thread, so the softmax gate of the expert mixture
+ * (reference notebooks/Expert_GPR.ipynb:139-147: reduce_max, exp, reduce_sum, divide, weighted sum -- eight launches
+ * op by op, three of them tf.reduce_* over axis 0) and its whole VJP are ONE launch each and every operand is read once.
+ *   code[q] = {op, dst, a, b, c}: op is an HB_EW_* code (not HB_EW_GAUSS_LOGPDF_GRAD) or HB_COLPROG_SUM / HB_COLPROG_MAX
+ *             (dst[0] = sum / max over the rows of register a, rows in order 0..R-1); registers 0..nin-1 are the inputs.
+ *   istrides[k] = {row stride, column stride} of input k in elements: {ld, 1} an [R, n] operand (ld >= n: a row block of a
+ *             taller matrix is passed by pointer offset, no copy), {0, 1} a row [1, n], {0, 0} a scalar.
+ *   out_regs / ostrides likewise; an output with column stride 0 is written by the thread of column 0.
+ * A register is R-high exactly when one of its operands is; handle_out / source_out / dry run as for
+ * hb_ewise_jit_build; the handle is launched with hb_ewise_jit_run and released with hb_ewise_jit_destroy. */
+enum { HB_COLPROG_SUM = -1, HB_COLPROG_MAX = -2 };
+int hb_ewise_colprog_build_f32(int ninstr, const int* code, const double* params, int nin, const void* const* in,
+                               const long* istrides, int nout, void* const* out, const int* out_regs,
+                               const long* ostrides, long R, long n, void** handle_out, char* source_out,
+                               long source_cap);
+int hb_ewise_colprog_build_f64(int ninstr, const int* code, const double* params, int nin, const void* const* in,
+                               const long* istrides, int nout, void* const* out, const int* out_regs,
+                               const long* ostrides, long R, long n, void** handle_out, char* source_out,
+                               long source_cap);
 
 enum { HB_RED_SUM = 0, HB_RED_MAX = 1 };
 /* out[K1,K2] = reduce over R of contiguous in[K1,R,K2]  (tf.reduce_sum / reduce_max) */

@@ -372,3 +372,73 @@ def test_serial_chain_source_generates_and_compiles_for_gfx950():
     finally:
         lib.raw("hb_chain_discard")()
     assert lib.raw("hb_chain_discard")() == 0
+
+
+def _gate_graph(E=4, n=4096):
+    from henbun_amd import graph as G
+
+    G.reset_interning()
+    f_all = G.leaf("var", (2 * E, 1, n), name="f_all")
+    kr, kv = G.leaf("var", (1,), name="kr"), G.leaf("var", (1,), name="kv")
+    y = G.leaf("var", (1, n), name="y")
+    f_e = f_all[:E, 0, :]
+    g_e = f_all[E:, 0, :] * G.unary("SQRT", kr)
+    w = G.unary("EXP", g_e - G.reduce_max(g_e, 0, keep_dims=True))
+    w = w / G.reduce_sum(w, 0, keep_dims=True)
+    f = G.reduce_sum(w * f_e, 0, keep_dims=True) * kv
+    loss = G.reshape(G.reduce_sum(G.square(f - y)), [])
+    return G, loss, G.gradients(loss, [f_all, kr, kv])
+
+
+def test_softmax_gate_becomes_two_column_clusters_and_an_in_place_concatenation():
+    """The softmax gate of the expert mixture (reference notebooks/Expert_GPR.ipynb:139-147) and its VJP: the planner
+    groups the elementwise ops, the tf.reduce_max / reduce_sum over the expert axis and the row-block slices of the
+    batched draw into two column programs (graph.cluster_columns); the gradient of the draw is the CONCATENATION of the
+    experts' and the gates' halves (leading-axis _scatter_partition), not two zero-filled scatters added up."""
+    G, loss, grads = _gate_graph()
+    order = G.topo_order([loss] + grads)
+    cm = G.cluster_columns(order, outputs=[loss] + grads)
+    clusters = list({id(c): c for c in cm.values()}.values())
+    assert len(clusters) == 2 and all((c.R, c.n) == (4, 4096) for c in clusters)
+    fwd, bwd = sorted(clusters, key=lambda c: order.index(c.nodes[0]))
+    assert sum(m.op == "strided" for m in fwd.nodes) == 2 and sum(m.op == "reduce" for m in fwd.nodes) == 3
+    assert sum(m.op == "reduce" for m in bwd.nodes) >= 2
+    # no row reduction, slice, scatter or add of [2E, n] arrays is left outside
+    left = [m for m in order if m.id not in cm]
+    assert not [m for m in left if m.op in ("strided", "scatter_strided")]
+    assert not [m for m in left if m.op == "reduce" and m.attrs["K2"] > 1]
+    assert grads[0].node.op == "concat" and grads[0].node.attrs["axis"] == 0
+    # regular elementwise clustering leaves the column members alone
+    reg = G.cluster_elementwise(order, skip=cm)
+    assert not set(reg) & set(cm)
+    # short arrays stay with the plain clusters
+    G2, loss2, grads2 = _gate_graph(n=64)
+    assert not G2.cluster_columns(G2.topo_order([loss2] + grads2), outputs=[loss2] + grads2)
+
+
+def test_column_program_source_compiles_for_gfx950_without_a_device():
+    import ctypes
+    from ctypes import c_double, c_int, c_long, c_void_p
+
+    from henbun_amd import _lib
+    from henbun_amd import hip_ops as H
+
+    lib = _lib.lib()
+    if not lib.raw("hb_ewise_jit_available")():
+        pytest.skip("hiprtc not available")
+    E = H.EW
+    code = [[H.COLPROG_MAX, 1, 0, -1, -1], [E["SUB"], 2, 0, 1, -1], [E["EXP"], 3, 2, -1, -1], [H.COLPROG_SUM, 4, 3, -1, -1],
+            [E["DIV"], 5, 3, 4, -1]]
+    codeA = (c_int * 25)(*[v for r in code for v in r])
+    par = (c_double * 10)(*[0.0] * 10)
+    src = ctypes.create_string_buffer(8192)
+    for suf in ("_f32", "_f64"):
+        lib.call("hb_ewise_colprog_build" + suf, 5, codeA, par, 1, (c_void_p * 1)(None), (c_long * 2)(1000, 1), 2,
+                 (c_void_p * 2)(None, None), (c_int * 2)(5, 4), (c_long * 4)(1000, 1, 0, 1), 4, 1000, None, src, 8192)
+        text = src.value.decode()
+        assert "hb_jit_kernel" in text and "r4[0] = acc" in text and "for (int q = 0; q < 4; ++q)" in text
+    # a register read before it is written is refused
+    bad = (c_int * 5)(E["EXP"], 3, 2, -1, -1)
+    with pytest.raises(_lib.HipBackendError):
+        lib.call("hb_ewise_colprog_build_f32", 1, bad, par, 1, (c_void_p * 1)(None), (c_long * 2)(1000, 1), 1,
+                 (c_void_p * 1)(None), (c_int * 1)(3), (c_long * 2)(1000, 1), 4, 1000, None, src, 8192)

@@ -1062,6 +1062,47 @@ def test_ewise_program_sum_outputs(H, p, n, mode):
 
 
 @pytest.mark.parametrize("p", ["f32", "f64"])
+@pytest.mark.parametrize("R,n", [(4, 3001), (2, 64), (7, 777)])
+def test_column_program_softmax_gate(H, p, R, n):
+    """hb_ewise_colprog_*: the softmax gate of the expert mixture (reference notebooks/Expert_GPR.ipynb:139-147) as ONE
+    launch over an [R, n] space -- row-block slices of a taller source read in place, tf.reduce_max / reduce_sum over
+    axis 0 as in-thread row loops, a scalar operand, a [1, n] result, an [R, n] result and a broadcast store of a
+    [1, n] value over the R rows -- against the oracle's op-by-op torch evaluation."""
+    dt = DT[p]
+    rng = np.random.RandomState(R * 1000 + n)
+    f_all = rng.randn(2 * R, 1, n)
+    kr = np.abs(rng.randn(1)) + 0.5
+    src = dev(f_all, dt)
+    E = H.EW
+    # r0 = f_all[:R], r1 = f_all[R:], r2 = kr ; g = r1 * sqrt(kr); m = max_rows g; w = exp(g - m); s = sum_rows w;
+    # wn = w / s; f = sum_rows(wn * r0)
+    code = [[E["SQRT"], 3, 2, -1, -1], [E["MUL"], 4, 1, 3, -1], [H.COLPROG_MAX, 5, 4, -1, -1], [E["SUB"], 6, 4, 5, -1],
+            [E["EXP"], 7, 6, -1, -1], [H.COLPROG_SUM, 8, 7, -1, -1], [E["DIV"], 9, 7, 8, -1], [E["MUL"], 10, 9, 0, -1],
+            [H.COLPROG_SUM, 11, 10, -1, -1]]
+    params = [[0.0, 0.0]] * len(code)
+    ins = [(src, 0, n, 1), (src, R * n, n, 1), (dev(kr, dt), 0, 0, 0)]
+    wn = torch.empty(R, n, dtype=dt, device="cuda")
+    f = torch.empty(1, n, dtype=dt, device="cuda")
+    mb = torch.empty(R, n, dtype=dt, device="cuda")     # the row maxima broadcast over the rows
+    sq = torch.full((1,), float("nan"), dtype=dt, device="cuda")
+    outs = [(wn, 0, n, 1), (f, 0, 0, 1), (mb, 0, n, 1), (sq, 0, 0, 0)]
+    prog = H.ColProgram(code, params, ins, outs, [9, 11, 5, 3], R, n)
+    assert "for (int q = 0; q < %d; ++q)" % R in prog.source
+    prog.launch()
+    t = O.T(f_all)
+    fe, ge = t[:R, 0, :], t[R:, 0, :] * O.T(kr).sqrt()
+    gm = ge.max(0, keepdim=True).values
+    w = (ge - gm).exp()
+    w = w / w.sum(0, keepdim=True)
+    fr = (w * fe).sum(0, keepdim=True)
+    tol = TOL[p] if p == "f64" else dict(rtol=2e-6, atol=2e-6)
+    assert_close(wn, w, tol)
+    assert_close(f, fr, tol)
+    assert_close(mb, gm.expand(R, n), tol)
+    assert_close(sq, O.T(kr).sqrt(), tol)
+
+
+@pytest.mark.parametrize("p", ["f32", "f64"])
 def test_ewise_program_compiled_equals_interpreted(H, p):
     """The run-time compiled form of a program (hb_ewise_jit_*) against the interpreted one (hb_ewise_prog_run_*): both
     evaluate the library's own ew_apply op by op, so a chain through the arithmetic part of the op table (broadcast
