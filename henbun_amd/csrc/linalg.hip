@@ -234,20 +234,20 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
   const long total = a.batch * a.M * a.N;
   const long stride = (long)gridDim.x * blockDim.x;
   if ((a.flags & HB_MM_COLSUM_B) && a.colsum) {
-    // the column sums of B ride along: S <= 64 slab partials per column.  16 lanes per column, every lane's (at most
+    // the column sums of B ride along: S <= 128 slab partials per column.  16 lanes per column, every lane's (at most
     // four) loads independent, then a fixed-order fold across the 16 lanes: one memory round trip (a serial loop over the
     // slabs is one dependent round trip PER SLAB -- it tripled the duration of this launch)
     const int sl = threadIdx.x & 15;
     for (long cb = blockIdx.x; cb * 16 < a.N; cb += gridDim.x) {
       const long c = cb * 16 + (threadIdx.x >> 4);
       const long cc = c < a.N ? c : a.N - 1;
-      T v[4];
+      T v[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 8; ++q) {
         const int s = sl + 16 * q;
         v[q] = s < a.S ? a.colsum_ws[(long)s * a.N + cc] : T(0);
       }
-      T acc = (v[0] + v[1]) + (v[2] + v[3]);
+      T acc = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 #pragma unroll
       for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
       if (sl == 0 && c < a.N) a.colsum[c] = acc;
@@ -514,6 +514,373 @@ int matmul_wgk_launch<float>(const MmArgs<float>& a, int transA, int transB, hip
   return 0;
 }
 
+// ===========================================================================
+// Row-streaming GEMM (round 3): C[M, N] = epilogue(A[M, K] op(B)[K, N]) for a TALL A (a minibatch of rows) and a small
+// op(B) (a layer's weights: K, N <= 256) -- the MatBias layers of the amortised encoder and their input gradients
+// (reference nn.py:31-32, 73-84; cfg 4: [32768, 64] x [64, 256], [32768, 256] x [256, 32], ...).
+//
+// The tile engine above gives every 64 x 64 output tile its own workgroup with a double-buffered LDS pipeline and one
+// barrier per 16-deep k-step: for K = 16 .. 256 that is all prologue and epilogue, and every such launch took ~15 us at
+// n = 32768 whatever its size (2.2-2.6 TB/s on operands that stream once).  Here the WEIGHTS are the LDS-resident
+// operand: a workgroup stages op(B) once as Ws[column][k] (k contiguous: the B-fragment of an MFMA is one 16-byte LDS
+// read per four k), then each of its four waves takes 32 rows of A at a time, reads them straight from global memory as
+// MFMA A-fragments (the contraction index is permuted so a lane reads G contiguous floats of its row: whole cache
+// lines, no LDS staging, no barrier in the loop), keeps the 32 x N result in registers (N/32 accumulator tiles) and
+// writes it once with the epilogue applied (bias + activation, or the activation gradient from the layer's output).
+// Two workgroups per CU (72 KB of LDS each).
+// ===========================================================================
+#define RS_LDS_FLOATS 18432
+// NT accumulator tiles (32 columns each) per wave; WC waves side by side along the columns (N <= 32 NT WC), NW / WC wave
+// rows of 32 matrix rows each.  n = 32768 rows are 1024 wave tiles for 2048 resident waves: with a whole 32 x N result
+// per wave every wave runs ONE tile -- staging, operand latency, MFMAs and a long epilogue in sequence, nothing to cover
+// them (N = 256 as NT = 8: 39 us; as NT = 4 x 2 wave columns: 31.6 us; the tile engine 25.7).  For N > 128 a workgroup is
+// therefore EIGHT waves side by side, one 32 x 32 tile each (16 accumulators, <= 128 registers: four waves per SIMD
+// with two workgroups per CU), and it walks several row tiles so the staged weights are used more than once.
+template <bool TB, int NT, int WC, int G, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) matmul_rows_kernel(MmArgs<float> a) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef Mma<float> MM;
+  __shared__ __attribute__((aligned(16))) float Ws[RS_LDS_FLOATS];   // [32 NT WC columns][K + 4]
+  const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
+  const int lda = (int)a.lda, ldb = (int)a.ldb, ldc = (int)a.ldc;
+  const int KLD = K + 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  constexpr int NP = 32 * NT * WC, ROWS = 32 * (NW / WC), NTHR = 64 * NW;
+  const int wr = w / WC, wc = w % WC;
+  // ---- stage op(B): element (column c, k) = op(B)[k][c]; columns past N are zero
+  {
+    const int kq = K >> 2;
+    if (TB) {             // stored [N][ldb]: k contiguous
+      for (int idx = tid; idx < NP * kq; idx += NTHR) {
+        const int c = idx / kq, k4 = idx - c * kq;
+        V4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < N) v = *reinterpret_cast<const V4*>(a.B + (long)c * ldb + 4 * k4);
+        *reinterpret_cast<V4*>(&Ws[c * KLD + 4 * k4]) = v;
+      }
+    } else {
+      // stored [K][ldb]: consecutive threads take consecutive COLUMNS of four k rows -- four coalesced scalar loads, one
+      // 16-byte LDS store whose addresses are K + 4 floats apart (all bank groups).  (A 4 x 4 register transpose with
+      // 16-byte loads was tried in both thread orders: column-major order puts a wave's stores on two bank groups, a
+      // 32-way conflict; k-major order turns every load into 64 cache lines, and 512 workgroups asking the same 512
+      // lines of the weights cost ~7 us of L2 hot-spotting.  Either way the launch never got under 26 us.)
+      for (int idx = tid; idx < NP * kq; idx += NTHR) {
+        const int k4 = idx / NP, c = idx - k4 * NP;
+        V4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < N) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = a.B[(long)(4 * k4 + i) * ldb + c];
+        }
+        *reinterpret_cast<V4*>(&Ws[c * KLD + 4 * k4]) = v;
+      }
+    }
+  }
+  const int cbase = 32 * NT * wc;   // this wave's first column
+  float breg[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int c = cbase + 32 * t + li;
+    breg[t] = (a.bias && !(a.flags & HB_MM_ACTGRAD) && c < N) ? a.bias[c] : 0.f;
+  }
+  __syncthreads();
+  const int nchunk = K / (2 * G);
+  const int ntile = (M + ROWS - 1) / ROWS;
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int r0 = tile * ROWS + 32 * wr;
+    if (r0 >= M || cbase >= N) continue;   // (whole waves; no barrier below)
+    const int arow = r0 + li < M ? r0 + li : M - 1;
+    const float* __restrict__ ap = a.A + (long)arow * lda + G * h;
+    typename MM::Acc acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    auto load = [&](V4 (&f)[G / 4], int c) {
+      const int cc = c < nchunk ? c : nchunk - 1;
+#pragma unroll
+      for (int v = 0; v < G / 4; ++v) f[v] = *reinterpret_cast<const V4*>(ap + 2 * G * cc + 4 * v);
+    };
+    auto compute = [&](const V4 (&f)[G / 4], int c) {
+      if (c >= nchunk) return;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float* wp = &Ws[(cbase + 32 * t + li) * KLD + 2 * G * c + G * h];
+        V4 bv[G / 4];
+#pragma unroll
+        for (int v = 0; v < G / 4; ++v) bv[v] = *reinterpret_cast<const V4*>(wp + 4 * v);
+#pragma unroll
+        for (int v = 0; v < G / 4; ++v)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) acc[t] = MM::mma(f[v][s2], bv[v][s2], acc[t]);
+      }
+    };
+    V4 fa[G / 4], fb[G / 4];
+    load(fa, 0);
+#pragma nounroll
+    for (int c = 0; c < nchunk; c += 2) {
+      load(fb, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fa, c);
+      __builtin_amdgcn_sched_barrier(0);
+      load(fa, c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fb, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: accumulator layout = column on the lane, rows in the registers (two 128-byte row segments per store)
+    if (a.flags & HB_MM_ACTGRAD) {
+      const float* __restrict__ Y = a.bias;   // the layer's output, [M][N]
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = cbase + 32 * t + li;
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + MM::acc_row(lane, r);
+          y[r] = Y[(long)(row < M ? row : M - 1) * N + (c < N ? c : N - 1)];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + MM::acc_row(lane, r);
+          if (row < M && c < N) a.C[(long)row * ldc + c] = a.alpha * acc[t][r] * act_grad<float>(a.act, y[r]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int c = cbase + 32 * t + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + MM::acc_row(lane, r);
+          if (row < M && c < N) a.C[(long)row * ldc + c] = apply_act<float>(a.act, a.alpha * acc[t][r] + breg[t]);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-streaming GEMM with REGISTER-resident weights (K <= 128): a wave owns one 32-column tile of the result and keeps
+// that tile's K x 32 block of op(B) in registers (K / 2 per lane, loaded once, straight from global memory in MFMA
+// B-fragment order), then walks its share of the 32-row tiles of A: next tile's A fragments requested before the
+// current tile's MFMAs, 32 x 32 result written with the epilogue applied.  No LDS, no barrier, no staging phase: the
+// LDS form above runs every workgroup through stage -> barrier -> load -> MFMA -> store in lock step (all 512 of them
+// at once, two row tiles each), so memory and matrix phases never overlap -- 24.6 us for [32768, 64] x [64, 256] whose
+// MFMAs are 7.5 us and whose bytes are 8 us.  Here the waves are independent and drift apart: 23.7 us for that product,
+// 18.0 (LDS form 21.7, tile engine 27.8) for the input gradient [32768, 32] x [256, 32]^T with the activation-gradient
+// epilogue, 7.2 (8.9) for [32768, 16] x [16, 64].  What still holds the first one at 24 us was narrowed down with two
+// timing variants: without its stores it takes the same time, with its MFMAs replaced by one FMA each it takes LONGER
+// (41 us) -- the operand side is the limit: a lane's A fragment is 16 bytes of its own row, so every load instruction
+// touches 64 different cache lines (the access pattern the fragment-major images remove for the sparse-GP operands);
+// a coalesced load + LDS transpose of the row tile is the form that remains to be built.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool TB, int G, int KC>
+__global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef Mma<float> MM;
+  const int M = (int)a.M, N = (int)a.N;
+  const int lda = (int)a.lda, ldb = (int)a.ldb, ldc = (int)a.ldc;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
+  const int nct = (N + 31) / 32, nrt = (M + 31) / 32;
+  const int gw = blockIdx.x * 4 + w, nw = gridDim.x * 4;
+  const int ct = gw % nct;
+  const int rstride = nw / nct;            // (the launcher makes nw a multiple of nct)
+  const int col = 32 * ct + li, colc = col < N ? col : N - 1;
+  // ---- this tile's weights: bf[c][j] = op(B)[2G c + G h + j][col]
+  float bf[KC][G];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    if (TB) {
+      const float* bp = a.B + (long)colc * ldb + 2 * G * c + G * h;
+#pragma unroll
+      for (int v = 0; v < G / 4; ++v) {
+        const V4 q = *reinterpret_cast<const V4*>(bp + 4 * v);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) bf[c][4 * v + s2] = col < N ? q[s2] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const float q = a.B[(long)(2 * G * c + G * h + j) * ldb + colc];
+        bf[c][j] = col < N ? q : 0.f;
+      }
+    }
+  }
+  const float bias = (a.bias && !(a.flags & HB_MM_ACTGRAD) && col < N) ? a.bias[col] : 0.f;
+  auto load = [&](V4 (&f)[KC][G / 4], int rt) {
+    const int rtc = rt < nrt ? rt : nrt - 1;
+    const int row = 32 * rtc + li;
+    const float* ap = a.A + (long)(row < M ? row : M - 1) * lda + G * h;
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int v = 0; v < G / 4; ++v) f[c][v] = *reinterpret_cast<const V4*>(ap + 2 * G * c + 4 * v);
+  };
+  auto compute = [&](const V4 (&f)[KC][G / 4], int rt) {
+    if (rt >= nrt) return;
+    typename MM::Acc acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int v = 0; v < G / 4; ++v)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc = MM::mma(f[c][v][s2], bf[c][4 * v + s2], acc);
+    const int r0 = 32 * rt;
+    if (a.flags & HB_MM_ACTGRAD) {
+      const float* __restrict__ Y = a.bias;
+      float y[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + MM::acc_row(lane, r);
+        y[r] = Y[(long)(row < M ? row : M - 1) * N + colc];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + MM::acc_row(lane, r);
+        if (row < M && col < N) a.C[(long)row * ldc + col] = a.alpha * acc[r] * act_grad<float>(a.act, y[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + MM::acc_row(lane, r);
+        if (row < M && col < N) a.C[(long)row * ldc + col] = apply_act<float>(a.act, a.alpha * acc[r] + bias);
+      }
+    }
+  };
+  int rt = gw / nct;
+  if (rt >= nrt) return;
+  V4 fa[KC][G / 4], fb[KC][G / 4];
+  load(fa, rt);
+#pragma nounroll
+  for (; rt < nrt; rt += 2 * rstride) {
+    load(fb, rt + rstride);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(fa, rt);
+    __builtin_amdgcn_sched_barrier(0);
+    load(fa, rt + 2 * rstride);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(fb, rt + rstride);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+static inline bool matmul_rowsreg_ok(const MmArgs<float>& a, int& G, int& KC) {
+  static const bool off = getenv("HB_MM_NO_ROWSREG") != nullptr;   // diagnostic: the LDS form
+  // one column tile (N <= 32): the LDS form is the faster one ([32768, 64] x [64, 16]: 5.7 against 8.7 us) -- every wave
+  // would hold the same weights
+  if (off || a.N <= 32) return false;
+  if (a.K == 16) {
+    G = 8, KC = 1;
+    return true;
+  }
+  G = 16;
+  KC = (int)(a.K / 32);
+  return a.K % 32 == 0 && (KC == 1 || KC == 2 || KC == 4);
+}
+static int matmul_rowsreg_launch(const MmArgs<float>& a, int transB, int G, int KC, hipStream_t stream) {
+  const long nct = hb_cdiv(a.N, 32), nrt = hb_cdiv(a.M, 32);
+  // enough waves to fill the chip at this register count, at least ~2 row tiles each; a multiple of nct waves
+  const long occ = KC >= 4 ? 2 : (KC == 2 ? 3 : 4);
+  long wgs = hb_cdiv(nrt * nct, 8);
+  if (wgs > 256 * occ) wgs = 256 * occ;
+  long unit = nct;                 // 4 wgs must be a multiple of nct (nct <= 8)
+  while (unit % 4 != 0) unit *= 2;
+  unit /= 4;
+  wgs = (wgs / unit) * unit;
+  if (wgs < unit) wgs = unit;
+  dim3 grid((unsigned)wgs, 1, 1);
+#define HB_RR2(TB_, G_, KC_) hipLaunchKernelGGL((matmul_rowsreg_kernel<TB_, G_, KC_>), grid, dim3(256), 0, stream, a)
+#define HB_RR1(TB_)           \
+  do {                        \
+    if (G == 8)               \
+      HB_RR2(TB_, 8, 1);      \
+    else if (KC == 1)         \
+      HB_RR2(TB_, 16, 1);     \
+    else if (KC == 2)         \
+      HB_RR2(TB_, 16, 2);     \
+    else                      \
+      HB_RR2(TB_, 16, 4);     \
+  } while (0)
+  if (transB)
+    HB_RR1(true);
+  else
+    HB_RR1(false);
+#undef HB_RR1
+#undef HB_RR2
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline void matmul_rows_shape(long N, int& NT, int& WC, int& NW) {
+  const long nt = (N + 31) / 32;
+  if (nt > 4) {
+    NT = 1, WC = 8, NW = 8;
+    return;
+  }
+  WC = 1, NW = 4;
+  NT = nt <= 1 ? 1 : nt <= 2 ? 2 : 4;
+}
+template <typename T>
+static bool matmul_rows_ok(const MmArgs<T>&, int, int) { return false; }
+template <>
+bool matmul_rows_ok<float>(const MmArgs<float>& a, int transA, int transB) {
+  static const bool off = getenv("HB_MM_NO_ROWS") != nullptr;   // diagnostic: the tile engine for everything
+  if (off || transA || a.batch != 1 || a.M < 2048 || a.K < 8 || a.K > 256 || a.K % 8 != 0 || a.N < 1 || a.N > 256) return false;
+  if (!(a.flags == 0 || a.flags == HB_MM_ACTGRAD) || a.beta != 0.f) return false;
+  int NT, WC, NW;
+  matmul_rows_shape(a.N, NT, WC, NW);
+  if (32L * NT * WC * (a.K + 4) > RS_LDS_FLOATS) return false;
+  if ((uintptr_t)a.A % 16 != 0 || a.lda % 4 != 0) return false;
+  if (transB && ((uintptr_t)a.B % 16 != 0 || a.ldb % 4 != 0)) return false;
+  return a.M * a.lda < 2147483647L && a.M * a.ldc < 2147483647L;
+}
+template <typename T>
+static int matmul_rows_launch(const MmArgs<T>&, int, hipStream_t) { return -1; }
+template <>
+int matmul_rows_launch<float>(const MmArgs<float>& a, int transB, hipStream_t stream) {
+  {
+    int G2, KC2;
+    if (matmul_rowsreg_ok(a, G2, KC2)) return matmul_rowsreg_launch(a, transB, G2, KC2, stream);
+  }
+  int NT, WC, NW;
+  matmul_rows_shape(a.N, NT, WC, NW);
+  const int G = a.K % 32 == 0 ? 16 : (a.K % 16 == 0 ? 8 : 4);
+  const long ntile = hb_cdiv(a.M, 32 * (NW / WC));
+  dim3 grid((unsigned)(ntile < 512 ? ntile : 512), 1, 1);
+#define HB_RS3(TB_, NT_, WC_, G_, NW_) \
+  hipLaunchKernelGGL((matmul_rows_kernel<TB_, NT_, WC_, G_, NW_>), grid, dim3(64 * NW_), 0, stream, a)
+#define HB_RS2(TB_, NT_, WC_, NW_)     \
+  do {                                 \
+    if (G == 16)                       \
+      HB_RS3(TB_, NT_, WC_, 16, NW_);  \
+    else if (G == 8)                   \
+      HB_RS3(TB_, NT_, WC_, 8, NW_);   \
+    else                               \
+      HB_RS3(TB_, NT_, WC_, 4, NW_);   \
+  } while (0)
+#define HB_RS1(TB_)          \
+  do {                       \
+    if (WC == 8)             \
+      HB_RS2(TB_, 1, 8, 8);  \
+    else if (NT == 1)        \
+      HB_RS2(TB_, 1, 1, 4);  \
+    else if (NT == 2)        \
+      HB_RS2(TB_, 2, 1, 4);  \
+    else                     \
+      HB_RS2(TB_, 4, 1, 4);  \
+  } while (0)
+  if (transB)
+    HB_RS1(true);
+  else
+    HB_RS1(false);
+#undef HB_RS1
+#undef HB_RS2
+#undef HB_RS3
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T>
 static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long N, long K, long lda, long ldb,
                          long ldc, long sA, long sB, long sC, int transA, int transB, double alpha, double beta,
@@ -540,9 +907,9 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   a.colsum = nullptr;
   a.colsum_ws = nullptr;
   if (colsum) {
-    // the slab partials of the column sums sit at the end of the workspace (64 slabs at most)
-    HB_REQUIRE(ws && ws_elems > 64 * N, "hb_matmul_colsum: workspace too small");
-    ws_elems -= 64 * N;
+    // the slab partials of the column sums sit at the end of the workspace (128 slabs at most)
+    HB_REQUIRE(ws && ws_elems > 128 * N, "hb_matmul_colsum: workspace too small");
+    ws_elems -= 128 * N;
     a.colsum_ws = ws + ws_elems;
   }
   // Tile / split choice.  These are latency-and-occupancy problems more often than throughput ones: a
@@ -556,6 +923,7 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
              "hb_matmul: ACTGRAD needs Y in `bias`, beta = 0 and no other flag");
   HB_REQUIRE(!(flags & HB_MM_SYMLOW_OUT) || (M == N && !bias && act == HB_ACT_NONE && beta == 0.0 && flags == HB_MM_SYMLOW_OUT),
              "hb_matmul: SYMLOW_OUT needs a square result and no other epilogue");
+  if (!colsum && matmul_rows_ok<T>(a, transA, transB)) return matmul_rows_launch<T>(a, transB, stream);   // tall A, small op(B)
   const bool lower = (flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT | HB_MM_SYMLOW_OUT)) != 0;
   auto active_tiles = [&](int bt) -> long {
     const long tr = hb_cdiv(M, bt), tc = hb_cdiv(N, bt);
@@ -585,6 +953,8 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
     const long s3 = ws_elems / (batch * M * N);
     if (s0 > s1) s0 = s1;
     if (s0 > s3) s0 = s3;
+    // (128 slabs for the weight gradients of cfg 4 -- K = 32768 into 64 x 256 -- were tried: the product 16.3 -> 13.5 us,
+    //  its finish launch 6.9 -> 11.9 us)
     if (s0 > 64) s0 = 64;
     if (s0 >= 2) S = (int)s0;
   }

@@ -329,6 +329,39 @@ def test_matmul_activation_gradient_epilogue(H, p):
         H.matmul(dev(g, dt), dev(w, dt), act="tanh", actgrad=dev(y, dt), bias=dev(rng.randn(50), dt))
 
 
+@pytest.mark.parametrize("tB", [False, True])
+def test_matmul_row_streaming_form_for_tall_operands(H, tB):
+    """fp32 products of a TALL A (a minibatch of rows) with a small op(B) (a MatBias layer's weights; reference
+    nn.py:31-32, cfg 4's [32768, 64] x [64, 256] ...) run in the row-streaming form (matmul_rows_kernel: weights resident
+    in LDS, A read straight into MFMA fragments): every k-group width (K % 32 / 16 / 8), every accumulator count
+    (N <= 32 / 64 / 128 / 256), ragged M and N, bias + activation and the activation-gradient epilogue, against numpy in
+    fp64."""
+    dt = torch.float32
+    rng = np.random.RandomState(11)
+    for m, k, n in ((4096, 64, 256), (2500, 256, 32), (3001, 16, 64), (2048, 64, 16), (2304, 32, 250), (2177, 24, 100),
+                    (4099, 8, 7), (2048, 40, 128)):
+        a = rng.randn(m, k)
+        b = rng.randn(*((n, k) if tB else (k, n)))
+        full = a @ (b.T if tB else b)
+        A_, B_ = dev(a, dt), dev(b, dt)
+        tol = dict(rtol=1e-5, atol=2e-5 * np.sqrt(k))    # observed <= 4e-6 sqrt(k)
+        got = H.matmul(A_, B_, transB=tB, alpha=0.5)
+        assert_close(got, 0.5 * full, tol)
+        bias = rng.randn(n)
+        assert_close(H.matmul(A_, B_, transB=tB, bias=dev(bias, dt), act="sigmoid", alpha=0.1),
+                     1 / (1 + np.exp(-(0.1 * full + bias))), dict(rtol=1e-5, atol=2e-6))
+        y = rng.rand(m, n)
+        assert_close(H.matmul(A_, B_, transB=tB, act="sigmoid", actgrad=dev(y, dt)), full * y * (1 - y), tol)
+        out = torch.full((m, n), float("nan"), dtype=dt, device="cuda")
+        H.matmul(A_, B_, transB=tB, out=out)
+        assert not torch.isnan(out).any()
+    # A = I padded with zero rows and an asymmetric B: the k permutation of the two operand forms and the row / column map
+    bb = (np.arange(64 * 96, dtype=np.float64).reshape(64, 96) % 251) - 100
+    eye = np.zeros((2048, 64)); eye[:64] = np.eye(64)
+    got = host(H.matmul(dev(eye, dt), dev(bb.T.copy() if tB else bb, dt), transB=tB))
+    assert np.array_equal(got[:64], bb) and not got[64:].any()
+
+
 @pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])
 def test_matmul_in_workgroup_split_k_small_gemms(H, tA, tB):
     """fp32 products with few output tiles (the M^3 GEMMs of the Cholesky VJP: 512^3 at cfg 2, 8 x 512^3 at cfg 5)
