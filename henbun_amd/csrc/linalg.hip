@@ -685,22 +685,24 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
   const int ct = gw % nct;
   const int rstride = nw / nct;            // (the launcher makes nw a multiple of nct)
   const int col = 32 * ct + li, colc = col < N ? col : N - 1;
-  // ---- this tile's weights: bf[c][j] = op(B)[2G c + G h + j][col]
+  // ---- this tile's weights: bf[c][4 v + s] = op(B)[2G c + 8 v + 4 h + s][col].  The contraction index is interleaved
+  // between the half-waves at 16-byte granularity: the A fragments of lanes (li, 0) and (li, 1) are then ADJACENT 16-byte
+  // pieces of row li, and a load instruction touches 32 cache lines instead of 64
   float bf[KC][G];
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     if (TB) {
-      const float* bp = a.B + (long)colc * ldb + 2 * G * c + G * h;
+      const float* bp = a.B + (long)colc * ldb + 2 * G * c + 4 * h;
 #pragma unroll
       for (int v = 0; v < G / 4; ++v) {
-        const V4 q = *reinterpret_cast<const V4*>(bp + 4 * v);
+        const V4 q = *reinterpret_cast<const V4*>(bp + 8 * v);
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) bf[c][4 * v + s2] = col < N ? q[s2] : 0.f;
       }
     } else {
 #pragma unroll
       for (int j = 0; j < G; ++j) {
-        const float q = a.B[(long)(2 * G * c + G * h + j) * ldb + colc];
+        const float q = a.B[(long)(2 * G * c + 8 * (j >> 2) + 4 * h + (j & 3)) * ldb + colc];
         bf[c][j] = col < N ? q : 0.f;
       }
     }
@@ -709,11 +711,11 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
   auto load = [&](V4 (&f)[KC][G / 4], int rt) {
     const int rtc = rt < nrt ? rt : nrt - 1;
     const int row = 32 * rtc + li;
-    const float* ap = a.A + (long)(row < M ? row : M - 1) * lda + G * h;
+    const float* ap = a.A + (long)(row < M ? row : M - 1) * lda + 4 * h;
 #pragma unroll
     for (int c = 0; c < KC; ++c)
 #pragma unroll
-      for (int v = 0; v < G / 4; ++v) f[c][v] = *reinterpret_cast<const V4*>(ap + 2 * G * c + 4 * v);
+      for (int v = 0; v < G / 4; ++v) f[c][v] = *reinterpret_cast<const V4*>(ap + 2 * G * c + 8 * v);
   };
   auto compute = [&](const V4 (&f)[KC][G / 4], int rt) {
     if (rt >= nrt) return;
