@@ -53,6 +53,14 @@ struct SgpArgs {
   long n, M, d, P;
   T* part;      // [E, gridDim.y, 5, n] column partial sums (sum A^2, sum_m u_pm A_mj for p < 4) or nullptr
   long efast;   // > 0: the grid is (columns * E, rows, 1) with the expert index fastest (see sgp_block)
+  // finishing pass inside the third strip form (fin != 0; see sgp_A_strip2t_kernel): v = 1 - sum A^2, f = u A + sqrt|v| eps
+  int fin = 0, fin_diag = 0;
+  const T* fin_eps_in = nullptr;
+  uint64_t* fin_rng = nullptr;
+  long fin_lanes = 0;
+  T* fin_eps_out = nullptr;
+  T* fin_f = nullptr;
+  T* fin_v = nullptr;
 };
 
 // Expert <-> XCD affinity.  Workgroups are dealt to the 8 XCDs round-robin by linear id, i.e. by blockIdx.x.  With
@@ -1011,7 +1019,42 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
     sum += __shfl_xor(sum, 2);
     sum += __shfl_xor(sum, 4);
     const int q = pair >> 5, c = pair & 31;
-    if (g == 0 && col0 + c < n && (q == 0 || means)) a.part[e * 5 * a.n + (long)q * n + col0 + c] = sum;
+    if (!a.fin) {
+      if (g == 0 && col0 + c < n && (q == 0 || means)) a.part[e * 5 * a.n + (long)q * n + col0 + c] = sum;
+      return;
+    }
+    // The finishing pass, here: one workgroup owns ALL rows of its 32 columns, so the totals just folded are final --
+    // v = 1 - sum A^2, f = u A + sqrt|v| eps for the strip (the residual noise drawn from the same per-pair RNG lanes
+    // and in the same pair order as the stand-alone pass, sgp_finish_part_kernel, whose launch -- 4.9 us of the cfg-2
+    // step for 64 KB of work -- disappears).  Same operations in the same order: same bits.
+    __syncthreads();                     // every thread is done reading the fold buffer
+    float* tot = lds_raw;                // [2][32]
+    if (g == 0) tot[q * 32 + c] = (q == 0 || means) ? sum : 0.f;
+    __syncthreads();
+    if (tid < 16) {
+      const long j0 = col0 + 2 * tid;    // (n is even: a pair is wholly inside or outside)
+      if (j0 < n) {
+        const long idx0 = e * (long)a.n + j0, pidx = idx0 >> 1;
+        float z0 = 0.f, z1 = 0.f;
+        if (a.fin_rng) {
+          HbRng gen = rng_load(a.fin_rng, a.fin_lanes, pidx);
+          gen.normal2(z0, z1);
+          rng_store(a.fin_rng, a.fin_lanes, pidx, gen);
+        } else if (a.fin_eps_in) {
+          z0 = a.fin_eps_in[idx0], z1 = a.fin_eps_in[idx0 + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float s2 = 0.f + tot[2 * tid + i];
+          const float vv = 1.f - s2;
+          const float zi = i ? z1 : z0;
+          a.fin_v[idx0 + i] = vv;
+          if (a.fin_eps_out && a.fin_eps_out != a.fin_eps_in) a.fin_eps_out[idx0 + i] = zi;
+          const float scale = a.fin_diag ? hb_sqrt(hb_abs(vv)) * zi : 0.f;
+          if (a.P > 0) a.fin_f[(e * a.P) * (long)a.n + j0 + i] = (0.f + tot[32 + 2 * tid + i]) + scale;
+        }
+      }
+    }
   }
 }
 
@@ -1433,8 +1476,23 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
                                           (sgp_strip_ok(E, n, M, d, W) && !hb_sgp_no_strip()));
     const int gyp = strip ? 1 : gy;  // partial rows of the column statistics
     int rc;
+    a.fin = 0;
     if (strip) {
+      // third strip form with one column mean: the finishing pass runs inside the contraction kernel
+      const bool nofuse = getenv("HB_SGP_NO_FUSED_FINISH") != nullptr || getenv("HB_SGP_STRIP_FORM2") != nullptr;   // (diagnostic)
+      if (!nofuse && a.Wf && !a.W3 && P <= 1 && n % 2 == 0 && (!draw || rng_lanes >= (E * n + 1) / 2)) {
+        a.fin = 1;
+        a.fin_diag = mode == HB_SGP_DIAGONAL;
+        a.fin_eps_in = mode == HB_SGP_DIAGONAL ? eps_in : (const T*)nullptr;
+        a.fin_rng = draw ? rng : (uint64_t*)nullptr;
+        a.fin_lanes = rng_lanes;
+        a.fin_eps_out = mode == HB_SGP_DIAGONAL ? eps_out : (T*)nullptr;
+        a.fin_f = f;
+        a.fin_v = v;
+      }
       rc = sgp_A_strip_launch(a, E, stream);
+      if (rc) return rc;
+      if (a.fin) return 0;
     } else {
       dim3 grid = sgp_grid(hb_cdiv(n, SGP_BN), gy, E, a.efast);
       rc = sgp_A_launch<T>(a, grid, stream);

@@ -10,6 +10,10 @@ cp $s/cfg2/kernel_stats.csv $p/r03_rocprofv3_kernel_stats_bench_cfg2.csv
 cp $s/cfg2/summary.txt $p/r03_rocprofv3_summary_bench_cfg2.txt
 cp $s/cfg4/kernel_stats.csv $p/r03_rocprofv3_kernel_stats_bench_cfg4.csv
 cp $s/cfg4/summary.txt $p/r03_rocprofv3_summary_bench_cfg4.txt
+cp $s/cfg5/kernel_stats.csv $p/r03_rocprofv3_kernel_stats_bench_cfg5.csv
+cp $s/cfg5/summary.txt $p/r03_rocprofv3_summary_bench_cfg5.txt
+cp $s/plan_cfg5.txt $p/r03_plan_cfg5.txt
+grep -v amdgpu.ids $s/bench_fwd_bwd.txt > $p/r03_contractions_fwd_bwd.txt
 cp $s/bw_rows.txt $p/r03_bw_rows.txt
 cp $s/plan_cfg2.txt $p/r03_plan_cfg2.txt
 cp $s/pmc_cfg2/pmc_kernels.txt $p/r03_pmc_cfg2_kernels.txt

@@ -12,6 +12,9 @@ for c in cfg3 cfg4 cfg5; do python bench.py --no-cpu-baseline --config $c --step
 python bench.py --no-cpu-baseline --config cfg5 --contraction bf16x3 --steps 50 --warmup 5 > $o/bench_cfg5_bf16x3.json 2>/dev/null
 python bench.py --no-cpu-baseline --config cfg3 --tri-pack --steps 50 --warmup 5 > $o/bench_cfg3_tripack.json 2>/dev/null
 tools/prof_bench.sh r3final/cfg4 --config cfg4 --steps 100 --warmup 10 > /dev/null
+tools/prof_bench.sh r3final/cfg5 --config cfg5 --steps 20 --warmup 3 > /dev/null
+python tools/dump_plan.py cfg5 > $o/plan_cfg5.txt 2>/dev/null
+python tools/bench_fwd.py > $o/bench_fwd_bwd.txt 2>/dev/null
 python tools/bw_rows.py > $o/bw_rows.txt 2>/dev/null
 python tools/dump_plan.py cfg2 > $o/plan_cfg2.txt 2>/dev/null
 tools/pmc_traffic.sh r3final/pmc_cfg2 > /dev/null 2>&1
