@@ -96,8 +96,31 @@ class Communicator:
             if dist.is_available() and dist.is_initialized() and ws > 1:
                 dist.broadcast_object_list(token, src=0)
             handle = ctypes.c_void_p(None)
-            lib.call("hb_comm_init", ctypes.create_string_buffer(token[0], 128), rank, ws, ctypes.byref(handle))
-            comm = cls(handle, rank, ws)
+            good = True
+            try:
+                lib.call("hb_comm_init", ctypes.create_string_buffer(token[0], 128), rank, ws, ctypes.byref(handle))
+                comm = cls(handle, rank, ws)
+                if ws > 1:
+                    # first use, checked: (rank + 1) summed over the ranks must be R (R + 1) / 2 everywhere -- a
+                    # communicator that cannot do this is dropped on EVERY rank and the step keeps torch.distributed's
+                    # all_reduce (the "torch-eager" exchange), instead of training on garbage
+                    import torch
+
+                    from . import hip_ops
+
+                    x = torch.full((256,), float(rank + 1), dtype=torch.float32, device=device)
+                    torch.cuda.synchronize(device)
+                    hip_ops.allreduce_sum(x, handle)
+                    torch.cuda.synchronize(device)
+                    good = bool((x == float(ws * (ws + 1) // 2)).all().item())
+            except Exception:
+                good = False
+            if dist.is_available() and dist.is_initialized() and ws > 1:
+                votes = [None] * ws
+                dist.all_gather_object(votes, bool(good))
+                good = all(votes)
+            if not good:
+                comm = None
         cls._cached[key] = comm
         return comm
 
