@@ -2360,6 +2360,120 @@ __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restr
   HB_LSTAMP(2);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Lbar for MANY blocks (experts x long minibatches; round 3): a 128 x 128 block per workgroup, operand tiles through LDS.
+//
+// With a 64 x 64 block per wave (kernel above) every wave fetches its own two Kbar and two A tiles of each strip: 16
+// flop per byte out of L2.  At cfg-5 size the units of a slab no longer run side by side, 76 % of those fetches miss
+// the L2 and the launch runs at the memory system's rate -- 7.4 GB fetched for 2.1 GB of operands, 4.5 TB/s, 1.64 ms
+// (profiles/r03_pmc_cfg5_contractions.txt).  Here the four waves of a workgroup own the four 64 x 64 quarters of ONE
+// 128 x 128 block and share its eight operand tiles of a strip (4 of Kbar, 4 of A: 32 KB), staged once per workgroup in
+// LDS -- double-buffered, one barrier per strip, fragment-major tiles copied as they are (contiguous kilobytes in,
+// conflict-free 16-byte LDS accesses both ways): half the bytes per flop.  Every unit (expert, slab, block) is resident
+// at once (two workgroups per CU), each wave writes its partial quarter itself; sgp_bwd_finish_kernel folds the slabs
+// as before.  fp32 operands only.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) sgp_lbar_lds_kernel(const float* __restrict__ Kf, const float* __restrict__ Af,
+                                                              float* __restrict__ slabs, int M, int nS, int S, long E,
+                                                              int pairs) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef Mma<float> MM;
+  __shared__ __attribute__((aligned(16))) float buf[2][8][1024];   // [stage][4 Kbar tiles, 4 A tiles][fragment-major tile]
+  const int nT = M / 32;
+  // XCD-aware unit order as in sgp_lbar_frag_kernel: XCD x takes a contiguous range of (expert, slab)-major units
+  const int U = gridDim.x, xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+  const int uq = U >> 3, ur = U & 7;
+  const int unit = xcd * uq + (xcd < ur ? xcd : ur) + kx;
+  const int group = unit / pairs, pair = unit - group * pairs;
+  const int slab = group % S;
+  const long e = group / S;
+  int bi = (int)((sqrtf(8.f * (float)pair + 1.f) - 1.f) * 0.5f);
+  while (bi * (bi + 1) / 2 > pair) --bi;
+  while ((bi + 1) * (bi + 2) / 2 <= pair) ++bi;
+  const int bj = pair - bi * (bi + 1) / 2;            // block (bi, bj), bj <= bi, 128 rows / columns each
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+  const int base = nS / S, rem = nS % S;
+  const int s0 = slab * base + (slab < rem ? slab : rem), s1 = s0 + base + (slab < rem ? 1 : 0);
+  const long tstride = (long)nS << 10;
+  const float* __restrict__ kbase = Kf + (long)e * nT * tstride;
+  const float* __restrict__ abase = Af + (long)e * nT * tstride;
+  // staging: V4 index q = i * 256 + tid covers the eight tiles (q >> 8 = tile, q & 255 = 16-byte group inside it)
+  const float* gsrc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int t = i < 4 ? 4 * bi + i : 4 * bj + (i - 4);
+    const int tc = t < nT ? t : nT - 1;                // (tiles past the matrix: a valid tile, never used)
+    gsrc[i] = (i < 4 ? kbase : abase) + tc * tstride + 4 * tid;
+  }
+  // this wave's quarter: row tiles ti0, ti1 = 4 bi + 2 wr (+1), column tiles tj0, tj1 = 4 bj + 2 wc (+1)
+  const int ti0 = 4 * bi + 2 * wr, tj0 = 4 * bj + 2 * wc;
+  bool live[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ti = ti0 + (q >> 1), tj = tj0 + (q & 1);
+    live[q] = ti < nT && tj < nT && tj <= ti;           // (tiles wholly above the diagonal are skipped)
+  }
+  const bool any_live = live[0] || live[1] || live[2] || live[3];
+  typename MM::Acc acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  V4 st[8];
+  auto gload = [&](int sidx) {
+    const long off = (long)sidx << 10;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = *reinterpret_cast<const V4*>(gsrc[i] + off);
+  };
+  auto lstore = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<V4*>(&buf[stage][i][4 * tid]) = st[i];
+  };
+  auto compute = [&](int stage) {
+    if (!any_live) return;   // (uniform per wave)
+    const float* k0 = &buf[stage][2 * wr][4 * lane];
+    const float* k1 = &buf[stage][2 * wr + 1][4 * lane];
+    const float* a0 = &buf[stage][4 + 2 * wc][4 * lane];
+    const float* a1 = &buf[stage][4 + 2 * wc + 1][4 * lane];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const V4 fk0 = *reinterpret_cast<const V4*>(k0 + 256 * v), fk1 = *reinterpret_cast<const V4*>(k1 + 256 * v);
+      const V4 fa0 = *reinterpret_cast<const V4*>(a0 + 256 * v), fa1 = *reinterpret_cast<const V4*>(a1 + 256 * v);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        if (live[0]) acc[0] = MM::mma(fk0[s2], fa0[s2], acc[0]);
+        if (live[1]) acc[1] = MM::mma(fk0[s2], fa1[s2], acc[1]);
+        if (live[2]) acc[2] = MM::mma(fk1[s2], fa0[s2], acc[2]);
+        if (live[3]) acc[3] = MM::mma(fk1[s2], fa1[s2], acc[3]);
+      }
+    }
+  };
+  if (s1 > s0) {
+    gload(s0);
+    lstore(0);
+    __syncthreads();
+#pragma nounroll
+    for (int sidx = s0; sidx < s1; ++sidx) {
+      const int stage = (sidx - s0) & 1;
+      const bool more = sidx + 1 < s1;
+      if (more) gload(sidx + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(stage);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) lstore(stage ^ 1);
+      __syncthreads();
+    }
+  }
+  float* out = slabs + (((long)slab * E + e) * M) * M;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (!live[q]) continue;
+    const int ti = ti0 + (q >> 1), tj = tj0 + (q & 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(long)(32 * ti + MM::acc_row(lane, r)) * M + 32 * tj + (lane & 31)] = acc[q][r];
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void sgp_lbar_finish_body(const T* __restrict__ slabs, int S, long E, long M, T* __restrict__ Lbar,
                                                      long vblock, long nvblocks) {
@@ -2749,6 +2863,23 @@ static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, 
   {
     static const char* fs = getenv("HB_LBAR_FORCE_S");  // diagnostic
     if (fs) S = atol(fs);
+  }
+  {
+    // many blocks (experts x a long minibatch): 128 x 128 blocks with LDS-staged operand tiles, every unit resident
+    static const char* nolds = getenv("HB_LBAR_NO_LDS");   // diagnostic
+    const long nB2 = (nT + 3) / 4, pairs2 = nB2 * (nB2 + 1) / 2;
+    if (prec != HB_PREC_BF16X3 && !nolds && pairs * E >= 256 && nS >= 64) {
+      long S2 = 512 / (pairs2 * E);
+      if (S2 > nS / 8) S2 = nS / 8;
+      if (S2 > slab_cap) S2 = slab_cap;
+      if (S2 >= 1) {
+        dim3 grid2((unsigned)(pairs2 * S2 * E), 1, 1);
+        hipLaunchKernelGGL(sgp_lbar_lds_kernel, grid2, dim3(256), 0, stream, Kf, Af, slabs, (int)M, (int)nS, (int)S2, E, (int)pairs2);
+        HB_LAUNCH_CHECK();
+        *S_out = (int)S2;
+        return 0;
+      }
+    }
   }
   dim3 grid((unsigned)(pairs * S * E), 1, 1);
   if (prec == HB_PREC_BF16X3)
