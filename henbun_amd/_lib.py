@@ -66,6 +66,7 @@ _TYPED = {
     "hb_ewise_jit_build": [I, P, P, I, P, P, I, P, P, P, I, P, P, P, P, P, L],
     "hb_ewise_colprog_build": [I, P, P, I, P, P, I, P, P, P, L, L, P, P, L],
     "hb_gauss_ll": [P, P, P, P, L, P, P, P, P, P, L, P],
+    "hb_gauss_ll_post": [P, P, P, P, L, P, P, P, P, D, P, P, L, P],
     "hb_reduce": [I, P, P, L, L, L, P, L, P],
     "hb_copy_nd": [P, P, P, P, I, P, P],
     "hb_fill": [P, L, D, P],

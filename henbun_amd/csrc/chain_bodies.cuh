@@ -156,11 +156,12 @@ __device__ __forceinline__ void hb_adam_body_vec(T* __restrict__ theta, const T*
 
 // ------------------------------------------------------------------------------------- Gaussian likelihood head (one WG)
 // sum_j log N(x_j | f_j * scale, var) with its gradients, n <= 16 * blockDim.x: every load of a thread is in flight before
-// the first use.  blockDim.x = 1024.
+// the first use.  blockDim.x = 1024.  fbar (nullable): also scale * (post * dmu_j), the gradient of post * ll w.r.t. f.
 template <typename T>
 __device__ __forceinline__ void hb_gauss_ll_single_body(const T* __restrict__ x, const T* __restrict__ f, const T* __restrict__ scale,
                                                         const T* __restrict__ var, long n, T* __restrict__ dmu, T* __restrict__ ll,
-                                                        T* __restrict__ dscale, T* __restrict__ dvar, T* smem) {
+                                                        T* __restrict__ dscale, T* __restrict__ dvar, T* smem,
+                                                        T* __restrict__ fbar = nullptr, T post = T(0)) {
   constexpr int PER = 16;
   const T s = scale ? scale[0] : T(1), v = var[0];
   const T iv = T(1) / v, lc = T(-0.91893853320467274178) - T(0.5) * hb_log(v);
@@ -180,6 +181,7 @@ __device__ __forceinline__ void hb_gauss_ll_single_body(const T* __restrict__ x,
     const T g = dlt * iv;
     if (j < n) {
       dmu[j] = g;
+      if (fbar) fbar[j] = s * (post * g);   // the gradient handed to the producer of f: scale * (upstream * dmu), same order as the graph's ops
       all += lc - T(0.5) * dlt * g;
       asc += g * fv[q];
       avr += T(-0.5) * iv + T(0.5) * g * g;

@@ -807,7 +807,8 @@ extern "C" int hb_gather_rows_multi_draw_f64(int narr, const double* const* srcs
 template <typename T>
 __global__ void __launch_bounds__(256) gauss_ll_kernel(const T* __restrict__ x, const T* __restrict__ f,
                                                        const T* __restrict__ scale, const T* __restrict__ var,
-                                                       long n, T* __restrict__ dmu, T* __restrict__ partial) {
+                                                       long n, T* __restrict__ dmu, T* __restrict__ partial,
+                                                       T* __restrict__ fbar, T post) {
   __shared__ T smem[16];
   const T s = scale ? scale[0] : T(1), v = var[0];
   const T iv = T(1) / v, lc = T(-0.91893853320467274178) - T(0.5) * hb_log(v);
@@ -822,6 +823,7 @@ __global__ void __launch_bounds__(256) gauss_ll_kernel(const T* __restrict__ x, 
     const T g = dlt * iv;
     if (j < n) {
       dmu[j] = g;
+      if (fbar) fbar[j] = s * (post * g);
       all += lc - T(0.5) * dlt * g;
       asc += g * fv;
       avr += T(-0.5) * iv + T(0.5) * g * g;
@@ -862,15 +864,16 @@ template <typename T>
 __global__ void __launch_bounds__(1024) gauss_ll_single_kernel(const T* __restrict__ x, const T* __restrict__ f,
                                                                const T* __restrict__ scale, const T* __restrict__ var,
                                                                long n, T* __restrict__ dmu, T* __restrict__ ll,
-                                                               T* __restrict__ dscale, T* __restrict__ dvar) {
+                                                               T* __restrict__ dscale, T* __restrict__ dvar,
+                                                               T* __restrict__ fbar, T post) {
   __shared__ T smem[16];
   static_assert(HB_GLL_SINGLE_N == 16 * 1024, "hb_gauss_ll_single_body: 16 elements per thread of a 1024-thread workgroup");
-  hb_gauss_ll_single_body<T>(x, f, scale, var, n, dmu, ll, dscale, dvar, smem);
+  hb_gauss_ll_single_body<T>(x, f, scale, var, n, dmu, ll, dscale, dvar, smem, fbar, post);
 }
 
 template <typename T>
 static int gauss_ll(const T* x, const T* f, const T* scale, const T* var, long n, T* ll, T* dmu, T* dscale, T* dvar,
-                    T* ws, long ws_elems, hipStream_t stream) {
+                    T* ws, long ws_elems, hipStream_t stream, double post = 0.0, T* fbar = nullptr) {
   HB_REQUIRE(n >= 0 && x && f && var && ll && dmu && dscale && dvar && ws, "hb_gauss_ll: bad arguments");
   const int nb = n > 0 ? hb_cdiv(n, HB_GLL_BLOCK_ELEMS) : 0;
   HB_REQUIRE(ws_elems >= 3L * (nb > 0 ? nb : 1), "hb_gauss_ll: workspace of 3*ceil(n/%d) elements required",
@@ -881,7 +884,9 @@ static int gauss_ll(const T* x, const T* f, const T* scale, const T* var, long n
       j.kind = HB_CHAIN_GLL;
       j.is64 = sizeof(T) == 8;
       j.p[0] = x, j.p[1] = f, j.p[2] = scale, j.p[3] = var, j.p[4] = dmu, j.p[5] = ll, j.p[6] = dscale, j.p[7] = dvar;
+      j.p[8] = fbar;
       j.l[0] = n;
+      j.d[0] = post;
       return hb_chain_push(j, stream);
     }
     const int crc = hb_chain_flush(stream);
@@ -889,12 +894,12 @@ static int gauss_ll(const T* x, const T* f, const T* scale, const T* var, long n
   }
   if (n > 0 && n <= HB_GLL_SINGLE_N) {
     hipLaunchKernelGGL(gauss_ll_single_kernel<T>, dim3(1), dim3(1024), 0, stream, x, f, scale, var, n, dmu, ll, dscale,
-                       dvar);
+                       dvar, fbar, (T)post);
     HB_LAUNCH_CHECK();
     return 0;
   }
   if (nb > 0) {
-    hipLaunchKernelGGL(gauss_ll_kernel<T>, dim3(nb), dim3(256), 0, stream, x, f, scale, var, n, dmu, ws);
+    hipLaunchKernelGGL(gauss_ll_kernel<T>, dim3(nb), dim3(256), 0, stream, x, f, scale, var, n, dmu, ws, fbar, (T)post);
     HB_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(gauss_ll_finish_kernel<T>, dim3(1), dim3(256), 0, stream, ws, nb, ll, dscale, dvar);
@@ -909,6 +914,18 @@ extern "C" int hb_gauss_ll_f64(const double* x, const double* f, const double* s
                                double* ll, double* dmu, double* dscale, double* dvar, double* ws, long ws_elems,
                                void* stream) {
   return gauss_ll<double>(x, f, scale, var, n, ll, dmu, dscale, dvar, ws, ws_elems, (hipStream_t)stream);
+}
+extern "C" int hb_gauss_ll_post_f32(const float* x, const float* f, const float* scale, const float* var, long n, float* ll,
+                                    float* dmu, float* dscale, float* dvar, double post, float* fbar, float* ws,
+                                    long ws_elems, void* stream) {
+  HB_REQUIRE(fbar, "hb_gauss_ll_post: fbar is NULL");
+  return gauss_ll<float>(x, f, scale, var, n, ll, dmu, dscale, dvar, ws, ws_elems, (hipStream_t)stream, post, fbar);
+}
+extern "C" int hb_gauss_ll_post_f64(const double* x, const double* f, const double* scale, const double* var, long n,
+                                    double* ll, double* dmu, double* dscale, double* dvar, double post, double* fbar,
+                                    double* ws, long ws_elems, void* stream) {
+  HB_REQUIRE(fbar, "hb_gauss_ll_post: fbar is NULL");
+  return gauss_ll<double>(x, f, scale, var, n, ll, dmu, dscale, dvar, ws, ws_elems, (hipStream_t)stream, post, fbar);
 }
 
 // ---------------------------------------------------------------------------

@@ -463,12 +463,53 @@ def _try_gauss_ll(x):
     return make("gauss_ll", ins, {}, [(1,), tuple(f.shape), (1,), (1,)]).outputs[0]
 
 
+def _gauss_ll_post(node, consumers, outputs):
+    """The elementwise tail TF autodiff appends to the likelihood head -- gmu = c * dmu (c: the constant upstream factor
+    of the likelihood term, N / n), then scale * gmu -- when nothing else reads those values: (c, the tensor that is
+    d objective / d f, [absorbed nodes]), else None.  The head then writes that gradient itself (hb_gauss_ll_post)."""
+    dmu = node.outputs[1]
+    if dmu in outputs:
+        return None
+    c1 = consumers.get(dmu, [])
+    if len(c1) != 1 or c1[0].op != "ew" or c1[0].attrs["f"] != "AFFINE" or len(c1[0].inputs) != 1:
+        return None
+    m1 = c1[0]
+    pp = list(m1.attrs["p"]) + [0.0, 0.0]
+    if pp[1] != 0.0:
+        return None
+    gmu = m1.outputs[0]
+    if len(node.inputs) <= 3:
+        return (float(pp[0]), gmu, [m1]) if gmu.shape == dmu.shape else None
+    if gmu in outputs:
+        return None
+    c2 = consumers.get(gmu, [])
+    if len(c2) != 1 or c2[0].op != "ew" or c2[0].attrs["f"] != "MUL" or len(c2[0].inputs) != 2:
+        return None
+    m2 = c2[0]
+    other = m2.inputs[0] if m2.inputs[1] is gmu else m2.inputs[1]
+
+    def root(t):
+        while t.node.op == "reshape":
+            t = t.node.inputs[0]
+        return t
+
+    if other.size != 1 or root(other) is not root(node.inputs[3]) or m2.outputs[0].size != dmu.size:
+        return None
+    return (float(pp[0]), m2.outputs[0], [m1, m2])
+
+
 def _gauss_ll_emit(plan, node):
     H = plan.H
     y, f, var = (plan.buf(t) for t in node.inputs[:3])
     scale = plan.buf(node.inputs[3]) if len(node.inputs) > 3 else None
     outs = tuple(plan.out(t) for t in node.outputs)
-    step = lambda: H.gauss_ll(y, f, scale, var, out=outs)
+    post = plan._gll_post.get(node.id)
+    if post is not None:
+        c, t_fbar, _ = post
+        fbar = plan.out(t_fbar)
+        step = lambda: H.gauss_ll(y, f, scale, var, out=outs, post=c, fbar=fbar)
+    else:
+        step = lambda: H.gauss_ll(y, f, scale, var, out=outs)
     plan.steps.append(step)
     plan.chain_kind[id(step)] = "full"     # hb_gauss_ll records itself into a serial chain (csrc/chain.cuh)
 
@@ -1802,7 +1843,7 @@ class _ColCluster:
         self.nodes, self.R, self.n, self.sealed, self.absorbed = [], R, n, False, {}
 
 
-def cluster_columns(order, outputs=(), enabled=True):
+def cluster_columns(order, outputs=(), enabled=True, skip=()):
     """Greedy clustering over a topological order, like cluster_elementwise, of the nodes a column program can hold:
     elementwise ops whose operands are [R, n], [1, n] or single elements, reductions over the row axis, reshapes /
     broadcasts between those forms, and row-block slices of a taller source (read in place).  Only clusters that contain
@@ -1857,7 +1898,7 @@ def cluster_columns(order, outputs=(), enabled=True):
 
     for nd in order:
         joined = None
-        if nd.op in ("ew", "reduce", "reshape", "bcast", "strided"):
+        if nd.id not in skip and nd.op in ("ew", "reduce", "reshape", "bcast", "strided"):
             cands = []
             for t in nd.inputs:
                 c = member.get(t.node.id)
@@ -1979,11 +2020,26 @@ class Plan:
         from ._settings import settings as _st
 
         fuse = bool(getattr(_st.runtime, "fuse_elementwise", True))
+        consumers0 = {}
+        for n in order:
+            for t in n.inputs:
+                consumers0.setdefault(t, []).append(n)
+        # the likelihood head writes d objective / d f itself when the two elementwise ops behind it feed nothing else
+        self._gll_post: Dict[int, tuple] = {}
+        self._absorbed = set()
+        if fuse:
+            outs_set = set(self.outputs)
+            for n in order:
+                if n.op == "gauss_ll":
+                    post = _gauss_ll_post(n, consumers0, outs_set)
+                    if post is not None and not any(m.id in self._absorbed for m in post[2]):
+                        self._gll_post[n.id] = post
+                        self._absorbed.update(m.id for m in post[2])
         # column programs first (short-and-wide spaces with row reductions inside: they need the compiled form), then
         # the plain elementwise clusters over what is left
-        self._colclusters = cluster_columns(order, outputs=self.outputs,
+        self._colclusters = cluster_columns(order, outputs=self.outputs, skip=self._absorbed,
                                             enabled=fuse and hip_ops.ewise_jit_enabled() and bool(getattr(_st.runtime, "column_programs", True)))
-        self._clusters = cluster_elementwise(order, enabled=fuse, skip=self._colclusters,
+        self._clusters = cluster_elementwise(order, enabled=fuse, skip=set(self._colclusters) | self._absorbed,
                                              max_elems=EW_CLUSTER_MAX_ELEMS_JIT if hip_ops.ewise_jit_enabled() else EW_CLUSTER_MAX_ELEMS)
         consumers = {}
         for n in order:
@@ -2046,6 +2102,9 @@ class Plan:
                     hoisted.add(n.id)
         for n in order:
             if n.id in hoisted:
+                continue
+            if n.id in self._absorbed:      # written by the likelihood head (hb_gauss_ll_post)
+                self._emitted.append(n)
                 continue
             cc = self._colclusters.get(n.id)
             if cc is not None:

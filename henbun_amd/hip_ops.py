@@ -288,8 +288,9 @@ class ColProgram:
                 pass
 
 
-def gauss_ll(x, f, scale, var, out=None):
-    """(ll[1], dmu[like x], dscale[1], dvar[1]) of sum_j log N(x_j | f_j*scale, var)  (hb_gauss_ll; scale may be None)."""
+def gauss_ll(x, f, scale, var, out=None, post=None, fbar=None):
+    """(ll[1], dmu[like x], dscale[1], dvar[1]) of sum_j log N(x_j | f_j*scale, var)  (hb_gauss_ll; scale may be None).
+    `post`, `fbar`: also fbar = scale * (post * dmu), the gradient of post * ll w.r.t. f (hb_gauss_ll_post)."""
     _chk(x), _chk(f), _chk(var)
     assert x.numel() == f.numel() and var.numel() == 1 and (scale is None or scale.numel() == 1)
     n = x.numel()
@@ -301,6 +302,12 @@ def gauss_ll(x, f, scale, var, out=None):
     else:
         ll, dmu, ds, dv = out
     ws = workspace(x.dtype, x.device, 3 * max((n + 1023) // 1024, 1))
+    if fbar is not None:
+        _chk(fbar)
+        assert fbar.numel() == n
+        _lib.lib().call("hb_gauss_ll_post" + _suf(x), _p(x), _p(f), _p(scale), _p(var), n, _p(ll), _p(dmu), _p(ds), _p(dv),
+                        float(post), _p(fbar), _p(ws), ws.numel(), stream())
+        return ll, dmu, ds, dv
     _lib.lib().call("hb_gauss_ll" + _suf(x), _p(x), _p(f), _p(scale), _p(var), n, _p(ll), _p(dmu), _p(ds), _p(dv), _p(ws),
                     ws.numel(), stream())
     return ll, dmu, ds, dv

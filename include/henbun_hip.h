@@ -92,6 +92,15 @@ int hb_gauss_ll_f32(const float* x, const float* f, const float* scale, const fl
 int hb_gauss_ll_f64(const double* x, const double* f, const double* scale, const double* var, long n,
                     double* ll, double* dmu, double* dscale, double* dvar, double* ws, long ws_elems,
                     void* stream);
+/* The same head with the gradient handed back to the producer of f written by the same launch:
+ * fbar_j = scale * (post * dmu_j) = d(post * ll) / d f_j (post: the constant upstream factor of the likelihood term, N / n
+ * in every notebook ELBO).  Replaces the two elementwise ops TF autodiff appends to the head (and their launch). */
+int hb_gauss_ll_post_f32(const float* x, const float* f, const float* scale, const float* var, long n, float* ll,
+                         float* dmu, float* dscale, float* dvar, double post, float* fbar, float* ws, long ws_elems,
+                         void* stream);
+int hb_gauss_ll_post_f64(const double* x, const double* f, const double* scale, const double* var, long n, double* ll,
+                         double* dmu, double* dscale, double* dvar, double post, double* fbar, double* ws, long ws_elems,
+                         void* stream);
 
 /* A whole cluster of elementwise ops in one launch: a register program interpreted per element
  * of the broadcast iteration space `shape[ndim]` (ndim <= 4).  Registers 0..nin-1 hold the inputs

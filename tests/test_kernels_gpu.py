@@ -1095,6 +1095,27 @@ def test_ewise_program_sum_outputs(H, p, n, mode):
 
 
 @pytest.mark.parametrize("p", ["f32", "f64"])
+@pytest.mark.parametrize("n", [300, 8192, 40000])
+def test_gauss_ll_head_writes_the_gradient_for_f_itself(H, p, n):
+    """hb_gauss_ll_post: the likelihood head (reference densities.py:25-27 under tf.reduce_sum + TF autodiff) also
+    leaves fbar = scale * (post * dmu) -- what the two elementwise ops behind it computed in a launch of their own --
+    in all three forms (one-workgroup head, partial sums + finish, with and without a scale); the other outputs keep
+    their bits."""
+    dt = DT[p]
+    rng = np.random.RandomState(n)
+    x, f = dev(rng.randn(1, n), dt), dev(rng.randn(1, n), dt)
+    var = dev(np.abs(rng.randn(1)) + 0.3, dt)
+    for scale in (dev(np.abs(rng.randn(1)) + 0.5, dt), None):
+        ref = H.gauss_ll(x, f, scale, var)
+        fbar = torch.full((1, n), float("nan"), dtype=dt, device="cuda")
+        got = H.gauss_ll(x, f, scale, var, post=122.07, fbar=fbar)
+        for a_, b_ in zip(ref, got):
+            assert torch.equal(a_, b_)
+        want = (1.0 if scale is None else scale.double()) * (122.07 * ref[1].double())
+        assert_close(fbar, want, dict(rtol=1e-12, atol=0) if p == "f64" else dict(rtol=3e-7, atol=0))
+
+
+@pytest.mark.parametrize("p", ["f32", "f64"])
 @pytest.mark.parametrize("R,n", [(4, 3001), (2, 64), (7, 777)])
 def test_column_program_softmax_gate(H, p, R, n):
     """hb_ewise_colprog_*: the softmax gate of the expert mixture (reference notebooks/Expert_GPR.ipynb:139-147) as ONE
