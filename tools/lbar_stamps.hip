@@ -17,6 +17,10 @@ __device__ int hb_lcu[1024];
 #include "../henbun_amd/csrc/gram.hip"
 #include "../henbun_amd/csrc/linalg.hip"
 #include "../henbun_amd/csrc/sgp.hip"
+// (the serial-chain recorder lives in csrc/jit.hip, which this diagnostic build leaves out: nothing is ever recording)
+bool hb_chain_recording() { return false; }
+int hb_chain_push(const HbChainJob&, hipStream_t) { return 0; }
+int hb_chain_flush(hipStream_t) { return 0; }
 #include <algorithm>
 #include <map>
 #include <stdio.h>
@@ -30,10 +34,11 @@ int main() {
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
   (void)hipMemcpy(Kf, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(Af, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  int S_used = 0;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) sgp_lbar_frag_launch(Kf, Af, slabs, Lbar, 1, M, nS, 0, 0);
+  for (int i = 0; i < 5; ++i) sgp_lbar_frag_launch(Kf, Af, slabs, 32, 1, M, nS, 0, &S_used, 0);
   (void)hipEventRecord(e0);
-  for (int i = 0; i < 50; ++i) sgp_lbar_frag_launch(Kf, Af, slabs, Lbar, 1, M, nS, 0, 0);
+  for (int i = 0; i < 50; ++i) sgp_lbar_frag_launch(Kf, Af, slabs, 32, 1, M, nS, 0, &S_used, 0);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   printf("lbar (kernel + finish): %.2f us per call\n", ms * 1e3 / 50);

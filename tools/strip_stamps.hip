@@ -15,6 +15,10 @@ __device__ long long hb_srt[256 * 2];
 #include "../henbun_amd/csrc/gram.hip"
 #include "../henbun_amd/csrc/linalg.hip"
 #include "../henbun_amd/csrc/sgp.hip"
+// (the serial-chain recorder lives in csrc/jit.hip, which this diagnostic build leaves out: nothing is ever recording)
+bool hb_chain_recording() { return false; }
+int hb_chain_push(const HbChainJob&, hipStream_t) { return 0; }
+int hb_chain_flush(hipStream_t) { return 0; }
 #include <algorithm>
 #include <stdio.h>
 #include <vector>
@@ -22,6 +26,7 @@ __device__ long long hb_srt[256 * 2];
 static float *g_u, *g_eps, *g_Af, *g_f, *g_v, *g_ws;
 #define RUN() hb_sgp_fwd_f32(0, 1, x, 0, z, ell, 1, W, Wf, 0, g_u, g_eps, nullptr, 0, nullptr, nullptr, g_Af, g_f, g_v, 1, n, M, 1, 1, g_ws, 0)
 int main() {
+  setenv("HB_SGP_STRIP_FORM2", "1", 1);   // the per-wave stamps sit in the second strip form (sgp_A_strip2_kernel)
   const int M = 512, n = 8192;
   float *K, *L, *W, *ws, *Wf, *z, *x, *A, *ell;
   int* info;
