@@ -268,6 +268,15 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
     auto slab_sum = [&](long at) -> T {
       T acc0 = T(0), acc1 = T(0), acc2 = T(0), acc3 = T(0);
       int s = 0;
+      // sixteen loads in flight per round while they last (64 slabs of a minibatch-deep weight gradient were sixteen
+      // dependent round trips at four per round: 7.5 us for 4 MB); the order of the additions stays fixed
+      for (; s + 16 <= a.S; s += 16) {
+        T v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = a.ws[(long)(s + q) * total + at];
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) acc0 += v[q], acc1 += v[q + 1], acc2 += v[q + 2], acc3 += v[q + 3];
+      }
       for (; s + 4 <= a.S; s += 4) {
         const T v0 = a.ws[(long)s * total + at], v1 = a.ws[(long)(s + 1) * total + at];
         const T v2 = a.ws[(long)(s + 2) * total + at], v3 = a.ws[(long)(s + 3) * total + at];
@@ -926,6 +935,12 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
   HB_REQUIRE(!(flags & HB_MM_SYMLOW_OUT) || (M == N && !bias && act == HB_ACT_NONE && beta == 0.0 && flags == HB_MM_SYMLOW_OUT),
              "hb_matmul: SYMLOW_OUT needs a square result and no other epilogue");
   if (!colsum && matmul_rows_ok<T>(a, transA, transB)) return matmul_rows_launch<T>(a, transB, stream);   // tall A, small op(B)
+  // (A^T B over a minibatch into a small result -- the weight gradients of cfg 4 -- stays on the tile engine below.  A
+  //  form with both operands read straight from global memory as MFMA fragments (64 x 64 block and one slab of rows per
+  //  workgroup, four waves taking the slab's 32-row chunks in turn) was built twice: with `in range ? v : 0` on every
+  //  loaded element the compiler issued a chunk's 96 loads two at a time with a full wait behind each pair (54 / 47 / 16 us
+  //  per product); with a select-free common path 19.5 / 13.9 / 17.3 us -- against 15.2 each for the tile engine.  Removed;
+  //  what it left behind is the split-K finish with sixteen slab loads in flight (7.5 -> 5.0 us).)
   const bool lower = (flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT | HB_MM_SYMLOW_OUT)) != 0;
   auto active_tiles = [&](int bt) -> long {
     const long tr = hb_cdiv(M, bt), tc = hb_cdiv(N, bt);

@@ -362,6 +362,28 @@ def test_matmul_row_streaming_form_for_tall_operands(H, tB):
     assert np.array_equal(got[:64], bb) and not got[64:].any()
 
 
+def test_matmul_minibatch_deep_weight_gradient_form(H):
+    """fp32 A^T B with a minibatch-deep contraction into a small result (the weight gradient x^T g of a MatBias layer,
+    reference nn.py:31-32 under TF autodiff; cfg 4: 32768 rows into 64 x 256, 256 x 32, 16 x 64): slabs of rows folded by
+    the split-K finish (sixteen slab loads in flight per round), with and without the column sums of B (the bias gradient)
+    riding along: ragged row counts, ragged and sub-tile result shapes, alpha."""
+    dt = torch.float32
+    rng = np.random.RandomState(21)
+    for k, m, n in ((32768, 64, 256), (8192, 256, 32), (4096, 16, 64), (5000, 40, 70), (4100, 7, 5), (6001, 33, 256)):
+        a, b = rng.randn(k, m), rng.randn(k, n)
+        full = a.T @ b
+        tol = dict(rtol=2e-5, atol=4e-6 * k ** 0.5 * 4)     # sums of k products of unit normals: sd sqrt(k); observed <= 1e-6 sqrt(k)
+        assert_close(H.matmul(dev(a, dt), dev(b, dt), transA=True, alpha=0.25), 0.25 * full, tol)
+        got, cs = H.matmul_colsum(dev(a, dt), dev(b, dt))
+        assert_close(got, full, tol)
+        assert_close(cs, b.sum(0), tol)
+    # an identity block in A picks rows of B exactly (row / column maps of both operand forms, slab boundaries)
+    k, m, n = 4096, 64, 96
+    a = np.zeros((k, m)); idx = rng.permutation(k)[:m]; a[idx, np.arange(m)] = 1.0
+    b = (np.arange(k * n, dtype=np.float64).reshape(k, n) % 1021) - 500
+    assert np.array_equal(host(H.matmul(dev(a, dt), dev(b, dt), transA=True)), b[idx])
+
+
 @pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False), (True, True)])
 def test_matmul_in_workgroup_split_k_small_gemms(H, tA, tB):
     """fp32 products with few output tiles (the M^3 GEMMs of the Cholesky VJP: 512^3 at cfg 2, 8 x 512^3 at cfg 5)
