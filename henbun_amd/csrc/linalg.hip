@@ -682,8 +682,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) matmul_rows_kernel(M
 // touches 64 different cache lines (the access pattern the fragment-major images remove for the sparse-GP operands);
 // a coalesced load + LDS transpose of the row tile is the form that remains to be built.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool TB, int G, int KC>
+// EPI: the epilogue, fixed at compile time -- 0 bias only, 1 bias + sigmoid, 2 bias + the activation in a.act (run-time
+// switch), 3 the sigmoid's gradient from the layer's output, 4 the gradient of the activation in a.act.  With the
+// activation switched per ELEMENT at run time the kernel was 13 000 lines of ISA in 2 500 basic blocks (tanhf inlined
+// sixteen times per epilogue copy).
+template <bool TB, int G, int KC, int EPI>
 __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
+
   typedef float V4 __attribute__((ext_vector_type(4)));
   typedef Mma<float> MM;
   const int M = (int)a.M, N = (int)a.N;
@@ -738,7 +743,7 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) acc = MM::mma(f[c][v][s2], bf[c][4 * v + s2], acc);
     const int r0 = 32 * rt;
-    if (a.flags & HB_MM_ACTGRAD) {
+    if (EPI >= 3) {
       const float* __restrict__ Y = a.bias;
       float y[16];
 #pragma unroll
@@ -749,13 +754,16 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = r0 + MM::acc_row(lane, r);
-        if (row < M && col < N) a.C[(long)row * ldc + col] = a.alpha * acc[r] * act_grad<float>(a.act, y[r]);
+        const float gy = EPI == 3 ? y[r] * (1.f - y[r]) : act_grad<float>(a.act, y[r]);
+        if (row < M && col < N) a.C[(long)row * ldc + col] = a.alpha * acc[r] * gy;
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = r0 + MM::acc_row(lane, r);
-        if (row < M && col < N) a.C[(long)row * ldc + col] = apply_act<float>(a.act, a.alpha * acc[r] + bias);
+        const float o = a.alpha * acc[r] + bias;
+        const float v = EPI == 0 ? o : (EPI == 1 ? hb_sigmoid(o) : apply_act<float>(a.act, o));
+        if (row < M && col < N) a.C[(long)row * ldc + col] = v;
       }
     }
   };
@@ -801,7 +809,22 @@ static int matmul_rowsreg_launch(const MmArgs<float>& a, int transB, int G, int 
   wgs = (wgs / unit) * unit;
   if (wgs < unit) wgs = unit;
   dim3 grid((unsigned)wgs, 1, 1);
-#define HB_RR2(TB_, G_, KC_) hipLaunchKernelGGL((matmul_rowsreg_kernel<TB_, G_, KC_>), grid, dim3(256), 0, stream, a)
+  const bool ag = (a.flags & HB_MM_ACTGRAD) != 0;
+  const int epi = ag ? (a.act == HB_ACT_SIGMOID ? 3 : 4) : (a.act == HB_ACT_NONE ? 0 : (a.act == HB_ACT_SIGMOID ? 1 : 2));
+#define HB_RR3(TB_, G_, KC_, E_) hipLaunchKernelGGL((matmul_rowsreg_kernel<TB_, G_, KC_, E_>), grid, dim3(256), 0, stream, a)
+#define HB_RR2(TB_, G_, KC_)     \
+  do {                           \
+    if (epi == 0)                \
+      HB_RR3(TB_, G_, KC_, 0);   \
+    else if (epi == 1)           \
+      HB_RR3(TB_, G_, KC_, 1);   \
+    else if (epi == 2)           \
+      HB_RR3(TB_, G_, KC_, 2);   \
+    else if (epi == 3)           \
+      HB_RR3(TB_, G_, KC_, 3);   \
+    else                         \
+      HB_RR3(TB_, G_, KC_, 4);   \
+  } while (0)
 #define HB_RR1(TB_)           \
   do {                        \
     if (G == 8)               \
@@ -819,6 +842,7 @@ static int matmul_rowsreg_launch(const MmArgs<float>& a, int transB, int G, int 
     HB_RR1(false);
 #undef HB_RR1
 #undef HB_RR2
+#undef HB_RR3
   HB_LAUNCH_CHECK();
   return 0;
 }
