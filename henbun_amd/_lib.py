@@ -35,6 +35,8 @@ _SIGS = {
     "hb_rng_randint": [P, L, P, L, L, L, P],
     "hb_sgp_ws_elems": [L, L, L, L, L],
     "hb_sgp_strip_path": [L, L, L, L, L, I],
+    "hb_sgp_head_units": [L, L, L, L, L, I, I, I, L],
+    "hb_sgp_fwd_gauss_f32": [I, I, P, L, P, P, L, P, P, I, P, P, P, L, P, P, P, P, P, L, L, L, L, L, P, P, P, P, D, P, P, P, L, P],
     "hb_ewise_prog_image_bytes": [],
     "hb_ewise_prog_build": [I, P, P, I, P, P, I, P, P, P, I, P, P, P, P],
     "hb_ewise_jit_available": [],
@@ -56,7 +58,8 @@ _SIGS = {
     "hb_comm_init": [P, I, I, P],
     "hb_comm_destroy": [P],
 }
-_RESTYPES = {"hb_last_error_string": c_char_p, "hb_sgp_ws_elems": c_long, "hb_ewise_prog_image_bytes": c_long}
+_RESTYPES = {"hb_last_error_string": c_char_p, "hb_sgp_ws_elems": c_long, "hb_ewise_prog_image_bytes": c_long,
+             "hb_sgp_head_units": c_long}
 
 # entry points that exist as _f32 and _f64
 _TYPED = {
@@ -67,6 +70,7 @@ _TYPED = {
     "hb_ewise_colprog_build": [I, P, P, I, P, P, I, P, P, P, L, L, P, P, L],
     "hb_gauss_ll": [P, P, P, P, L, P, P, P, P, P, L, P],
     "hb_gauss_ll_post": [P, P, P, P, L, P, P, P, P, D, P, P, L, P],
+    "hb_gauss_ll_fold": [P, L, P, P, P, P],
     "hb_reduce": [I, P, P, L, L, L, P, L, P],
     "hb_copy_nd": [P, P, P, P, I, P, P],
     "hb_fill": [P, L, D, P],

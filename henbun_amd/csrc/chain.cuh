@@ -15,7 +15,7 @@
 #include "common.cuh"
 #include "ew_prog.cuh"
 
-enum { HB_CHAIN_PROG = 1, HB_CHAIN_ADAM = 2, HB_CHAIN_GLL = 3, HB_CHAIN_SGP_FINISH = 4, HB_CHAIN_GRAM_ELL = 5 };
+enum { HB_CHAIN_PROG = 1, HB_CHAIN_ADAM = 2, HB_CHAIN_GLL = 3, HB_CHAIN_SGP_FINISH = 4, HB_CHAIN_GRAM_ELL = 5, HB_CHAIN_GLL_FOLD = 6 };
 #define HB_CHAIN_MAX_JOBS 6
 // A chain is ONE workgroup, and one CU streams ~10 bytes per cycle (24 GB/s): a job that moves more than a few tens
 // of KB costs more inside a chain than the ~4.5 us kernel boundary it saves (measured: the sparse-GP finishing pass at
@@ -25,6 +25,7 @@ enum { HB_CHAIN_PROG = 1, HB_CHAIN_ADAM = 2, HB_CHAIN_GLL = 3, HB_CHAIN_SGP_FINI
 #define HB_CHAIN_GLL_MAX_N 4096       // points of a likelihood head
 #define HB_CHAIN_ADAM_MAX_N 4096      // parameters of an Adam update
 #define HB_CHAIN_ELL_MAX_N 16384      // partials of a lengthscale fold
+#define HB_CHAIN_GLL_FOLD_MAX_N 4096  // units of a likelihood-head fold
 
 struct HbChainJob {
   int kind = 0, is64 = 0;

@@ -197,6 +197,38 @@ __device__ __forceinline__ void hb_gauss_ll_single_body(const T* __restrict__ x,
   }
 }
 
+// One point of the head (the operations of hb_gauss_ll_single_body's loop, for callers outside this file: contraction
+// is off HERE, so the forward strip kernel of csrc/sgp.hip gets the head's bits from it)
+template <typename T>
+__device__ __forceinline__ void hb_gauss_point(T xv, T fv, T s, T iv, T lc, T& g, T& all, T& asc, T& avr) {
+  const T dlt = xv - fv * s;
+  g = dlt * iv;
+  all += lc - T(0.5) * dlt * g;
+  asc += g * fv;
+  avr += T(-0.5) * iv + T(0.5) * g * g;
+}
+
+// Fold of the per-unit partial sums (ll, dscale, dvar) that a multi-workgroup head leaves as partial[3][nb] -- the
+// partial-sum kernel of hb_gauss_ll, or the forward strip kernel of hb_sgp_fwd_gauss, one unit per strip.  One workgroup.
+template <typename T>
+__device__ __forceinline__ void hb_gauss_fold_body(const T* __restrict__ partial, long nb, T* __restrict__ ll, T* __restrict__ dscale,
+                                                   T* __restrict__ dvar, T* smem) {
+  T a0 = T(0), a1 = T(0), a2 = T(0);
+  for (long i = threadIdx.x; i < nb; i += blockDim.x) {
+    a0 += partial[i];
+    a1 += partial[nb + i];
+    a2 += partial[2 * nb + i];
+  }
+  a0 = block_sum(a0, smem);
+  a1 = block_sum(a1, smem);
+  a2 = block_sum(a2, smem);
+  if (threadIdx.x == 0) {
+    ll[0] = a0;
+    dscale[0] = a1;
+    dvar[0] = a2;
+  }
+}
+
 // -------------------------------------------------------------------------------------------- sparse-GP finishing pass
 // f, v (and the residual noise) from the column partials of the forward contraction: v = 1 - sum A^2, f = u A + sqrt|v| eps.
 // The noise is drawn here (same per-lane streams and pair order as the stand-alone fill) or taken from eps_in.

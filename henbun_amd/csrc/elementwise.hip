@@ -915,6 +915,40 @@ extern "C" int hb_gauss_ll_f64(const double* x, const double* f, const double* s
                                void* stream) {
   return gauss_ll<double>(x, f, scale, var, n, ll, dmu, dscale, dvar, ws, ws_elems, (hipStream_t)stream);
 }
+// hb_gauss_ll_fold: partial[3][nb] -> ll, dscale, dvar (the second half of a head whose per-point part ran elsewhere:
+// hb_sgp_fwd_gauss).  Chain-aware: recorded into a serial chain when one is open.
+template <typename T>
+__global__ void __launch_bounds__(256) gauss_fold_kernel(const T* __restrict__ partial, long nb, T* __restrict__ ll,
+                                                         T* __restrict__ dscale, T* __restrict__ dvar) {
+  __shared__ T smem[16];
+  hb_gauss_fold_body<T>(partial, nb, ll, dscale, dvar, smem);
+}
+template <typename T>
+static int gauss_fold(const T* partial, long nb, T* ll, T* dscale, T* dvar, hipStream_t stream) {
+  HB_REQUIRE(partial && nb >= 1 && ll && dscale && dvar, "hb_gauss_ll_fold: bad arguments");
+  if (hb_chain_recording()) {
+    if (nb <= HB_CHAIN_GLL_FOLD_MAX_N) {
+      HbChainJob j;
+      j.kind = HB_CHAIN_GLL_FOLD;
+      j.is64 = sizeof(T) == 8;
+      j.p[0] = partial, j.p[1] = ll, j.p[2] = dscale, j.p[3] = dvar;
+      j.l[0] = nb;
+      return hb_chain_push(j, stream);
+    }
+    const int crc = hb_chain_flush(stream);
+    if (crc) return crc;
+  }
+  hipLaunchKernelGGL(gauss_fold_kernel<T>, dim3(1), dim3(256), 0, stream, partial, nb, ll, dscale, dvar);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_gauss_ll_fold_f32(const float* partial, long nb, float* ll, float* dscale, float* dvar, void* stream) {
+  return gauss_fold<float>(partial, nb, ll, dscale, dvar, (hipStream_t)stream);
+}
+extern "C" int hb_gauss_ll_fold_f64(const double* partial, long nb, double* ll, double* dscale, double* dvar, void* stream) {
+  return gauss_fold<double>(partial, nb, ll, dscale, dvar, (hipStream_t)stream);
+}
+
 extern "C" int hb_gauss_ll_post_f32(const float* x, const float* f, const float* scale, const float* var, long n, float* ll,
                                     float* dmu, float* dscale, float* dvar, double post, float* fbar, float* ws,
                                     long ws_elems, void* stream) {

@@ -61,6 +61,17 @@ struct SgpArgs {
   T* fin_eps_out = nullptr;
   T* fin_f = nullptr;
   T* fin_v = nullptr;
+  // ... and the per-point part of the Gaussian likelihood head behind it (head != 0; P == 1; hb_sgp_fwd_gauss):
+  // dmu_j = (y_j - f_j s) / var, fbar_j = s (post dmu_j), and this strip's partial sums of (ll, dscale, dvar)
+  int head = 0;
+  const T* hy = nullptr;
+  const T* hscale = nullptr;
+  const T* hvar = nullptr;
+  T* hdmu = nullptr;
+  T* hfbar = nullptr;
+  T hpost = T(0);
+  T* hpart = nullptr;      // [3][hunits], unit = e * nS + strip
+  long hunits = 0;
 };
 
 // Expert <-> XCD affinity.  Workgroups are dealt to the 8 XCDs round-robin by linear id, i.e. by blockIdx.x.  With
@@ -1031,6 +1042,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
     float* tot = lds_raw;                // [2][32]
     if (g == 0) tot[q * 32 + c] = (q == 0 || means) ? sum : 0.f;
     __syncthreads();
+    float h_ll = 0.f, h_sc = 0.f, h_vr = 0.f;
     if (tid < 16) {
       const long j0 = col0 + 2 * tid;    // (n is even: a pair is wholly inside or outside)
       if (j0 < n) {
@@ -1051,8 +1063,33 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
           a.fin_v[idx0 + i] = vv;
           if (a.fin_eps_out && a.fin_eps_out != a.fin_eps_in) a.fin_eps_out[idx0 + i] = zi;
           const float scale = a.fin_diag ? hb_sqrt(hb_abs(vv)) * zi : 0.f;
-          if (a.P > 0) a.fin_f[(e * a.P) * (long)a.n + j0 + i] = (0.f + tot[32 + 2 * tid + i]) + scale;
+          const float fj = (0.f + tot[32 + 2 * tid + i]) + scale;
+          if (a.P > 0) a.fin_f[(e * a.P) * (long)a.n + j0 + i] = fj;
+          if (a.head) {
+            // the likelihood head of this point (same operations as hb_gauss_ll's kernels)
+            const float hs = a.hscale ? a.hscale[0] : 1.f, hv = a.hvar[0];
+            const float iv = 1.f / hv, lc = -0.91893853320467274178f - 0.5f * hb_log(hv);
+            float gg;
+            hb_gauss_point<float>(a.hy[idx0 + i], fj, hs, iv, lc, gg, h_ll, h_sc, h_vr);
+            a.hdmu[idx0 + i] = gg;
+            if (a.hfbar) a.hfbar[idx0 + i] = hs * (a.hpost * gg);
+          }
         }
+      }
+    }
+    if (a.head && tid < 64) {
+      // the strip's partial sums: the sixteen pair threads sit in lanes 0..15 of wave 0 (fixed order)
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        h_ll += __shfl_xor(h_ll, off, 16);
+        h_sc += __shfl_xor(h_sc, off, 16);
+        h_vr += __shfl_xor(h_vr, off, 16);
+      }
+      if (tid == 0) {
+        const long unit = e * (long)((n + SGP_SN - 1) / SGP_SN) + bx;
+        a.hpart[unit] = h_ll;
+        a.hpart[a.hunits + unit] = h_sc;
+        a.hpart[2 * a.hunits + unit] = h_vr;
       }
     }
   }
@@ -1438,10 +1475,33 @@ static inline int sgp_grid_y(long E, long n, int nRB) {
   return (paired < 384 && nRB > 1) ? nRB : (nRB + 1) / 2;
 }
 
+// the likelihood head that may ride in the forward strip kernel (hb_sgp_fwd_gauss)
+template <typename T>
+struct SgpHead {
+  const T* y = nullptr;
+  const T* scale = nullptr;
+  const T* var = nullptr;
+  double post = 0.0;
+  T* dmu = nullptr;
+  T* fbar = nullptr;
+  T* part = nullptr;
+  long units = 0;
+};
+// can hb_sgp_fwd run its finishing pass (and a likelihood head) inside the third strip form for this call?
+static inline bool sgp_fused_finish_ok(long E, long n, long M, long d, long P, int prec, bool has_wfrag, bool draw, long rng_lanes) {
+  const bool nofuse = getenv("HB_SGP_NO_FUSED_FINISH") != nullptr || getenv("HB_SGP_STRIP_FORM2") != nullptr;   // (diagnostic)
+  return !nofuse && has_wfrag && prec == HB_PREC_NATIVE && hb_sgp_strip_path(E, n, M, d, P, prec) && P <= 1 && n % 2 == 0 &&
+         (!draw || rng_lanes >= (E * n + 1) / 2);
+}
+extern "C" long hb_sgp_head_units(long E, long n, long M, long d, long P, int prec, int has_wfrag, int draw, long rng_lanes) {
+  if (P != 1 || !sgp_fused_finish_ok(E, n, M, d, P, prec, has_wfrag != 0, draw != 0, rng_lanes)) return 0;
+  return E * hb_cdiv(n, SGP_SN);
+}
+
 template <typename T>
 static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T* ell, long dl, const T* W, const T* Wf,
                    int prec, const T* u, const T* eps_in, uint64_t* rng, long rng_lanes, T* eps_out, T* A, T* A_frag, T* f,
-                   T* v, long E, long n, long M, long d, long P, T* ws, hipStream_t stream) {
+                   T* v, long E, long n, long M, long d, long P, T* ws, hipStream_t stream, const SgpHead<T>* head = nullptr) {
   HB_REQUIRE(!A_frag || (sizeof(T) == 4 && Wf && ws && hb_sgp_strip_path(E, n, M, d, P, prec)),
              "hb_sgp_fwd: a fragment-major A needs the column-strip form (fp32, Wfrag, hb_sgp_strip_path)");
   if (hb_chain_recording()) {
@@ -1461,6 +1521,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
   if (E * n == 0) return 0;
   const bool draw = mode == HB_SGP_DIAGONAL && !eps_in;
   if (draw) HB_REQUIRE(rng && rng_lanes > 0 && eps_out, "hb_sgp_fwd: need eps_in, or rng and eps_out");
+  HB_REQUIRE(!head || (M > 0 && P == 1 && ws && Wf), "hb_sgp_fwd_gauss: needs Wfrag, a workspace and P == 1");
   const int nRB = hb_cdiv(M, SGP_BM);
   const int gy = sgp_grid_y(E, n, nRB);
   // fused path: the contraction kernel leaves per-column partial sums, one small kernel finishes f, v (and draws eps)
@@ -1479,8 +1540,7 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
     a.fin = 0;
     if (strip) {
       // third strip form with one column mean: the finishing pass runs inside the contraction kernel
-      const bool nofuse = getenv("HB_SGP_NO_FUSED_FINISH") != nullptr || getenv("HB_SGP_STRIP_FORM2") != nullptr;   // (diagnostic)
-      if (!nofuse && a.Wf && !a.W3 && P <= 1 && n % 2 == 0 && (!draw || rng_lanes >= (E * n + 1) / 2)) {
+      if (sizeof(T) == 4 && sgp_fused_finish_ok(E, n, M, d, P, prec, a.Wf != nullptr && !a.W3, draw, rng_lanes)) {
         a.fin = 1;
         a.fin_diag = mode == HB_SGP_DIAGONAL;
         a.fin_eps_in = mode == HB_SGP_DIAGONAL ? eps_in : (const T*)nullptr;
@@ -1489,7 +1549,15 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
         a.fin_eps_out = mode == HB_SGP_DIAGONAL ? eps_out : (T*)nullptr;
         a.fin_f = f;
         a.fin_v = v;
+        if (head) {
+          HB_REQUIRE(P == 1 && head->units == E * hb_cdiv(n, SGP_SN), "hb_sgp_fwd_gauss: units must be hb_sgp_head_units(...)");
+          a.head = 1;
+          a.hy = head->y, a.hscale = head->scale, a.hvar = head->var;
+          a.hdmu = head->dmu, a.hfbar = head->fbar, a.hpost = (T)head->post;
+          a.hpart = head->part, a.hunits = head->units;
+        }
       }
+      HB_REQUIRE(!head || a.fin, "hb_sgp_fwd_gauss: this call cannot carry the head (hb_sgp_head_units(...) == 0)");
       rc = sgp_A_strip_launch(a, E, stream);
       if (rc) return rc;
       if (a.fin) return 0;
@@ -1600,6 +1668,22 @@ extern "C" int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, cons
                               void* stream) {
   return sgp_fwd<double>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps_in, rng, rng_lanes, eps_out, A, A_frag, f,
                          v, E, n, M, d, P, ws, (hipStream_t)stream);
+}
+
+// hb_sgp_fwd with the per-point part of the Gaussian likelihood head behind it inside the same launch (the forward strip
+// kernel's finishing pass already holds f_j): only where hb_sgp_head_units(...) > 0.  The partial sums are folded by
+// hb_gauss_ll_fold -- typically as a job of the step's last serial chain.
+extern "C" int hb_sgp_fwd_gauss_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell, long dl,
+                                    const float* W, const float* Wfrag, int prec, const float* u, const float* eps_in,
+                                    uint64_t* rng, long rng_lanes, float* eps_out, float* A, float* A_frag, float* f, float* v,
+                                    long E, long n, long M, long d, long P, float* ws, const float* y, const float* scale,
+                                    const float* var, double post, float* dmu, float* fbar, float* head_part, long units,
+                                    void* stream) {
+  HB_REQUIRE(y && var && dmu && head_part && units > 0, "hb_sgp_fwd_gauss: NULL pointer");
+  SgpHead<float> h;
+  h.y = y, h.scale = scale, h.var = var, h.post = post, h.dmu = dmu, h.fbar = fbar, h.part = head_part, h.units = units;
+  return sgp_fwd<float>(kind, mode, x, sx, z, ell, dl, W, Wfrag, prec, u, eps_in, rng, rng_lanes, eps_out, A, A_frag, f, v,
+                        E, n, M, d, P, ws, (hipStream_t)stream, &h);
 }
 
 // ---------------------------------------------------------------------------

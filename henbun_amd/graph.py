@@ -500,6 +500,16 @@ def _gauss_ll_post(node, consumers, outputs):
 
 def _gauss_ll_emit(plan, node):
     H = plan.H
+    fusedh = plan._gll_fused.get(node.id)
+    if fusedh is not None:
+        # the per-point part ran inside the forward strip kernel (hb_sgp_fwd_gauss, see _sgp_emit): what is left is the
+        # fold of its partial sums, emitted right in front of the first reader of (ll, dscale, dvar)
+        part, units = fusedh
+        ll, _, ds, dv = (plan.out(t) for t in node.outputs)
+        step = lambda: H.gauss_ll_fold(part, units, ll, ds, dv)
+        plan.chain_kind[id(step)] = "full"
+        plan._pending.append((step, "gauss_ll_fold", node, {node.outputs[0], node.outputs[2], node.outputs[3]}))
+        return
     y, f, var = (plan.buf(t) for t in node.inputs[:3])
     scale = plan.buf(node.inputs[3]) if len(node.inputs) > 3 else None
     outs = tuple(plan.out(t) for t in node.outputs)
@@ -1514,8 +1524,27 @@ def _sgp_emit(plan, node):
         a_frag = plan.scratch((H.sgp_frag_elems(E, n, M, prec),))
         plan._afrag[node.outputs[1]] = (a_frag, prec)
         skip_a = node.outputs[1] not in plan.outputs
+    head = None
+    g = plan._sgp_head.get(node.id)
+    if g is not None and wfrag is not None:
+        units = H.sgp_head_units(x, z, u, prec, True, eps_in is None and mode == 1, rng)
+        if units > 0:
+            post = plan._gll_post.get(g.id)
+            def early(t):
+                # (an operand may be a view whose reshape node sits later in the emission order: take it from its source)
+                shp = t.shape
+                while t.node.op == "reshape" and t not in plan._buf:
+                    t = t.node.inputs[0]
+                return plan.buf(t).view(shp)
+
+            head = dict(y=early(g.inputs[0]), var=early(g.inputs[2]),
+                        scale=early(g.inputs[3]) if len(g.inputs) > 3 else None,
+                        dmu=plan.out(g.outputs[1]), post=post[0] if post else 0.0,
+                        fbar=plan.out(post[1]) if post else None,
+                        part=plan.scratch((3 * units,)), units=units)
+            plan._gll_fused[g.id] = (head["part"], units)
     step = lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag,
-                             prec=prec, a_frag=a_frag, skip_a=skip_a)
+                             prec=prec, a_frag=a_frag, skip_a=skip_a, head=head)
     plan.steps.append(step)
     plan.chain_kind[id(step)] = "tail"       # its finishing pass may open a serial chain
 
@@ -2046,6 +2075,42 @@ class Plan:
             for t in n.inputs:
                 consumers.setdefault(t, []).append(n)
         self._consumers = consumers
+        # The likelihood head riding in the forward contraction (hb_sgp_fwd_gauss): a gauss_ll whose f is the single latent
+        # function of an sgp draw, and whose other operands exist before that draw is launched.  The head's per-point part
+        # then runs in the strip kernel's finishing pass; its three sums are folded by a small step that is emitted right in
+        # front of their first reader (the step's last serial chain).
+        self._sgp_head: Dict[int, Node] = {}      # sgp node id -> gauss_ll node
+        self._gll_in_sgp: Dict[int, Node] = {}    # gauss_ll node id -> sgp node
+        self._gll_fused: Dict[int, tuple] = {}    # gauss_ll node id -> (partials buffer, units): set by _sgp_emit
+        self._pending: List[tuple] = []           # (step, label, node, tensors it writes): emitted before their first reader
+        if fuse and bool(getattr(_st.runtime, "head_in_contraction", True)):
+            hoist_mb = self.side_jobs_enabled()
+
+            def emitted_before(t, pos):
+                while t.node.op == "reshape":      # a view: what matters is where its source comes from
+                    t = t.node.inputs[0]
+                nd = t.node
+                if nd.op == "leaf:minibatch" and hoist_mb:
+                    return True                    # minibatch gathers are emitted first (see below)
+                cl = self._clusters.get(nd.id) or self._colclusters.get(nd.id)
+                last = cl.nodes[-1] if (cl is not None and len(cl.nodes) >= 2) else nd
+                return self._order_pos[last.id] < pos
+            for n in order:
+                if n.op != "gauss_ll" or len(n.inputs[1].shape) == 0:
+                    continue
+                ft = n.inputs[1]
+                while ft.node.op == "reshape":
+                    ft = ft.node.inputs[0]
+                sg = ft.node
+                if sg.op != "sgp" or ft is not sg.outputs[0] or sg.id in self._sgp_head or sg.inputs[5].shape[-2] != 1:
+                    continue
+                if n.inputs[0].size != ft.size:
+                    continue
+                pos = self._order_pos[sg.id]
+                others = [n.inputs[0], n.inputs[2]] + list(n.inputs[3:4])
+                if all(emitted_before(t, pos) for t in others):
+                    self._sgp_head[sg.id] = n
+                    self._gll_in_sgp[n.id] = sg
         # Concatenation in place: the parts of a concat along its leading non-unit axis are contiguous blocks of the
         # result, so a part that a fused program (or a single elementwise launch) produces is WRITTEN there -- the
         # gradient of a batched GP draw whose expert / gate halves come out of one column program needs no
@@ -2108,15 +2173,20 @@ class Plan:
                 continue
             cc = self._colclusters.get(n.id)
             if cc is not None:
-                if n is cc.nodes[-1] and self._emit_colcluster(cc):
-                    self._emitted.extend(cc.nodes)
+                if n is cc.nodes[-1]:
+                    self._flush_pending([t for m in cc.nodes for t in m.inputs])
+                    if self._emit_colcluster(cc):
+                        self._emitted.extend(cc.nodes)
                 continue
             c = self._clusters.get(n.id)
             if c is None or len(c.nodes) < 2:
+                self._flush_pending(n.inputs)
                 self._emit(n)
             elif n is c.nodes[-1]:
+                self._flush_pending([t for m in c.nodes for t in m.inputs])
                 self._emit_cluster(c)
                 self._emitted.extend(c.nodes)
+        self._flush_pending(None)
         # outputs that could not be bound in place: explicit copy
         for t, b in list(self._bind.items()) + self._extra_copies:
             got = self._buf.get(t)
@@ -2135,6 +2205,20 @@ class Plan:
             self._extra_copies.append((t, b))  # same tensor feeds two destinations
         else:
             self._bind[t] = b
+
+    def _flush_pending(self, reads):
+        """Append the deferred steps whose results `reads` (a list of tensors; None = all of them) needs."""
+        if not self._pending:
+            return
+        keep = []
+        for step, label, node, writes in self._pending:
+            if reads is None or any(t in writes for t in reads):
+                self.steps.append(step)
+                self.step_labels[id(step)] = label
+                self.step_nodes[id(step)] = node
+            else:
+                keep.append((step, label, node, writes))
+        self._pending = keep
 
     def _place_target(self, t):
         """The tensor whose buffer a concat part really is: looks through reshapes (views) down to a value that a fused

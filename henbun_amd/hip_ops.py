@@ -781,9 +781,25 @@ def sgp_frag_elems(E, n, M, prec=PREC_NATIVE):
     return base * 3 // 2 if prec == PREC_BF16X3 else base
 
 
+def sgp_head_units(x, z, u, prec, has_wfrag, draw, rng):
+    """Number of partial-sum units hb_sgp_fwd_gauss leaves for this call (0: the likelihood head cannot ride in it)."""
+    E, n, M, d, P, _ = _sgp_dims(x, z, u)
+    if x.dtype != torch.float32:
+        return 0
+    return int(_lib.lib().raw("hb_sgp_head_units")(E, n, M, d, P, int(prec), int(bool(has_wfrag)), int(bool(draw)),
+                                                  rng.nlanes if rng is not None else 0))
+
+
+def gauss_ll_fold(part, nb, ll, ds, dv):
+    """(ll, dscale, dvar) from the partial sums part[3][nb] of a head whose per-point part ran elsewhere (hb_gauss_ll_fold)."""
+    _lib.lib().call("hb_gauss_ll_fold" + _suf(part), _p(part), int(nb), _p(ll), _p(ds), _p(dv), stream())
+
+
 def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None, wfrag=None, prec=PREC_NATIVE,
-            a_frag=None, skip_a=False):
-    """Returns (f[E?,P,n], A[E?,M,n], v[E?,n], eps[E?,n]).  `wfrag`: cholesky_inverse's fragment-major copies of W."""
+            a_frag=None, skip_a=False, head=None):
+    """Returns (f[E?,P,n], A[E?,M,n], v[E?,n], eps[E?,n]).  `wfrag`: cholesky_inverse's fragment-major copies of W.
+    `head`: dict(y, scale, var, post, dmu, fbar, part, units) -- the Gaussian likelihood head's per-point part in the same
+    launch (hb_sgp_fwd_gauss; units = sgp_head_units(...) > 0)."""
     for t in (x, z, ell, W, u):
         _chk(t)
     E, n, M, d, P, sx = _sgp_dims(x, z, u)
@@ -800,6 +816,12 @@ def sgp_fwd(x, z, ell, W, u, eps_in=None, rng=None, mode=SGP_DIAGONAL, out=None,
     rp, rl = _rng_args(rng)
     ws = workspace(dt, dev, int(_lib.lib().raw("hb_sgp_ws_elems")(E, n, M, d, P)))
     # a_frag: also (skip_a: only) leave A fragment-major for sgp_bwd (column-strip form, see the header)
+    if head is not None:
+        _lib.lib().call("hb_sgp_fwd_gauss_f32", KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(wfrag), int(prec), _p(u),
+                        _p(eps_in), rp, rl, _p(eps), None if (skip_a and a_frag is not None) else _p(A), _p(a_frag), _p(f), _p(v),
+                        E, n, M, d, P, _p(ws), _p(head["y"]), _p(head.get("scale")), _p(head["var"]), float(head.get("post") or 0.0),
+                        _p(head["dmu"]), _p(head.get("fbar")), _p(head["part"]), int(head["units"]), stream())
+        return f, A, v, eps
     _lib.lib().call("hb_sgp_fwd" + _suf(x), KERN_RBF, mode, _p(x), sx, _p(z), _p(ell), dl, _p(W), _p(wfrag), int(prec), _p(u), _p(eps_in),
                     rp, rl, _p(eps), None if (skip_a and a_frag is not None) else _p(A), _p(a_frag), _p(f), _p(v), E, n,
                     M, d, P, _p(ws), stream())

@@ -428,6 +428,21 @@ int hb_sgp_fwd_f64(int kind, int mode, const double* x, long sx, const double* z
                    const double* eps_in, uint64_t* rng, long rng_lanes, double* eps_out, double* A,
                    double* A_frag, double* f, double* v, long E, long n, long M, long d, long P,
                    double* ws, void* stream);
+/* The Gaussian likelihood head riding in the forward contraction (fp32, column-strip form, one latent function): where
+ * hb_sgp_head_units(...) > 0 the strip kernel that finishes f_j also computes the per-point part of
+ * hb_gauss_ll_post -- dmu_j, fbar_j = scale * (post * dmu_j) -- and leaves its strip's partial sums of
+ * (ll, dscale, dvar) in head_part[3][units]; hb_gauss_ll_fold_* folds them (chain-aware: a job of the step's last serial
+ * chain).  Replaces a launch of its own between the forward and the backward contraction (hb_gauss_ll: 5.6 us of the
+ * cfg-2 step).  y [E, n] like f; draw = 1 when eps is drawn from rng (eps_in == NULL, DIAGONAL). */
+long hb_sgp_head_units(long E, long n, long M, long d, long P, int prec, int has_wfrag, int draw, long rng_lanes);
+int hb_sgp_fwd_gauss_f32(int kind, int mode, const float* x, long sx, const float* z, const float* ell, long dl,
+                         const float* W, const float* Wfrag, int prec, const float* u, const float* eps_in,
+                         uint64_t* rng, long rng_lanes, float* eps_out, float* A, float* A_frag, float* f, float* v,
+                         long E, long n, long M, long d, long P, float* ws, const float* y, const float* scale,
+                         const float* var, double post, float* dmu, float* fbar, float* head_part, long units,
+                         void* stream);
+int hb_gauss_ll_fold_f32(const float* partial, long nb, float* ll, float* dscale, float* dvar, void* stream);
+int hb_gauss_ll_fold_f64(const double* partial, long nb, double* ll, double* dscale, double* dvar, void* stream);
 /* The contraction alone, A = W k(z,x) (posterior-prediction callers; isolated timing). */
 int hb_sgp_A_f32(int kind, const float* x, long sx, const float* z, const float* ell, long dl,
                  const float* W, const float* Wfrag, int prec, float* A, long E, long n, long M, long d,

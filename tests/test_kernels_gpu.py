@@ -1116,6 +1116,43 @@ def test_ewise_program_sum_outputs(H, p, n, mode):
     assert_close(outs[2], np.array([(prod + a).sum()]), tol)
 
 
+@pytest.mark.parametrize("M,n", [(512, 8192), (96, 1030), (64, 64)])
+def test_likelihood_head_inside_the_forward_contraction(H, M, n):
+    """hb_sgp_fwd_gauss + hb_gauss_ll_fold: the Gaussian likelihood head's per-point part (dmu, fbar) computed by the
+    forward strip kernel's finishing pass and its three sums folded from per-strip partials -- against hb_sgp_fwd
+    followed by hb_gauss_ll_post on the same noise: f, v, dmu and fbar keep their bits, the sums (taken in another fixed
+    order) agree to fp32 rounding; with injected and with drawn residual noise."""
+    dt = torch.float32
+    rng = np.random.RandomState(M + n)
+    z = np.sort(rng.uniform(0, M / 2.0, (M, 1)), axis=0)
+    x = rng.uniform(0, M / 2.0, (n, 1))
+    zz, xx, ell = dev(z, dt), dev(x, dt), dev(np.ones(1), dt)
+    K = H.gram_fwd(zz, zz, ell, diag_add=1e-3)
+    frag = torch.empty(2 * M * M, dtype=dt, device="cuda")
+    L, W, info = H.cholesky_inverse(K, frag=frag)
+    u = dev(rng.randn(1, M), dt)
+    y = dev(rng.randn(1, n), dt)
+    scale, var = dev(np.abs(rng.randn(1)) + 0.5, dt), dev(np.abs(rng.randn(1)) + 0.3, dt)
+    eps = dev(rng.randn(n), dt)
+    for eps_in, seed in ((eps, None), (None, 7)):
+        rngs = [None if seed is None else H.Rng(seed), None if seed is None else H.Rng(seed)]
+        units = H.sgp_head_units(xx, zz, u, H.PREC_NATIVE, True, eps_in is None, rngs[0])
+        assert units == (n + 31) // 32
+        f0, _, v0, e0 = H.sgp_fwd(xx, zz, ell, W, u, eps_in=eps_in, rng=rngs[0], wfrag=frag)
+        fb0 = torch.empty(1, n, dtype=dt, device="cuda")
+        ll0, dmu0, ds0, dv0 = H.gauss_ll(y, f0, scale, var, post=3.25, fbar=fb0)
+        dmu1, fb1 = torch.full((1, n), float("nan"), dtype=dt, device="cuda"), torch.full((1, n), float("nan"), dtype=dt, device="cuda")
+        part = torch.full((3 * units,), float("nan"), dtype=dt, device="cuda")
+        f1, _, v1, e1 = H.sgp_fwd(xx, zz, ell, W, u, eps_in=eps_in, rng=rngs[1], wfrag=frag,
+                                  head=dict(y=y, scale=scale, var=var, post=3.25, dmu=dmu1, fbar=fb1, part=part, units=units))
+        ll1, ds1, dv1 = (torch.empty(1, dtype=dt, device="cuda") for _ in range(3))
+        H.gauss_ll_fold(part, units, ll1, ds1, dv1)
+        for a_, b_ in ((f0, f1), (v0, v1), (e0, e1), (dmu0, dmu1), (fb0, fb1)):
+            assert torch.equal(a_.reshape(-1), b_.reshape(-1))
+        for a_, b_ in ((ll0, ll1), (ds0, ds1), (dv0, dv1)):
+            assert abs(float(a_) - float(b_)) <= 2e-6 * max(abs(float(a_)), float(n) ** 0.5), (float(a_), float(b_))   # observed <= 3e-7 relative
+
+
 @pytest.mark.parametrize("p", ["f32", "f64"])
 @pytest.mark.parametrize("n", [300, 8192, 40000])
 def test_gauss_ll_head_writes_the_gradient_for_f_itself(H, p, n):
