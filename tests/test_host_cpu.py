@@ -442,3 +442,20 @@ def test_column_program_source_compiles_for_gfx950_without_a_device():
     with pytest.raises(_lib.HipBackendError):
         lib.call("hb_ewise_colprog_build_f32", 1, bad, par, 1, (c_void_p * 1)(None), (c_long * 2)(1000, 1), 1,
                  (c_void_p * 1)(None), (c_int * 1)(3), (c_long * 2)(1000, 1), 4, 1000, None, src, 8192)
+
+
+def test_host_code_of_the_abi_is_clean_under_asan_and_ubsan():
+    """tools/host_sanitize/run.sh: a HOST-ONLY, ASan + UBSan instrumented build of csrc/*.hip and a C++ driver that walks
+    the ABI's host code -- program validators, the hiprtc source generators (elementwise, column programs, serial chains:
+    dry-run compiles), the side-job / chain recorders, ~20 argument-check failures -- without a GPU.  Every call either
+    succeeds on the host or returns an error with a message; no sanitizer report."""
+    import shutil
+    import subprocess
+
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["bash", os.path.join(root, "tools", "host_sanitize", "run.sh")], capture_output=True, text=True, timeout=600)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0 and "all checks passed" in out, out[-3000:]
+    assert "ERROR: AddressSanitizer" not in out and "runtime error:" not in out, out[-3000:]
