@@ -750,7 +750,8 @@ def test_fragment_major_copies_of_the_inverse(H):
 
 
 @pytest.mark.parametrize("E,M,n,d,P,mode", [(1, 512, 3000, 1, 1, "diagonal"), (2, 96, 257, 2, 3, "diagonal"),
-                                             (1, 64, 64, 3, 1, "neglected"), (3, 160, 1000, 1, 2, "diagonal")])
+                                             (1, 64, 64, 3, 1, "neglected"), (3, 160, 1000, 1, 2, "diagonal"),
+                                             (96, 96, 2048, 1, 1, "diagonal")])   # many blocks, ragged 128-row blocks: sgp_lbar_lds_kernel
 def test_sgp_backward_column_strip_form(H, E, M, n, d, P, mode):
     """hb_sgp_bwd with the fragment-major W^T (one column-strip kernel: Kbar + the row gradients zbar / ellbar / ubar
     folded as each 32 x 32 tile completes, no second pass over Kbar and A) against torch autograd in fp64 -- at fp32
