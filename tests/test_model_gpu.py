@@ -99,7 +99,7 @@ def test_svgp_fp32_tracks_fp64():
     # observed on MI355X (round 3): ELBO 6.3e-6; worst 32-entry tile of z 4.9e-3, lengthscales 8.0e-4, q_mu 6.9e-4,
     # q_sqrt 6.4e-4, k_var 8.6e-6, var 8.8e-6 (jitter 1e-5: cond(Kmm) ~ 1e5, fp32 unit roundoff 6e-8)
     observe("svgp_fp32_tracks_fp64/ELBO", abs(val - ref_val.item()) / abs(ref_val.item()), 5e-5)
-    bound = {"model.gp.z": 4e-2, "model.gp.kern.lengthscales": 8e-3, "model.u.q_mu": 6e-3, "model.u.q_sqrt": 6e-3}
+    bound = {"model.gp.z": 4e-2, "model.gp.kern.lengthscales": 6e-3, "model.u.q_mu": 6e-3, "model.u.q_sqrt": 6e-3}
     for mine, theirs in NAMES:
         # worst 32-entry tile of every leaf gradient (tests/parity.py), not max-norm over the whole leaf
         observe("svgp_fp32_tracks_fp64/" + mine, tile_err(grads[mine], ref[theirs].numpy()), bound.get(mine, 8e-5))
