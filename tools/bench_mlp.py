@@ -35,6 +35,11 @@ rows += [
     ("x    [n,64]x[64,256] no epilogue", lambda: H.matmul(Y, W1, out=out_h), 2 * n * 64 * 256, 4 * (n * 64 + n * 256)),
     ("x    [n,64]x[64,128]+b sigmoid", lambda: H.matmul(Y, W1[:, :128].contiguous(), bias=b1[:128].contiguous(), act="sigmoid", out=out_h[:, :128].contiguous()), 2 * n * 64 * 128, 4 * (n * 64 + n * 128)),
 ]
+rows += [
+    ("ref  fill [n,256]", lambda: H.fill(out_h, 0.5), 0, 4 * n * 256),
+    ("ref  sigmoid [n,256] -> [n,256]", lambda: H.ewise("SIGMOID", [h], out=out_h), 0, 8 * n * 256),
+    ("ref  copy [n,64] -> [n,64]", lambda: H.ewise("COPY", [Y], out=out_d), 0, 8 * n * 64),
+]
 sel = [int(a) for a in sys.argv[1:]]
 if sel:
     rows = [rows[i] for i in sel]
