@@ -743,7 +743,18 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) acc = MM::mma(f[c][v][s2], bf[c][4 * v + s2], acc);
     const int r0 = 32 * rt;
-    if (EPI >= 3) {
+    if (EPI >= 3 && r0 + 32 <= M && col < N) {
+      const float* __restrict__ yp = a.bias + (long)(r0 + 4 * h) * N + col;
+      float* __restrict__ cp = a.C + (long)(r0 + 4 * h) * ldc + col;
+      float y[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[r] = yp[((r & 3) + 8 * (r >> 2)) * N];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float gy = EPI == 3 ? y[r] * (1.f - y[r]) : act_grad<float>(a.act, y[r]);
+        cp[((r & 3) + 8 * (r >> 2)) * ldc] = a.alpha * acc[r] * gy;
+      }
+    } else if (EPI >= 3) {
       const float* __restrict__ Y = a.bias;
       float y[16];
 #pragma unroll
@@ -756,6 +767,15 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
         const int row = r0 + MM::acc_row(lane, r);
         const float gy = EPI == 3 ? y[r] * (1.f - y[r]) : act_grad<float>(a.act, y[r]);
         if (row < M && col < N) a.C[(long)row * ldc + col] = a.alpha * acc[r] * gy;
+      }
+    } else if (r0 + 32 <= M && col < N) {
+      // whole tile inside the result: one 64-bit address per tile, 32-bit row offsets, no per-element masks (the epilogue
+      // runs on the same pipe as the fp32 MFMAs and costs about as much as they do at K = 64: every instruction counts)
+      float* __restrict__ cp = a.C + (long)(r0 + 4 * h) * ldc + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float o = a.alpha * acc[r] + bias;
+        cp[((r & 3) + 8 * (r >> 2)) * ldc] = EPI == 0 ? o : (EPI == 1 ? hb_sigmoid(o) : apply_act<float>(a.act, o));
       }
     } else {
 #pragma unroll
