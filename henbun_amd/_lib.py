@@ -25,6 +25,9 @@ P, L, I, D, U64 = c_void_p, c_long, c_int, c_double, c_uint64
 # name -> argument ctypes (return type is int unless listed in _RESTYPES)
 _SIGS = {
     "hb_version": [],
+    "hb_debug_set": [c_char_p, L],
+    "hb_debug_clear": [],
+    "hb_cholesky_inverse_ws_elems": [L, L, I],
     "hb_last_error_string": [],
     "hb_device_info": [P, I, P],
     "hb_graph_begin_capture": [P],
@@ -59,7 +62,7 @@ _SIGS = {
     "hb_comm_destroy": [P],
 }
 _RESTYPES = {"hb_last_error_string": c_char_p, "hb_sgp_ws_elems": c_long, "hb_ewise_prog_image_bytes": c_long,
-             "hb_sgp_head_units": c_long}
+             "hb_sgp_head_units": c_long, "hb_cholesky_inverse_ws_elems": c_long}
 
 # entry points that exist as _f32 and _f64
 _TYPED = {
@@ -128,7 +131,7 @@ class _Lib:
         for base, args in _TYPED.items():
             for suf in ("_f32", "_f64"):
                 self._bind(base + suf, args, c_int)
-        if self.raw("hb_version")() != 1:
+        if self.raw("hb_version")() != 2:
             raise ImportError("henbun_amd: ABI version mismatch in " + path)
 
     def _bind(self, name, args, restype):

@@ -1,0 +1,407 @@
+// Cholesky (+ inverse) as ONE persistent launch (fp32, M % 64 == 0); round 4.
+//
+// The 8-launch right-looking chain (chol_rl64_kernel) spends half of every launch on things that exist only because
+// the factorisation is cut into launches: the kernel boundary, reloading the trailing matrix, storing it again
+// (profiles/r03_chol_panel_phase_stamps.txt: ~16 000 of ~33 000 cycles per launch), and its in-panel phase is a chain
+// paced by ONE wave (elimination of 8 columns, then four dependent MFMAs, ~1 750 cycles per 8 columns).  Here:
+//
+//   * Every workgroup OWNS its tiles for the whole factorisation.  Workgroup (j, s) holds, in registers, column
+//     block j (64 columns) of one 64-row block of the stacked matrix [A; I] (its "strip": an A row block i > j, or a
+//     row block i' <= j of the identity, whose elimination yields Y = L^-T) plus -- redundantly, like the factor
+//     workgroups of the chain -- the 64 x 64 diagonal block (j, j).  nb = M / 64 strips per column block, nb^2
+//     workgroups per matrix, 8 waves each: wave (r, q) holds 64 rows (r = 0 diagonal block, r = 1 strip) x 16
+//     columns (group q).  Nothing but finished panels ever travels.
+//   * A finished panel travels through an EXCHANGE buffer (the workspace: nb^2 blocks of 64 x 64 per matrix, exactly
+//     B M^2 elements) in the order its consumers' MFMA operand loads want it, 16 columns at a time: the strip wave
+//     that has finished column group q writes its 4 KB with write-through (sc1) stores, drains them (vmcnt(0)) and
+//     raises that chunk's flag word; a consumer wave polls the flag (relaxed agent-scope load, s_sleep) and then
+//     reads the chunk with sc1 loads -- the hand-off form of cdna_hip_programming.md Guideline 16 R1 with one storing
+//     wave per flag, no L2 write-back (buffer_wbl2) and no L1 invalidate anywhere.  Consumers of column block j + 1
+//     apply chunk q of panel j while chunk q + 1 is still being factored: when the last chunk lands, one rank-16
+//     update (16 MFMAs) separates it from the next in-panel phase.
+//   * The trailing update runs on v_mfma_f32_16x16x4_f32 with the matrix ROW on the lane (lane & 15): a wave's four
+//     16 x 16 accumulators become "lane = row, 16 columns in 16 registers" with eight v_permlane32_swap + eight
+//     v_permlane16_swap (a 4 x 4 block transpose over the lane groups), no LDS.
+//   * In-panel phase, row per lane: the owner of a column group eliminates its 16 columns with v_readlane (pivot and
+//     multipliers are rows of its own lanes) and publishes every finished column to LDS at once (64 values + the
+//     reciprocal pivot, then a monotonic counter; LDS executes a wave's instructions in order, so no wait sits
+//     between them); all other waves follow column by column -- L_ic from the published column (their own rows:
+//     per-lane read), the multipliers L[c2][c] of their 16 columns as uniform 16-byte reads, 16 FMAs -- on the other
+//     three SIMDs.  The chain is one readlane -> rsq -> mul -> readlane -> fma sequence per column plus one LDS round
+//     trip per change of owner, instead of elimination + MFMA update alternating in one wave.
+//   * Deadlock freedom does not depend on dispatch order or residency: a workgroup takes its identity from a ticket
+//     (atomic counter) in START order, identities are numbered column block by column block, and a workgroup waits
+//     only for workgroups of earlier column blocks -- i.e. only for tickets that have already started.  Every spin
+//     is bounded (s_memrealtime deadline): on expiry the launch sets a timeout word, every wait falls through, and
+//     info[] = -1.
+//   * State: flags, ticket, failure words live behind the exchange area in the caller's workspace.  They must be zero
+//     when the kernel starts; the LAST workgroup to finish (arrival counter) writes info[] and zeroes them again, so a
+//     workspace is zero-filled once by its owner and then reused call after call (graph replays included).
+#pragma once
+#include "common.cuh"
+#include "side_jobs.cuh"
+
+#define CP_NB 64       // panel width = rows per row block
+#define CP_G 16        // columns per wave
+#define CP_LD 68       // LDS stride of a published column (floats): 16-byte aligned rows, conflict-free transposed reads
+#define CP_HDR 4       // sync words: ticket, finished, timeout, reserved
+#define CP_FAILBIG 0x40000000u
+#define CP_TIMEOUT_TICKS 200000000ull   // s_memrealtime ticks (100 MHz): 2 s
+
+typedef float CpV4 __attribute__((ext_vector_type(4)));
+typedef unsigned CpU4 __attribute__((ext_vector_type(4)));
+
+struct CpArgs {
+  const float* A;
+  float* L;
+  float* W;          // nullptr: plain factorisation (no identity rows)
+  float* X;          // exchange area, B*M*M floats
+  unsigned* sync;    // CP_HDR + roundup4(B) + 4*B*nb*nb words, zero at entry, zero at exit
+  int* info;
+  int M, B, nb, total;   // total = number of workgroups of the factorisation (side-job blocks come after them)
+  unsigned long long* stamps;   // diagnostic builds only (HB_CP_STAMPS)
+};
+
+static inline long cp_sync_words(long B, long M) {
+  const long nb = M / CP_NB;
+  return CP_HDR + ((B + 3) / 4) * 4 + 4 * B * nb * nb;
+}
+static inline int cp_strips(int nb, int j, int inv) {
+  const int n = (nb - 1 - j) + (inv ? j + 1 : 0);
+  return n > 0 ? n : 1;
+}
+static inline long cp_total(long B, int nb, int inv) {
+  long t = 0;
+  for (int j = 0; j < nb; ++j) t += B * cp_strips(nb, j, inv);
+  return t;
+}
+
+#ifdef HB_CP_STAMPS
+#define CP_STAMP(slot)                                                                                   \
+  do {                                                                                                   \
+    if (a.stamps && lane == 0) a.stamps[((size_t)ticket * 8 + w) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define CP_STAMP(slot)
+#endif
+
+__device__ __forceinline__ void cp_swap32(float& a, float& b) {   // a = [a.lo32, b.lo32], b = [a.hi32, b.hi32]
+  unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+  a = __builtin_bit_cast(float, x);
+  b = __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ void cp_swap16(float& a, float& b) {   // rows of 16 lanes: a = [a0, b0, a2, b2], b = [a1, b1, a3, b3]
+  unsigned x = __builtin_bit_cast(unsigned, a), y = __builtin_bit_cast(unsigned, b);
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+  a = __builtin_bit_cast(float, x);
+  b = __builtin_bit_cast(float, y);
+}
+
+// bounded wait for a flag word of another workgroup (one storing wave per word; see the header)
+struct CpWait {
+  unsigned* tmo;               // the launch's timeout word
+  unsigned long long deadline;
+  bool dead;
+  __device__ __forceinline__ void wait(const unsigned* f) {
+    if (dead) return;
+    unsigned spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 127u) == 0u) {
+        if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+            __builtin_amdgcn_s_memrealtime() > deadline) {
+          __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dead = true;
+          return;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the payload loads below the poll
+  }
+};
+
+__global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJobs side) {
+  if ((int)blockIdx.x >= a.total) {
+    // small independent launches of the step ride here as extra workgroups (side_jobs.cuh); their bodies are written
+    // for 256-thread blocks: the upper half of this block leaves
+    if (threadIdx.x < 256) hb_side_run(side, (int)blockIdx.x - a.total);
+    return;
+  }
+  __shared__ __attribute__((aligned(16))) float colbuf[2][CP_NB][CP_LD];   // [diag | strip][column][row]
+  __shared__ __attribute__((aligned(16))) float pibuf[CP_NB];              // reciprocal pivots
+  __shared__ int done[2];                                                    // columns published by the diag / strip waves
+  __shared__ unsigned s_ticket, s_last;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = w >> 2;                                   // 0: diagonal block, 1: strip
+  const int q = r == 0 ? (w & 3) : ((w + 2) & 3);         // column group; the strip wave of group q sits on another SIMD
+  const int i16 = lane & 15, g4 = lane >> 4;              // MFMA 16x16x4 lane coordinates
+  const int M = a.M, nb = a.nb, inv = a.W != nullptr;
+
+  if (tid == 0) {
+    done[0] = 0, done[1] = 0;
+    s_ticket = __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const unsigned ticket = s_ticket;
+  // ticket -> (column block j, matrix b, strip s), column block major
+  int j = 0, b, s;
+  {
+    unsigned t = ticket;
+    for (;; ++j) {
+      const unsigned per = (unsigned)a.B * (unsigned)((nb - 1 - j) + (inv ? j + 1 : 0) > 0 ? (nb - 1 - j) + (inv ? j + 1 : 0) : 1);
+      if (t < per || j == nb - 1) break;
+      t -= per;
+    }
+    const int ns = (nb - 1 - j) + (inv ? j + 1 : 0) > 0 ? (nb - 1 - j) + (inv ? j + 1 : 0) : 1;
+    b = (int)(t / (unsigned)ns);
+    s = (int)(t % (unsigned)ns);
+  }
+  const int nA = nb - 1 - j;                 // A strips of this column block
+  const bool stripA = s < nA;
+  const bool stripY = !stripA && inv;
+  const int irow = stripA ? j + 1 + s : s - nA;   // row block of the strip (A row block, or identity row block)
+  const bool strip_live = stripA || stripY;
+  const bool ydiag = stripY && irow == j;    // rows of the identity that start in this column block
+
+  const size_t mm = (size_t)M * M;
+  const float* Ab = a.A + (size_t)b * mm;
+  float* Lb = a.L + (size_t)b * mm;
+  float* Wb = inv ? a.W + (size_t)b * mm : nullptr;
+  unsigned* fail = a.sync + CP_HDR + b;
+  unsigned* flags = a.sync + CP_HDR + ((a.B + 3) / 4) * 4 + (size_t)b * nb * nb * 4;   // [panel k][strip s'][chunk]
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc(a.X + (size_t)b * mm, 0, (int)(mm * sizeof(float)), 0x00020000);
+  CpWait wt = {a.sync + 2, __builtin_amdgcn_s_memrealtime() + CP_TIMEOUT_TICKS, false};
+  CP_STAMP(0);
+
+  // ---- accumulators: tile t = rows 16t .. 16t+15 of the wave's row block, columns 16q .. 16q+15;
+  // lane (i16, g4) register e = element (row 16t + i16, column 16q + 4 g4 + e)
+  CpV4 R[4];
+  {
+    const bool fromA = r == 0 || stripA;
+    const int rb = r == 0 ? j : irow;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (fromA && (r == 1 || t >= q)) {   // tiles of the diagonal block strictly above the diagonal are never read
+        R[t] = *reinterpret_cast<const CpV4*>(Ab + (size_t)(CP_NB * rb + 16 * t + i16) * M + CP_NB * j + CP_G * q + 4 * g4);
+      } else {
+        CpV4 z = {0.f, 0.f, 0.f, 0.f};
+        if (r == 1 && ydiag) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (16 * t + i16 == CP_G * q + 4 * g4 + e) z[e] = 1.f;
+        }
+        R[t] = z;
+      }
+    }
+  }
+
+  // ---- trailing updates by panels 0 .. j-1, 16 columns (one chunk) at a time
+  for (int k = 0; k < j; ++k) {
+    if (r == 1 && (!strip_live || ydiag || (stripY && k < irow))) continue;   // identity rows are zero left of their 1s
+    const int sB = j - (k + 1);                                       // producer of L(j, k) in column block k
+    const int sA = r == 0 ? sB : (stripA ? irow - (k + 1) : (nb - 1 - k) + irow);
+    const unsigned* fB = flags + ((size_t)k * nb + sB) * 4;
+    const unsigned* fA = flags + ((size_t)k * nb + sA) * 4;
+    const int offB = (k * nb + sB) * (CP_NB * CP_NB * 4), offA = (k * nb + sA) * (CP_NB * CP_NB * 4);   // bytes
+#pragma unroll 1
+    for (int c4 = 0; c4 < 4; ++c4) {
+      wt.wait(fB + c4);
+      if (r == 1) wt.wait(fA + c4);
+      // chunk layout [chunk][v = k-quad][row][4 floats]: lane (i16, g4) takes k-quad g4 of its rows
+      const int chunk = ((c4 * 4 + g4) * CP_NB) * 16;
+      const CpV4 av = __builtin_bit_cast(CpV4, __builtin_amdgcn_raw_buffer_load_b128(xr, offB + chunk + (CP_G * q + i16) * 16, 0, 16));
+      CpV4 bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (r == 1 || t >= q)
+          bv[t] = __builtin_bit_cast(CpV4, __builtin_amdgcn_raw_buffer_load_b128(xr, offA + chunk + (16 * t + i16) * 16, 0, 16));
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (r == 1 || t >= q) R[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[e], bv[t][e], R[t], 0, 0, 0);
+    }
+  }
+  CP_STAMP(1);
+
+  // ---- row per lane: a 4 x 4 block transpose over (lane group, tile); afterwards lane l holds row l of its row
+  // block, x[4 s + e] = column 16 q + 4 s + e
+  float x[16];
+  {
+    float T[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = R[t][e];
+        T[t][e] = v;
+      }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cp_swap32(T[0][e], T[2][e]);
+      cp_swap32(T[1][e], T[3][e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cp_swap16(T[0][e], T[1][e]);
+      cp_swap16(T[2][e], T[3][e]);
+    }
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[4 * sl + e] = T[sl][e];
+  }
+
+  // ---- in-panel phase
+  const int cq = CP_G * q;
+  if (r == 0 || strip_live) {
+    int seen0 = 0, seen1 = 0;
+    auto wait0 = [&](int c) {
+      while (seen0 <= c) {
+        seen0 = __hip_atomic_load(&done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (seen0 <= c) __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    };
+    auto wait1 = [&](int c) {
+      while (seen1 <= c) {
+        seen1 = __hip_atomic_load(&done[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (seen1 <= c) __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    };
+    // follow the columns of the groups to the left
+#pragma unroll 1
+    for (int c = 0; c < cq; ++c) {
+      if (r == 0) wait0(c); else wait1(c);
+      const float Lc = colbuf[r][c][lane];
+      CpV4 m[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) m[v] = *reinterpret_cast<const CpV4*>(&colbuf[0][c][cq + 4 * v]);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[4 * v + e] = __builtin_fmaf(-Lc, m[v][e], x[4 * v + e]);
+    }
+    CP_STAMP(2);
+    if (r == 0) {
+      // PIVOT wave of columns cq .. cq+15: the diagonal rows are lanes cq + p of this wave
+      __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+      for (int p = 0; p < CP_G; ++p) {
+        const int c = cq + p;
+        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[p]), c));
+        float lcc, pi;
+        pivot_sqrt(d, lcc, pi);
+        (void)lcc;
+        x[p] *= pi;
+        colbuf[0][c][lane] = x[p];
+        if (lane == 0) pibuf[c] = pi;
+        asm volatile("" ::: "memory");
+        // (LDS executes one wave's instructions in order: the counter store lands after the column)
+        if (lane == 0) __hip_atomic_store(&done[0], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int p2 = p + 1; p2 < CP_G; ++p2) {
+          const float mlt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[p]), cq + p2));
+          x[p2] = __builtin_fmaf(-x[p], mlt, x[p2]);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    } else {
+      // the strip's own group: scale by the published reciprocal pivot, publish, eliminate with the diagonal rows' entries
+#pragma unroll
+      for (int p = 0; p < CP_G; ++p) {
+        const int c = cq + p;
+        wait0(c);
+        const float pi = pibuf[c];
+        CpV4 m[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) m[v] = *reinterpret_cast<const CpV4*>(&colbuf[0][c][cq + 4 * v]);
+        x[p] *= pi;
+        colbuf[1][c][lane] = x[p];
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&done[1], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int p2 = p + 1; p2 < CP_G; ++p2) x[p2] = __builtin_fmaf(-x[p], m[p2 >> 2][p2 & 3], x[p2]);
+      }
+      // ---- hand the finished chunk to the later column blocks (write-through stores, drained, then its flag)
+      if (j < nb - 1) {
+        const int off = (j * nb + s) * (CP_NB * CP_NB * 4) + ((q * 4) * CP_NB + lane) * 16;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const CpV4 o = {x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(CpU4, o), xr, off + v * CP_NB * 16, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store(flags + ((size_t)j * nb + s) * 4 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  CP_STAMP(3);
+  __syncthreads();
+
+  // ---- results, from the published columns in LDS (colbuf[.][column][row])
+  if (stripA) {
+    // L(irow, j)
+    for (int idx = tid; idx < CP_NB * (CP_NB / 4); idx += 512) {
+      const int rr = idx >> 4, c4 = (idx & 15) * 4;
+      const CpV4 v = {colbuf[1][c4][rr], colbuf[1][c4 + 1][rr], colbuf[1][c4 + 2][rr], colbuf[1][c4 + 3][rr]};
+      *reinterpret_cast<CpV4*>(Lb + (size_t)(CP_NB * irow + rr) * M + CP_NB * j + c4) = v;
+    }
+  } else if (stripY) {
+    // W(j, irow) = Y(irow, j)^T: row c of the block is the published column c
+    for (int idx = tid; idx < CP_NB * (CP_NB / 4); idx += 512) {
+      const int c = idx >> 4, r4 = (idx & 15) * 4;
+      CpV4 v = *reinterpret_cast<const CpV4*>(&colbuf[1][c][r4]);
+      if (ydiag) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (r4 + e > c) v[e] = 0.f;
+      }
+      *reinterpret_cast<CpV4*>(Wb + (size_t)(CP_NB * j + c) * M + CP_NB * irow + r4) = v;
+    }
+  }
+  if (s == 0) {
+    // L(j, j), lower triangle; and the first failed pivot of this column block (a pivot <= 0 or NaN leaves a NaN on
+    // the diagonal at its own column, and only NaNs after it)
+    for (int idx = tid; idx < CP_NB * (CP_NB / 4); idx += 512) {
+      const int rr = idx >> 4, c4 = (idx & 15) * 4;
+      CpV4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = c4 + e <= rr ? colbuf[0][c4 + e][rr] : 0.f;
+      *reinterpret_cast<CpV4*>(Lb + (size_t)(CP_NB * j + rr) * M + CP_NB * j + c4) = v;
+    }
+    if (w == 0) {
+      const float dg = colbuf[0][lane][lane];
+      const unsigned long long bad = __ballot(!(dg == dg));
+      if (bad != 0ull && lane == 0) {
+        const unsigned col = (unsigned)(CP_NB * j + __builtin_ctzll(bad) + 1);   // LAPACK's info
+        __hip_atomic_fetch_max(fail, CP_FAILBIG - col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  CP_STAMP(4);
+
+  // ---- arrival; the last workgroup writes info[] and leaves the sync words zero for the next call
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&a.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (old == (unsigned)a.total - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last) {
+    const unsigned tmo = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int bb = tid; bb < a.B; bb += 512) {
+      const unsigned f = __hip_atomic_load(&a.sync[CP_HDR + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.info[bb] = tmo ? -1 : (f ? (int)(CP_FAILBIG - f) : 0);
+    }
+    __syncthreads();
+    const long nw = CP_HDR + ((a.B + 3) / 4) * 4 + 4l * a.B * nb * nb;
+    for (long t = tid; t < nw; t += 512) __hip_atomic_store(&a.sync[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}

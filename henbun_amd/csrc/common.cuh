@@ -15,6 +15,9 @@
 // argument, >0 for a HIP runtime failure (hipError_t value).
 // ---------------------------------------------------------------------------
 void hb_set_error(const char* fmt, ...);
+// Diagnostic switches (A/B forms of a dispatch rule, forced tile sizes): a process-wide key -> value table written only
+// through hb_debug_set() (include/henbun_hip.h).  Nothing in the library reads the environment.
+long hb_debug_get(const char* key, long dflt);
 
 #define HB_REQUIRE(cond, ...)                                   \
   do {                                                          \

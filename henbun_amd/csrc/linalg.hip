@@ -486,7 +486,7 @@ template <typename T>
 static bool matmul_wgk_ok(const MmArgs<T>&, long, long, long, long, int, bool) { return false; }
 template <>
 bool matmul_wgk_ok<float>(const MmArgs<float>& a, long M, long N, long K, long batch, int flags, bool aligned) {
-  static const bool off = getenv("HB_MM_NO_WGK") != nullptr;  // diagnostic A/B switch
+  const bool off = hb_debug_get("mm_no_wgk", 0) != 0;  // diagnostic A/B switch (hb_debug_set)
   if (off || !aligned) return false;
   if (M % 32 || N % 32 || K % 128 || K < 128 || K > 4096) return false;
   if (flags & HB_MM_ACTGRAD) return false;
@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
 }
 
 static inline bool matmul_rowsreg_ok(const MmArgs<float>& a, int& G, int& KC) {
-  static const bool off = getenv("HB_MM_NO_ROWSREG") != nullptr;   // diagnostic: the LDS form
+  const bool off = hb_debug_get("mm_no_rowsreg", 0) != 0;   // diagnostic: the LDS form
   // one column tile (N <= 32): the LDS form is the faster one ([32768, 64] x [64, 16]: 5.7 against 8.7 us) -- every wave
   // would hold the same weights
   if (off || a.N <= 32) return false;
@@ -880,7 +880,7 @@ template <typename T>
 static bool matmul_rows_ok(const MmArgs<T>&, int, int) { return false; }
 template <>
 bool matmul_rows_ok<float>(const MmArgs<float>& a, int transA, int transB) {
-  static const bool off = getenv("HB_MM_NO_ROWS") != nullptr;   // diagnostic: the tile engine for everything
+  const bool off = hb_debug_get("mm_no_rows", 0) != 0;   // diagnostic: the tile engine for everything
   if (off || transA || a.batch != 1 || a.M < 2048 || a.K < 8 || a.K > 256 || a.K % 8 != 0 || a.N < 1 || a.N > 256) return false;
   if (!(a.flags == 0 || a.flags == HB_MM_ACTGRAD) || a.beta != 0.f) return false;
   int NT, WC, NW;
@@ -1020,15 +1020,14 @@ static int matmul_launch(const T* A, const T* B, T* C, long batch, long M, long 
     if (s0 >= 2) S = (int)s0;
   }
   {
-    // diagnostic overrides (tools/stride_probe.py): HB_MM_FORCE_BT=64|128, HB_MM_FORCE_S=<slabs>
-    static const char* fbt = getenv("HB_MM_FORCE_BT");
-    static const char* fs = getenv("HB_MM_FORCE_S");
+    // diagnostic overrides (tools/stride_probe.py): hb_debug_set("mm_force_bt", 64|128), ("mm_force_s", <slabs>)
+    const long fbt = hb_debug_get("mm_force_bt", 0), fs = hb_debug_get("mm_force_s", 0);
     if (fbt) {
-      BT = atoi(fbt) == 128 ? 128 : 64;
+      BT = fbt == 128 ? 128 : 64;
       a.tile = BT;
     }
     if (fs && ws) {
-      long s = atol(fs);
+      long s = fs;
       const long s3 = ws_elems / (batch * M * N);
       if (s > s3) s = s3;
       if (s > K / 16) s = K / 16;
@@ -2125,6 +2124,31 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
   HB_STAMP(3);
 }
 
+#include "chol_persist.cuh"
+
+// One persistent launch (chol_persist.cuh) for fp32 factor + inverse at M % 64 == 0; `ws` then carries the exchange area
+// and, behind it, the launch's sync words (zero at entry, left zero at exit: hb_cholesky_inverse_ws_elems).
+static int chol_persist_launch(const float* A, float* L, float* W, float* ws, long B, long M, int* info, hipStream_t stream) {
+  CpArgs a;
+  a.A = A, a.L = L, a.W = W, a.X = ws;
+  a.sync = reinterpret_cast<unsigned*>(ws + B * M * M);
+  a.info = info;
+  a.M = (int)M, a.B = (int)B, a.nb = (int)(M / CP_NB);
+  a.total = (int)cp_total(B, a.nb, 1);
+  a.stamps = nullptr;
+  const HbSideJobs sj = hb_side_take();   // pending side jobs of this thread ride on this launch
+  hipLaunchKernelGGL(chol_persist_kernel, dim3((unsigned)(a.total + sj.total)), dim3(512), 0, stream, a, sj);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+static inline bool chol_persist_shape(long B, long M, size_t elem) {
+  return elem == 4 && M >= CP_NB && M % CP_NB == 0 && M <= 8192 && B >= 1 && B * (M / CP_NB) * (M / CP_NB) <= 65536;
+}
+extern "C" long hb_cholesky_inverse_ws_elems(long B, long M, int elem_bytes) {
+  if (B <= 0 || M <= 0) return 1;
+  return B * M * M + (chol_persist_shape(B, M, (size_t)elem_bytes) ? cp_sync_words(B, M) : 0);
+}
+
 template <typename T>
 static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, long B, long M, int* info, hipStream_t stream) {
   HB_REQUIRE(!Wf || (W && M % 32 == 0), "hb_cholesky_inverse: the fragment-major copies need W and M %% 32 == 0");
@@ -2144,8 +2168,11 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, lon
   const int inv = W != nullptr;
   const int nblk = hb_cdiv(M, CR_B);
   const bool fast = ((uintptr_t)L % 16 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)ws % 16 == 0) && M % CR_B == 0;
-  static const bool no64 = getenv("HB_CHOL_NO64") != nullptr;  // diagnostic A/B switch
-  if (sizeof(T) == 4 && fast && M % C64_NB == 0 && !no64) {
+  const bool no64 = hb_debug_get("chol_no64", 0) != 0;  // diagnostic A/B switches (hb_debug_set)
+  if (sizeof(T) == 4 && fast && inv && chol_persist_shape(B, M, sizeof(T)) && hb_debug_get("chol_persist", 1) != 0) {
+    const int rc = chol_persist_launch((const float*)A, (float*)L, (float*)W, (float*)ws, B, M, info, stream);
+    if (rc) return rc;
+  } else if (sizeof(T) == 4 && fast && M % C64_NB == 0 && !no64) {
     const int nrt = (int)(M / 32);
     HbSideJobs noside = {};
     for (int k = 0; k < nrt / 2; ++k) {

@@ -17,6 +17,39 @@ void hb_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hb_last_error_string(void) { return g_err; }
+
+// ---- diagnostic switches: see common.cuh.  A handful of keys, set by tests and tools before the calls they steer.
+#include <mutex>
+namespace {
+struct HbDebugEntry { char key[40]; long value; };
+HbDebugEntry g_dbg[32];
+int g_ndbg = 0;
+std::mutex g_dbg_mu;
+}  // namespace
+long hb_debug_get(const char* key, long dflt) {
+  std::lock_guard<std::mutex> lk(g_dbg_mu);
+  for (int i = 0; i < g_ndbg; ++i)
+    if (strcmp(g_dbg[i].key, key) == 0) return g_dbg[i].value;
+  return dflt;
+}
+extern "C" int hb_debug_set(const char* key, long value) {
+  HB_REQUIRE(key && key[0] && strlen(key) < sizeof(g_dbg[0].key), "hb_debug_set: bad key");
+  std::lock_guard<std::mutex> lk(g_dbg_mu);
+  for (int i = 0; i < g_ndbg; ++i)
+    if (strcmp(g_dbg[i].key, key) == 0) {
+      g_dbg[i].value = value;
+      return 0;
+    }
+  HB_REQUIRE(g_ndbg < 32, "hb_debug_set: table full");
+  strcpy(g_dbg[g_ndbg].key, key);
+  g_dbg[g_ndbg++].value = value;
+  return 0;
+}
+extern "C" int hb_debug_clear(void) {
+  std::lock_guard<std::mutex> lk(g_dbg_mu);
+  g_ndbg = 0;
+  return 0;
+}
 extern "C" int hb_version(void) { return HB_ABI_VERSION; }
 
 extern "C" int hb_device_info(char* buf, int buflen, int* cu_count) {

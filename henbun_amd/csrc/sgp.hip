@@ -1294,15 +1294,14 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip3_kernel(SgpArgs
 
 // diagnostic switch: HB_SGP_NO_STRIP=1 forces the tiled kernels (A/B timing)
 static inline bool hb_sgp_no_strip() {
-  static const bool v = getenv("HB_SGP_NO_STRIP") != nullptr;
-  return v;
+  return hb_debug_get("sgp_no_strip", 0) != 0;   // diagnostic (hb_debug_set)
 }
 // The strip form wins when the tiled kernel would leave ~one workgroup per CU (cfg 2: 33.5 -> 28.8 us); with
 // many experts / a long minibatch the tiled kernel runs several workgroups per CU and stays the faster one
 // (cfg 5, E = 8, n = 65536: 1.68 ms tiled vs 1.76 ms strip, HB_SGP_FORCE_STRIP=1).
 static inline bool sgp_strip_ok(long E, long n, long M, long d, const void* W) {
   const long tiled_wgs = E * hb_cdiv(n, SGP_BN) * ((hb_cdiv(M, SGP_BM) + 1) / 2);
-  static const bool force = getenv("HB_SGP_FORCE_STRIP") != nullptr;  // diagnostic: strip form whenever it is applicable
+  const bool force = hb_debug_get("sgp_force_strip", 0) != 0;  // diagnostic: strip form whenever it is applicable
   return M >= 32 && M <= SGP_SM_MAX && M % 32 == 0 && d <= SGP_DREG && ((uintptr_t)W % 16 == 0) && (tiled_wgs < 1024 || force);
 }
 
@@ -1316,7 +1315,7 @@ extern "C" int hb_sgp_strip_path(long E, long n, long M, long d, long P, int pre
   // strip kernel) no longer holds with the fragment-major W / A / Kbar exchange: cfg 5 (E = 8, n = 65536) runs
   // 6.03 ms per step tiled against 5.33 ms in strip form (sgp_grad 3742 -> 3371 us, sgp 1554 -> 1479 us).
   // HB_SGP_TILED_CROSSOVER=1 restores the old rule (diagnostic).
-  static const bool old_rule = getenv("HB_SGP_TILED_CROSSOVER") != nullptr;
+  const bool old_rule = hb_debug_get("sgp_tiled_crossover", 0) != 0;
   // (the backward's strip partials [nS][2d + P][M] and at least one Lbar slab must fit the 32 M^2 workspace per expert)
   if (!old_rule) return (E * hb_cdiv(n, SGP_SN) <= (1L << 22) && (long)hb_cdiv(n, SGP_SN) * (2 * d + P) <= 31 * M) ? 1 : 0;
   const long tiled_wgs = E * hb_cdiv(n, SGP_BN) * ((hb_cdiv(M, SGP_BM) + 1) / 2);
@@ -1327,7 +1326,7 @@ static int sgp_A_strip_launch(SgpArgs<float> a, long E, hipStream_t stream) {
   dim3 grid = sgp_grid(hb_cdiv(a.n, SGP_SN), 1, E, a.efast);
   // third form (transposed accumulators, two workgroups per CU) whenever its one column mean suffices;
   // HB_SGP_STRIP_FORM2=1 keeps the second form (diagnostic: A/B timing, the two forms agree bit for bit in A)
-  const bool form3 = (!a.part || a.P <= 1) && !getenv("HB_SGP_STRIP_FORM2");
+  const bool form3 = (!a.part || a.P <= 1) && hb_debug_get("sgp_strip_form2", 0) == 0;
 #define HB_STRIP(D_)                                                                                          \
   do {                                                                                                        \
     if (a.W3)                                                                                                 \
@@ -1489,7 +1488,7 @@ struct SgpHead {
 };
 // can hb_sgp_fwd run its finishing pass (and a likelihood head) inside the third strip form for this call?
 static inline bool sgp_fused_finish_ok(long E, long n, long M, long d, long P, int prec, bool has_wfrag, bool draw, long rng_lanes) {
-  const bool nofuse = getenv("HB_SGP_NO_FUSED_FINISH") != nullptr || getenv("HB_SGP_STRIP_FORM2") != nullptr;   // (diagnostic)
+  const bool nofuse = hb_debug_get("sgp_no_fused_finish", 0) != 0 || hb_debug_get("sgp_strip_form2", 0) != 0;   // (diagnostic)
   return !nofuse && has_wfrag && prec == HB_PREC_NATIVE && hb_sgp_strip_path(E, n, M, d, P, prec) && P <= 1 && n % 2 == 0 &&
          (!draw || rng_lanes >= (E * n + 1) / 2);
 }
@@ -2945,12 +2944,12 @@ static int sgp_lbar_frag_launch(const float* Kf, const float* Af, float* slabs, 
   if (S > slab_cap) S = slab_cap;   // the slabs live in what is left of the 32*E*M*M-element workspace
   if (S < 1) S = 1;
   {
-    static const char* fs = getenv("HB_LBAR_FORCE_S");  // diagnostic
-    if (fs) S = atol(fs);
+    const long fs = hb_debug_get("lbar_force_s", 0);  // diagnostic
+    if (fs) S = fs;
   }
   {
     // many blocks (experts x a long minibatch): 128 x 128 blocks with LDS-staged operand tiles, every unit resident
-    static const char* nolds = getenv("HB_LBAR_NO_LDS");   // diagnostic
+    const bool nolds = hb_debug_get("lbar_no_lds", 0) != 0;   // diagnostic
     const long nB2 = (nT + 3) / 4, pairs2 = nB2 * (nB2 + 1) / 2;
     if (prec != HB_PREC_BF16X3 && !nolds && pairs * E >= 256 && nS >= 64) {
       long S2 = 512 / (pairs2 * E);

@@ -202,6 +202,9 @@ struct HbSideJobs {
 // one side workgroup (256 threads; `vb` = its index among the side workgroups of the launch)
 __device__ __forceinline__ void hb_side_run(const HbSideJobs& J, int vb) {
   __shared__ float side_smem[16];
+  // a host with more than four waves per block (chol_persist_kernel: 512 threads, its upper half leaves before this
+  // call) makes block_sum read as many slots as the block has waves: the slots nobody writes must hold zeros
+  if (threadIdx.x < 16) side_smem[threadIdx.x] = 0.f;
 #pragma unroll
   for (int q = 0; q < HB_SIDE_MAX; ++q) {
     if (q >= J.n) return;

@@ -1093,7 +1093,9 @@ def _cholesky_emit(plan, node):
     inv_node = next((c for c in plan._consumers.get(node.outputs[0], ()) if c.op == "trinv"), None)
     if inv_node is not None and a.data_ptr() != out.data_ptr():
         w = plan.out(inv_node.outputs[0])
-        ws = plan.scratch((max(int(np.prod(node.outputs[0].shape)), 1),))
+        # exchange area + sync words of the persistent launch: zero-filled once, left zero by every call
+        ws = plan.torch.zeros((max(H.cholesky_ws_elems(B, node.outputs[0].shape[-1], plan.dtype), 1),), dtype=plan.dtype,
+                              device=plan.device)
         plan._fused_trinv.add(inv_node.id)
         # fragment-major copies of W / W^T for the M^2 n contractions that consume this inverse (csrc/sgp.hip)
         frag = None

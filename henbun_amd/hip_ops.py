@@ -724,6 +724,32 @@ def cholesky(A, out=None, info=None):
 
 PREC_NATIVE, PREC_BF16X3 = 0, 1
 
+_chol_ws_cache = {}
+
+
+def debug_set(key, value):
+    """Diagnostic switch of the native library (hb_debug_set, include/henbun_hip.h): tests and tools only."""
+    _lib.lib().call("hb_debug_set", key.encode(), int(value))
+
+
+def debug_clear():
+    _lib.lib().call("hb_debug_clear")
+
+
+def cholesky_ws_elems(B, M, dtype):
+    return int(_lib.lib().raw("hb_cholesky_inverse_ws_elems")(B, M, 4 if dtype == torch.float32 else 8))
+
+
+def cholesky_workspace(dtype, device, B, M):
+    """ZERO-FILLED workspace of hb_cholesky_inverse for (B, M) on the current stream: the persistent launch keeps its
+    sync words there and leaves them zero after every call (include/henbun_hip.h, workspace contract)."""
+    key = (dtype, str(device), torch.cuda.current_stream().cuda_stream, B, M)
+    w = _chol_ws_cache.get(key)
+    if w is None:
+        w = torch.zeros(max(cholesky_ws_elems(B, M, dtype), 1), dtype=dtype, device=device)
+        _chol_ws_cache[key] = w
+    return w
+
 
 def cholesky_inverse(A, out=None, inv=None, info=None, ws=None, frag=None, frag_bf16x3=False):
     """(L, W, info): L = chol(A) and W = L^-1 from one fused launch sequence (batched over leading dims).
@@ -739,7 +765,8 @@ def cholesky_inverse(A, out=None, inv=None, info=None, ws=None, frag=None, frag_
     if info is None:
         info = _empty(max(B, 1), dtype=torch.int32, device=A.device)
     if ws is None:
-        ws = workspace(A.dtype, A.device, max(B * M * M, 1))
+        ws = cholesky_workspace(A.dtype, A.device, B, M)
+    assert ws.numel() >= cholesky_ws_elems(B, M, A.dtype), "hb_cholesky_inverse: workspace too small (cholesky_ws_elems)"
     if frag is not None:
         assert frag.numel() >= (5 if frag_bf16x3 else 2) * B * M * M and M % 32 == 0 and frag.dtype == A.dtype
     _lib.lib().call("hb_cholesky_inverse" + _suf(A), _p(A), _p(out), _p(inv), B, M, _p(info), _p(ws), _p(frag),

@@ -38,11 +38,21 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 1
+/* ABI history: 1 = rounds 1-3 (the round that removed hb_cholesky_inverse_sgp_f32 and hb_sgp_finish_* should have
+ * bumped it and did not); 2 = round 4: hb_debug_set / hb_debug_clear, hb_cholesky_inverse_ws_elems and the workspace
+ * contract of hb_cholesky_inverse_f32 (exchange + sync area, zero-filled once by its owner). */
+#define HB_ABI_VERSION 2
 
 /* ---- runtime ----------------------------------------------------------- */
 int hb_version(void);
 const char* hb_last_error_string(void);
+/* Diagnostic switches (A/B forms of a dispatch rule, forced tile sizes; tests and tools/ use them): a process-wide
+ * key -> value table.  The library never reads the environment; without a call here every dispatch rule is the
+ * shipped one.  Keys: chol_persist (0: the launch-chain Cholesky), chol_no64, mm_no_wgk, mm_no_rowsreg, mm_no_rows,
+ * mm_force_bt, mm_force_s, sgp_no_strip, sgp_force_strip, sgp_tiled_crossover, sgp_strip_form2, sgp_no_fused_finish,
+ * lbar_force_s, lbar_no_lds.  hb_debug_clear() drops every entry. */
+int hb_debug_set(const char* key, long value);
+int hb_debug_clear(void);
 /* device name / arch of the current device into (host) buf; returns 0 or hipError */
 int hb_device_info(char* buf, int buflen, int* cu_count);
 
@@ -371,7 +381,15 @@ int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void*
 
 /* K4+K6 fused: L = chol(A) and W = L^-1 from the same launches (the identity is
  * eliminated alongside A: the inverse costs extra width per launch, no extra
- * depth).  ws: B*M*M elements.  Replaces the tf.cholesky +
+ * depth).  fp32 with M % 64 == 0 runs as ONE persistent launch (csrc/chol_persist.cuh): workgroups keep their tiles
+ * in registers for the whole factorisation and hand finished 16-column chunks of a panel to each other through ws.
+ * ws: hb_cholesky_inverse_ws_elems(B, M, sizeof element) elements (B*M*M, plus the persistent launch's sync words).
+ * WORKSPACE CONTRACT (fp32, M % 64 == 0): the sync words behind the first B*M*M elements must be ZERO when a call
+ * starts.  The caller zero-fills a workspace once, after allocating it (or whenever something else wrote into it);
+ * every call leaves them zero again, so the same workspace serves call after call (graph replays included) as long
+ * as it is used with the same (B, M) and by one stream at a time.  info[b] = -1 reports a synchronisation timeout
+ * (dirty sync words, or a device that stopped making progress for 2 s): the outputs are then invalid.
+ * Replaces the tf.cholesky +
  * tf.matrix_triangular_solve(Lm, .) pair of SparseGP.samples (reference
  * gp/gp.py:135,162,169).  A, L, W must not alias.
  * Wfrag (nullable; 2*B*M*M elements, needs M % 32 == 0): fragment-major copies of W and of W^T --
@@ -381,6 +399,7 @@ int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void*
  * frag_bf16x3 != 0 (fp32 only): Wfrag has 5*B*M*M elements and, behind the two fp32 images, receives the bf16x3
  * operand images of W and W^T (3 + 3 planes of B*M*M bf16: each fp32 entry split into hi + mid + lo bf16 terms;
  * [term][B][t][Q][k16-step q][64 lanes][8] = X[32t+li][32Q+16q+8h+j]) for the HB_PREC_BF16X3 contractions. */
+long hb_cholesky_inverse_ws_elems(long B, long M, int elem_bytes);
 int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long B, long M, int* info, float* ws,
                             float* Wfrag, int frag_bf16x3, void* stream);
 int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info,
