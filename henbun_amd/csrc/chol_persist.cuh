@@ -50,6 +50,7 @@
 
 typedef float CpV4 __attribute__((ext_vector_type(4)));
 typedef unsigned CpU4 __attribute__((ext_vector_type(4)));
+typedef float CpV2 __attribute__((ext_vector_type(2)));
 
 struct CpArgs {
   const float* A;
@@ -130,13 +131,15 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
   }
   __shared__ __attribute__((aligned(16))) float colbuf[2][CP_NB][CP_LD];   // [diag | strip][column][row]
   __shared__ __attribute__((aligned(16))) float pibuf[CP_NB];              // reciprocal pivots
-  __shared__ int done[2];                                                    // columns published by the diag / strip waves
+  __shared__ int done[2];     // columns of the diagonal block (0) / of the strip (1) that are published
   __shared__ unsigned s_ticket, s_last;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = w >> 2;                                   // 0: diagonal block, 1: strip
-  const int q = r == 0 ? (w & 3) : ((w + 2) & 3);         // column group; the strip wave of group q sits on another SIMD
+  // column group.  Wave w runs on SIMD w & 3; the work of a wave grows with q (it follows 16 q columns before its own
+  // 16), so the diagonal wave of group q shares its SIMD with the strip wave of group 3 - q: 5 units of 16 columns each
+  const int q = r == 0 ? (w & 3) : 3 - (w & 3);
   const int i16 = lane & 15, g4 = lane >> 4;              // MFMA 16x16x4 lane coordinates
   const int M = a.M, nb = a.nb, inv = a.W != nullptr;
 
@@ -211,6 +214,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
     for (int c4 = 0; c4 < 4; ++c4) {
       wt.wait(fB + c4);
       if (r == 1) wt.wait(fA + c4);
+      CP_STAMP(8 + 4 * (k & 7) + c4);
       // chunk layout [chunk][v = k-quad][row][4 floats]: lane (i16, g4) takes k-quad g4 of its rows
       const int chunk = ((c4 * 4 + g4) * CP_NB) * 16;
       const CpV4 av = __builtin_bit_cast(CpV4, __builtin_amdgcn_raw_buffer_load_b128(xr, offB + chunk + (CP_G * q + i16) * 16, 0, 16));
@@ -224,11 +228,50 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           if (r == 1 || t >= q) R[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[e], bv[t][e], R[t], 0, 0, 0);
+      if (k == j - 1) CP_STAMP(40 + c4);
     }
   }
   CP_STAMP(1);
 
-  // ---- row per lane: a 4 x 4 block transpose over (lane group, tile); afterwards lane l holds row l of its row
+  // ---- in-panel phase.
+  // (a) FOLLOW the column groups to the left, still in the MFMA layout, four published columns at a time: one rank-4
+  //     MFMA per tile, operands straight from the published columns (A: the multipliers L[cq + m][c], B: the wave's own
+  //     rows' L[row][c]) -- 5 LDS reads + 4 MFMAs per four columns.
+  const int cq = CP_G * q;
+  const bool in_panel = r == 0 || strip_live;
+  int seen0 = 0, seen1 = 0;
+  auto wait0 = [&](int upto) {   // columns [0, upto) of the diagonal block are published
+    while (seen0 < upto) {
+      seen0 = __hip_atomic_load(&done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (seen0 < upto) __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  };
+  auto wait1 = [&](int upto) {   // ... of the strip (published after the same columns of the diagonal block)
+    while (seen1 < upto) {
+      seen1 = __hip_atomic_load(&done[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (seen1 < upto) __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  };
+  if (in_panel) {
+    if (r == 0) __builtin_amdgcn_s_setprio(2);
+#pragma unroll 1
+    for (int c0 = 0; c0 < cq; c0 += 4) {
+      if (r == 0) wait0(c0 + 4); else wait1(c0 + 4);   // (a strip column is published after the same column of the diagonal block)
+      const float av = colbuf[0][c0 + g4][cq + i16];
+      float bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (r == 1 || t >= q) bv[t] = colbuf[r][c0 + g4][16 * t + i16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (r == 1 || t >= q) R[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av, bv[t], R[t], 0, 0, 0);
+    }
+  }
+  CP_STAMP(2);
+
+  // (b) row per lane: a 4 x 4 block transpose over (lane group, tile); afterwards lane l holds row l of its row
   // block, x[4 s + e] = column 16 q + 4 s + e
   float x[16];
   {
@@ -256,78 +299,114 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
       for (int e = 0; e < 4; ++e) x[4 * sl + e] = T[sl][e];
   }
 
-  // ---- in-panel phase
-  const int cq = CP_G * q;
-  if (r == 0 || strip_live) {
-    int seen0 = 0, seen1 = 0;
-    auto wait0 = [&](int c) {
-      while (seen0 <= c) {
-        seen0 = __hip_atomic_load(&done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (seen0 <= c) __builtin_amdgcn_s_sleep(1);
-      }
-      asm volatile("" ::: "memory");
-    };
-    auto wait1 = [&](int c) {
-      while (seen1 <= c) {
-        seen1 = __hip_atomic_load(&done[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (seen1 <= c) __builtin_amdgcn_s_sleep(1);
-      }
-      asm volatile("" ::: "memory");
-    };
-    // follow the columns of the groups to the left
-#pragma unroll 1
-    for (int c = 0; c < cq; ++c) {
-      if (r == 0) wait0(c); else wait1(c);
-      const float Lc = colbuf[r][c][lane];
-      CpV4 m[4];
+  // (c) the wave's own column group.  Measured (tools/xlane_cost.hip, profiles/r04_xlane_cost.txt): a lone wave issues
+  // one vector instruction per ~6.6 cycles whatever it is (v_readlane + v_fma pair 16.7 dependent, v_fmac_f32_dpp 11.6),
+  // the chain readlane -> rsq -> mul -> readlane -> fma is ~50 cycles per column -- so the INSTRUCTION COUNT of the pivot
+  // wave paces the panel, not the latency of its cross-lane operations.
+  //   Pivot wave (diagonal block, all 64 rows at once): per column 3 chain instructions, 2 LDS writes, ONE eager update
+  //   (the next column, multiplier by v_readlane) -- every later column takes the update one step later, multipliers read
+  //   back from the published column as uniform 16-byte LDS reads (LDS executes a wave's instructions in order, so the
+  //   read-back sees the wave's own write) and applied two columns per instruction (v_pk_fma_f32).
+  //   Strip wave: all reads of a four-column sub-group first (one LDS latency per sub-group), then the arithmetic (packed),
+  //   then its four stores and the counter.
+  if (in_panel) {
+    CpV2 xx[8];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) m[v] = *reinterpret_cast<const CpV4*>(&colbuf[0][c][cq + 4 * v]);
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[4 * v + e] = __builtin_fmaf(-Lc, m[v][e], x[4 * v + e]);
-    }
-    CP_STAMP(2);
+    for (int i = 0; i < 8; ++i) xx[i] = CpV2{x[2 * i], x[2 * i + 1]};
     if (r == 0) {
-      // PIVOT wave of columns cq .. cq+15: the diagonal rows are lanes cq + p of this wave
       __builtin_amdgcn_s_setprio(3);
+      CpV4 mb[2][4];
+      float xprev = 0.f;
 #pragma unroll
       for (int p = 0; p < CP_G; ++p) {
         const int c = cq + p;
-        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[p]), c));
+        float xp = (p & 1) ? xx[p >> 1][1] : xx[p >> 1][0];
+        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xp), c));
         float lcc, pi;
         pivot_sqrt(d, lcc, pi);
         (void)lcc;
-        x[p] *= pi;
-        colbuf[0][c][lane] = x[p];
-        if (lane == 0) pibuf[c] = pi;
-        asm volatile("" ::: "memory");
-        // (LDS executes one wave's instructions in order: the counter store lands after the column)
-        if (lane == 0) __hip_atomic_store(&done[0], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int p2 = p + 1; p2 < CP_G; ++p2) {
-          const float mlt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[p]), cq + p2));
-          x[p2] = __builtin_fmaf(-x[p], mlt, x[p2]);
+        xp *= pi;
+        colbuf[0][c][lane] = xp;
+        pibuf[c] = pi;
+        if ((p & 3) == 3) {
+          asm volatile("" ::: "memory");
+          __hip_atomic_store(&done[0], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
+          CP_STAMP(56 + (p >> 2));
         }
+        if (p + 1 < CP_G) {
+          // eager: the next column (it is the next pivot)
+          const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xp), c + 1));
+          float xn = ((p + 1) & 1) ? xx[(p + 1) >> 1][1] : xx[(p + 1) >> 1][0];
+          xn = __builtin_fmaf(-xp, m1, xn);
+          if ((p + 1) & 1) xx[(p + 1) >> 1][1] = xn; else xx[(p + 1) >> 1][0] = xn;
+        }
+        // multipliers of this column for the columns p + 2 .. 15, read back for the next step
+#pragma unroll
+        for (int v = (p + 2) >> 2; v < 4; ++v) mb[p & 1][v] = *reinterpret_cast<const CpV4*>(&colbuf[0][c][cq + 4 * v]);
+        // lazy: column p - 1 applied to the columns p + 1 .. 15
+        if (p >= 1) {
+#pragma unroll
+          for (int i = (p + 1) >> 1; i < 8; ++i) {
+            const CpV4 mv = mb[(p - 1) & 1][i >> 1];
+            const CpV2 m2 = (i & 1) ? CpV2{mv[2], mv[3]} : CpV2{mv[0], mv[1]};
+            if (2 * i >= p + 1) {
+              xx[i] = __builtin_elementwise_fma(CpV2{-xprev, -xprev}, m2, xx[i]);
+            } else {   // 2 i == p: only the odd element (column p + 1)
+              const float t1 = xx[i][1];
+              xx[i][1] = __builtin_fmaf(-xprev, m2[1], t1);
+            }
+          }
+        }
+        if (p & 1) xx[p >> 1][1] = xp; else xx[p >> 1][0] = xp;
+        xprev = xp;
       }
       __builtin_amdgcn_s_setprio(0);
     } else {
-      // the strip's own group: scale by the published reciprocal pivot, publish, eliminate with the diagonal rows' entries
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int p = 0; p < CP_G; ++p) {
-        const int c = cq + p;
-        wait0(c);
-        const float pi = pibuf[c];
-        CpV4 m[4];
+      for (int sg = 0; sg < 4; ++sg) {
+        CP_STAMP(44 + 3 * sg);
+        wait0(cq + 4 * sg + 4);
+        CP_STAMP(45 + 3 * sg);
+        const CpV4 pi4 = *reinterpret_cast<const CpV4*>(&pibuf[cq + 4 * sg]);
+        CpV4 mv[4][4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) m[v] = *reinterpret_cast<const CpV4*>(&colbuf[0][c][cq + 4 * v]);
-        x[p] *= pi;
-        colbuf[1][c][lane] = x[p];
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+          for (int v = sg; v < 4; ++v) mv[pp][v] = *reinterpret_cast<const CpV4*>(&colbuf[0][cq + 4 * sg + pp][cq + 4 * v]);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          const int p = 4 * sg + pp;
+          float xp = (p & 1) ? xx[p >> 1][1] : xx[p >> 1][0];
+          xp *= pi4[pp];
+          if (p & 1) xx[p >> 1][1] = xp; else xx[p >> 1][0] = xp;
+#pragma unroll
+          for (int i = (p + 1) >> 1; i < 8; ++i) {
+            const CpV4 m4 = mv[pp][i >> 1];
+            const CpV2 m2 = (i & 1) ? CpV2{m4[2], m4[3]} : CpV2{m4[0], m4[1]};
+            if (2 * i >= p + 1) {
+              xx[i] = __builtin_elementwise_fma(CpV2{-xp, -xp}, m2, xx[i]);
+            } else {
+              const float t1 = xx[i][1];
+              xx[i][1] = __builtin_fmaf(-xp, m2[1], t1);
+            }
+          }
+        }
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          const int p = 4 * sg + pp;
+          colbuf[1][cq + p][lane] = (p & 1) ? xx[p >> 1][1] : xx[p >> 1][0];
+        }
         asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&done[1], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int p2 = p + 1; p2 < CP_G; ++p2) x[p2] = __builtin_fmaf(-x[p], m[p2 >> 2][p2 & 3], x[p2]);
+        __hip_atomic_store(&done[1], cq + 4 * sg + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        CP_STAMP(46 + 3 * sg);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[2 * i] = xx[i][0], x[2 * i + 1] = xx[i][1];
+    if (r == 1) {
       // ---- hand the finished chunk to the later column blocks (write-through stores, drained, then its flag)
       if (j < nb - 1) {
         const int off = (j * nb + s) * (CP_NB * CP_NB * 4) + ((q * 4) * CP_NB + lane) * 16;
@@ -337,9 +416,9 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(CpU4, o), xr, off + v * CP_NB * 16, 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-          __hip_atomic_store(flags + ((size_t)j * nb + s) * 4 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flags + ((size_t)j * nb + s) * 4 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      __builtin_amdgcn_s_setprio(0);
     }
   }
   CP_STAMP(3);

@@ -2125,6 +2125,9 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
 }
 
 #include "chol_persist.cuh"
+#ifdef HB_CP_STAMPS
+extern unsigned long long* hb_cp_stamps_buffer;   // diagnostic build (tools/chol_persist_stamps.hip)
+#endif
 
 // One persistent launch (chol_persist.cuh) for fp32 factor + inverse at M % 64 == 0; `ws` then carries the exchange area
 // and, behind it, the launch's sync words (zero at entry, left zero at exit: hb_cholesky_inverse_ws_elems).
@@ -2135,7 +2138,11 @@ static int chol_persist_launch(const float* A, float* L, float* W, float* ws, lo
   a.info = info;
   a.M = (int)M, a.B = (int)B, a.nb = (int)(M / CP_NB);
   a.total = (int)cp_total(B, a.nb, 1);
+#ifdef HB_CP_STAMPS
+  a.stamps = hb_cp_stamps_buffer;   // diagnostic build (tools/chol_persist_stamps.hip)
+#else
   a.stamps = nullptr;
+#endif
   const HbSideJobs sj = hb_side_take();   // pending side jobs of this thread ride on this launch
   hipLaunchKernelGGL(chol_persist_kernel, dim3((unsigned)(a.total + sj.total)), dim3(512), 0, stream, a, sj);
   HB_LAUNCH_CHECK();

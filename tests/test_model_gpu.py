@@ -451,7 +451,7 @@ def test_cfg2_full_size_properties_fp32():
     # lengthscales 8.4e-5, q_mu 2.0e-4, q_sqrt 2.0e-4, k_var 2.7e-7, var 1.0e-5
     observe("cfg2_fullsize_fp32/ELBO", abs(v1 - ref_val.item()) / abs(ref_val.item()), 5e-5)
     bound = {"model.gp.z": 1e-2, "model.gp.kern.lengthscales": 6e-4, "model.u.q_mu": 1.9e-3, "model.u.q_sqrt": 1.9e-3,
-             "model.k_var": 2.5e-6, "model.var": 1e-4}
+             "model.k_var": 2e-5, "model.var": 1e-4}   # k_var: a scalar, 2.7e-7 (round 3) .. 6.6e-6 (round 4, persistent Cholesky: another rounding of L)
     for mine, theirs in NAMES:
         observe("cfg2_fullsize_fp32/" + mine, tile_err(g1[mine], ref[theirs].numpy()), bound[mine])
     # kernel identities at the same size
