@@ -59,6 +59,8 @@ struct CpArgs {
   float* X;          // exchange area, B*M*M floats
   unsigned* sync;    // CP_HDR + roundup4(B) + 4*B*nb*nb words, zero at entry, zero at exit
   int* info;
+  float* Wf;         // nullable: the fragment-major images of W and W^T (and the bf16x3 planes behind them)
+  int bf16x3;
   int M, B, nb, total;   // total = number of workgroups of the factorisation (side-job blocks come after them)
   unsigned long long* stamps;   // diagnostic builds only (HB_CP_STAMPS)
 };
@@ -78,10 +80,10 @@ static inline long cp_total(long B, int nb, int inv) {
 }
 
 #ifdef HB_CP_STAMPS
-#define CP_STAMP(slot)                                                                                   \
-  do {                                                                                                   \
-    if (a.stamps && lane == 0) a.stamps[((size_t)ticket * 8 + w) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
+// diagnostic build: stamps stay in registers (a stamp that stores to memory costs ~250 cycles and distorts what it
+// measures) and leave through a buffer of their own at the end of the kernel
+#define CP_NSTAMP 16
+#define CP_STAMP(slot) cpst[slot] = __builtin_amdgcn_s_memtime()
 #else
 #define CP_STAMP(slot)
 #endif
@@ -178,6 +180,11 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
   const __amdgpu_buffer_rsrc_t xr =
       __builtin_amdgcn_make_buffer_rsrc(a.X + (size_t)b * mm, 0, (int)(mm * sizeof(float)), 0x00020000);
   CpWait wt = {a.sync + 2, __builtin_amdgcn_s_memrealtime() + CP_TIMEOUT_TICKS, false};
+#ifdef HB_CP_STAMPS
+  unsigned long long cpst[CP_NSTAMP];
+#pragma unroll
+  for (int i = 0; i < CP_NSTAMP; ++i) cpst[i] = 0;
+#endif
   CP_STAMP(0);
 
   // ---- accumulators: tile t = rows 16t .. 16t+15 of the wave's row block, columns 16q .. 16q+15;
@@ -214,7 +221,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
     for (int c4 = 0; c4 < 4; ++c4) {
       wt.wait(fB + c4);
       if (r == 1) wt.wait(fA + c4);
-      CP_STAMP(8 + 4 * (k & 7) + c4);
+      if (k == j - 1 && c4 == 3) CP_STAMP(5);
       // chunk layout [chunk][v = k-quad][row][4 floats]: lane (i16, g4) takes k-quad g4 of its rows
       const int chunk = ((c4 * 4 + g4) * CP_NB) * 16;
       const CpV4 av = __builtin_bit_cast(CpV4, __builtin_amdgcn_raw_buffer_load_b128(xr, offB + chunk + (CP_G * q + i16) * 16, 0, 16));
@@ -228,7 +235,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           if (r == 1 || t >= q) R[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(-av[e], bv[t][e], R[t], 0, 0, 0);
-      if (k == j - 1) CP_STAMP(40 + c4);
+      if (k == j - 1 && c4 == 3) CP_STAMP(6);
     }
   }
   CP_STAMP(1);
@@ -243,7 +250,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
   auto wait0 = [&](int upto) {   // columns [0, upto) of the diagonal block are published
     while (seen0 < upto) {
       seen0 = __hip_atomic_load(&done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (seen0 < upto) __builtin_amdgcn_s_sleep(1);
+      if (seen0 < upto && r == 1) __builtin_amdgcn_s_sleep(1);   // (a diagonal wave is the next pivot: it polls without sleeping)
     }
     asm volatile("" ::: "memory");
   };
@@ -309,6 +316,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
   //   read-back sees the wave's own write) and applied two columns per instruction (v_pk_fma_f32).
   //   Strip wave: all reads of a four-column sub-group first (one LDS latency per sub-group), then the arithmetic (packed),
   //   then its four stores and the counter.
+  CP_STAMP(11);
   if (in_panel) {
     CpV2 xx[8];
 #pragma unroll
@@ -332,7 +340,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
           asm volatile("" ::: "memory");
           __hip_atomic_store(&done[0], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           asm volatile("" ::: "memory");
-          CP_STAMP(56 + (p >> 2));
+          CP_STAMP(7 + (p >> 2));
         }
         if (p + 1 < CP_G) {
           // eager: the next column (it is the next pivot)
@@ -366,9 +374,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg) {
-        CP_STAMP(44 + 3 * sg);
         wait0(cq + 4 * sg + 4);
-        CP_STAMP(45 + 3 * sg);
         const CpV4 pi4 = *reinterpret_cast<const CpV4*>(&pibuf[cq + 4 * sg]);
         CpV4 mv[4][4];
 #pragma unroll
@@ -401,7 +407,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
         asm volatile("" ::: "memory");
         __hip_atomic_store(&done[1], cq + 4 * sg + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
-        CP_STAMP(46 + 3 * sg);
+        CP_STAMP(7 + sg);
       }
     }
 #pragma unroll
@@ -416,6 +422,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(CpU4, o), xr, off + v * CP_NB * 16, 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CP_STAMP(12);
         __hip_atomic_store(flags + ((size_t)j * nb + s) * 4 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __builtin_amdgcn_s_setprio(0);
@@ -424,13 +431,54 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
   CP_STAMP(3);
   __syncthreads();
 
-  // ---- results, from the published columns in LDS (colbuf[.][column][row])
+  // ---- results, from the published columns in LDS (colbuf[.][column][row]).  Every 64 x 64 block of L, W and of the
+  // fragment-major images (include/henbun_hip.h: hb_cholesky_inverse, Wfrag) has exactly one writer, zero blocks of the
+  // strict upper triangles included -- there is no finishing pass.
+  //   A strip (i, j), i > j:  L(i, j);  zeros: W(j, i), its W image block, the W^T image block (i, j).
+  //   identity strip (i', j), i' <= j:  W(j, i') = Y(i', j)^T and both image blocks;  zeros: L(i', j) when i' < j.
+  const int nT = M / 32;
+  float* Wf = a.Wf ? a.Wf + (size_t)b * mm : nullptr;                 // image of W;  + B*M*M: image of W^T
+  const size_t tot = (size_t)a.B * mm;
+  __bf16* W3 = (a.Wf && a.bf16x3) ? reinterpret_cast<__bf16*>(a.Wf + 2 * tot) + (size_t)b * mm : nullptr;   // planes: + p * tot
+  const CpV4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // one 16-byte group of a fragment-major image block: tile row tt (32 rows), k chunk QQ (32 columns), group index g =
+  // (v, lane): element s of the group is X[32 tt + li][32 QQ + 16 h + 4 v + s]
+  auto frag_off = [&](int tt, int QQ, int g) -> size_t { return (((size_t)tt * nT + QQ) * 256 + g) * 4; };
+  auto store_bf3 = [&](__bf16* plane0, size_t off8, const float (&x8)[8]) {
+    // bf16x3 planes, [t][Q][q][64 lanes][8]: eight consecutive k of one lane, split into hi + mid + lo
+    typedef __bf16 B8 __attribute__((ext_vector_type(8)));
+    B8 h8, m8, l8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      __bf16 h_, m_, l_;
+      hb_split_bf16x3(x8[e], h_, m_, l_);
+      h8[e] = h_, m8[e] = m_, l8[e] = l_;
+    }
+    *reinterpret_cast<B8*>(plane0 + off8) = h8;
+    *reinterpret_cast<B8*>(plane0 + tot + off8) = m8;
+    *reinterpret_cast<B8*>(plane0 + 2 * tot + off8) = l8;
+  };
   if (stripA) {
-    // L(irow, j)
     for (int idx = tid; idx < CP_NB * (CP_NB / 4); idx += 512) {
       const int rr = idx >> 4, c4 = (idx & 15) * 4;
       const CpV4 v = {colbuf[1][c4][rr], colbuf[1][c4 + 1][rr], colbuf[1][c4 + 2][rr], colbuf[1][c4 + 3][rr]};
       *reinterpret_cast<CpV4*>(Lb + (size_t)(CP_NB * irow + rr) * M + CP_NB * j + c4) = v;
+      if (inv) *reinterpret_cast<CpV4*>(Wb + (size_t)(CP_NB * j + rr) * M + CP_NB * irow + c4) = zero4;
+    }
+    if (Wf) {
+      for (int idx = tid; idx < 4 * 256; idx += 512) {
+        const int sub = idx >> 8, g = idx & 255;
+        *reinterpret_cast<CpV4*>(Wf + frag_off(2 * j + (sub >> 1), 2 * irow + (sub & 1), g)) = zero4;          // W(j, i)
+        *reinterpret_cast<CpV4*>(Wf + tot + frag_off(2 * irow + (sub >> 1), 2 * j + (sub & 1), g)) = zero4;    // W^T(i, j)
+      }
+      if (W3) {
+        const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int idx = tid; idx < 4 * 128; idx += 512) {
+          const int sub = idx >> 7, g = idx & 127;
+          store_bf3(W3, (((size_t)(2 * j + (sub >> 1)) * nT + 2 * irow + (sub & 1)) * 128 + g) * 8, z8);
+          store_bf3(W3 + 3 * tot, (((size_t)(2 * irow + (sub >> 1)) * nT + 2 * j + (sub & 1)) * 128 + g) * 8, z8);
+        }
+      }
     }
   } else if (stripY) {
     // W(j, irow) = Y(irow, j)^T: row c of the block is the published column c
@@ -443,6 +491,51 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
           if (r4 + e > c) v[e] = 0.f;
       }
       *reinterpret_cast<CpV4*>(Wb + (size_t)(CP_NB * j + c) * M + CP_NB * irow + r4) = v;
+      if (!ydiag) *reinterpret_cast<CpV4*>(Lb + (size_t)(CP_NB * irow + c) * M + CP_NB * j + r4) = zero4;   // L(i', j), i' < j
+    }
+    if (Wf) {
+      for (int idx = tid; idx < 4 * 256; idx += 512) {
+        const int sub = idx >> 8, g = idx & 255, v4 = g >> 6, l6 = g & 63, li = l6 & 31, h = l6 >> 5;
+        const int tsub = sub >> 1, qsub = sub & 1;
+        {
+          // W image: row 32 (2j + tsub) + li = column 32 tsub + li of the block; k = 64 i' + 32 qsub + 16 h + 4 v4 + s
+          const int c = 32 * tsub + li, r4 = 32 * qsub + 16 * h + 4 * v4;
+          CpV4 v = *reinterpret_cast<const CpV4*>(&colbuf[1][c][r4]);
+          if (ydiag) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (r4 + e > c) v[e] = 0.f;
+          }
+          *reinterpret_cast<CpV4*>(Wf + frag_off(2 * j + tsub, 2 * irow + qsub, g)) = v;
+        }
+        {
+          // W^T image: row 32 (2 i' + tsub) + li = row 32 tsub + li of the strip; k = 64 j + 32 qsub + 16 h + 4 v4 + s
+          const int rr = 32 * tsub + li, c4 = 32 * qsub + 16 * h + 4 * v4;
+          CpV4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (ydiag && rr > c4 + e) ? 0.f : colbuf[1][c4 + e][rr];
+          *reinterpret_cast<CpV4*>(Wf + tot + frag_off(2 * irow + tsub, 2 * j + qsub, g)) = v;
+        }
+      }
+      if (W3) {
+        for (int idx = tid; idx < 4 * 128; idx += 512) {
+          const int sub = idx >> 7, g = idx & 127, q2 = g >> 6, l6 = g & 63, li = l6 & 31, h = l6 >> 5;
+          const int tsub = sub >> 1, qsub = sub & 1;
+          float x8[8];
+          {
+            const int c = 32 * tsub + li, r8 = 32 * qsub + 16 * q2 + 8 * h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x8[e] = (ydiag && r8 + e > c) ? 0.f : colbuf[1][c][r8 + e];
+            store_bf3(W3, (((size_t)(2 * j + tsub) * nT + 2 * irow + qsub) * 128 + g) * 8, x8);
+          }
+          {
+            const int rr = 32 * tsub + li, c8 = 32 * qsub + 16 * q2 + 8 * h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x8[e] = (ydiag && rr > c8 + e) ? 0.f : colbuf[1][c8 + e][rr];
+            store_bf3(W3 + 3 * tot, (((size_t)(2 * irow + tsub) * nT + 2 * j + qsub) * 128 + g) * 8, x8);
+          }
+        }
+      }
     }
   }
   if (s == 0) {
@@ -465,6 +558,13 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
     }
   }
   CP_STAMP(4);
+#ifdef HB_CP_STAMPS
+  if (a.stamps && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < CP_NSTAMP; ++i) a.stamps[((size_t)ticket * 8 + w) * CP_NSTAMP + i] = cpst[i];
+    a.stamps[((size_t)a.total * 8 + (size_t)ticket * 8 + w)] = __builtin_amdgcn_s_memrealtime();   // (a clock all XCDs share)
+  }
+#endif
 
   // ---- arrival; the last workgroup writes info[] and leaves the sync words zero for the next call
   __syncthreads();

@@ -2131,9 +2131,11 @@ extern unsigned long long* hb_cp_stamps_buffer;   // diagnostic build (tools/cho
 
 // One persistent launch (chol_persist.cuh) for fp32 factor + inverse at M % 64 == 0; `ws` then carries the exchange area
 // and, behind it, the launch's sync words (zero at entry, left zero at exit: hb_cholesky_inverse_ws_elems).
-static int chol_persist_launch(const float* A, float* L, float* W, float* ws, long B, long M, int* info, hipStream_t stream) {
+static int chol_persist_launch(const float* A, float* L, float* W, float* ws, float* Wf, int bf16x3, long B, long M, int* info,
+                               hipStream_t stream) {
   CpArgs a;
   a.A = A, a.L = L, a.W = W, a.X = ws;
+  a.Wf = Wf, a.bf16x3 = bf16x3;
   a.sync = reinterpret_cast<unsigned*>(ws + B * M * M);
   a.info = info;
   a.M = (int)M, a.B = (int)B, a.nb = (int)(M / CP_NB);
@@ -2177,8 +2179,8 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, lon
   const bool fast = ((uintptr_t)L % 16 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)ws % 16 == 0) && M % CR_B == 0;
   const bool no64 = hb_debug_get("chol_no64", 0) != 0;  // diagnostic A/B switches (hb_debug_set)
   if (sizeof(T) == 4 && fast && inv && chol_persist_shape(B, M, sizeof(T)) && hb_debug_get("chol_persist", 1) != 0) {
-    const int rc = chol_persist_launch((const float*)A, (float*)L, (float*)W, (float*)ws, B, M, info, stream);
-    if (rc) return rc;
+    // (every block of L, W and of the fragment-major images is written by the launch itself: no finishing pass)
+    return chol_persist_launch((const float*)A, (float*)L, (float*)W, (float*)ws, (float*)Wf, bf16x3, B, M, info, stream);
   } else if (sizeof(T) == 4 && fast && M % C64_NB == 0 && !no64) {
     const int nrt = (int)(M / 32);
     HbSideJobs noside = {};

@@ -962,6 +962,12 @@ def _matmul_emit(plan, node):
                                        epilogue=epi))
     if host:
         plan.steps.append(lambda: H.side_flush())
+    if csn is not None:
+        # the planner paired this product with the column sums of its right operand (Plan: _colsum_of), but the product
+        # takes a matutil epilogue, which hb_matmul_colsum does not have: the absorbed reduction runs as a launch of its
+        # own (its node emits nothing by itself, _reduce_emit)
+        cout, ra = plan.out(csn.outputs[0]), csn.attrs
+        plan.steps.append(lambda: H.reduce_mid(b, ra["K1"], ra["R"], ra["K2"], op=H.RED_SUM, out=cout))
 
 
 def _sum_lead(g, t):
@@ -1545,6 +1551,9 @@ def _sgp_emit(plan, node):
                         fbar=plan.out(post[1]) if post else None,
                         part=plan.scratch((3 * units,)), units=units)
             plan._gll_fused[g.id] = (head["part"], units)
+            # the head makes THIS step read y, var and scale, which are not inputs of the sgp node: a pending side job
+            # that produces one of them (the hoisted minibatch gather of Y) must not ride on a launch behind this one
+            plan.pin_side_reads([g.inputs[0], g.inputs[2]] + ([g.inputs[3]] if len(g.inputs) > 3 else []))
     step = lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag,
                              prec=prec, a_frag=a_frag, skip_a=skip_a, head=head)
     plan.steps.append(step)
@@ -2303,6 +2312,19 @@ class Plan:
             if adopted == 3:
                 break
         return adopted > 0
+
+    def pin_side_reads(self, tensors):
+        """A step about to be emitted reads `tensors` although they are not inputs of its node (operands of a fused
+        epilogue): pending side candidates that write one of them -- directly or behind reshape / stop_gradient views --
+        stop being adoptable, i.e. they run as a launch of their own at their original position."""
+        src = set()
+        for t in tensors:
+            while t is not None:
+                src.add(t)
+                t = t.node.inputs[0] if t.node.op in ("reshape", "stop_gradient") and t.node.inputs else None
+        for c in self._side_cands:
+            if not c["cell"]["defer"] and not c.get("dead") and any(o in src for o in c["outs"]):
+                c["dead"] = True
 
     def new_info(self, n, label):
         """`n` LAPACK-style status words for one (batched) factorisation, carved from one pool so that the

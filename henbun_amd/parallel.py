@@ -96,31 +96,52 @@ class Communicator:
             if dist.is_available() and dist.is_initialized() and ws > 1:
                 dist.broadcast_object_list(token, src=0)
             handle = ctypes.c_void_p(None)
-            good = True
+            multi = dist.is_available() and dist.is_initialized() and ws > 1
+
+            def agree(flag):
+                if not multi:
+                    return bool(flag)
+                votes = [None] * ws
+                dist.all_gather_object(votes, bool(flag))
+                return all(votes)
+
+            # 1. communicator set-up, voted on BEFORE any collective is issued: the test all-reduce below is attempted
+            # only when every rank holds a communicator.  (ncclCommInitRank is itself a rendezvous: a rank whose call
+            # THROWS while its peers are still inside theirs leaves them waiting for RCCL's own timeout -- that case
+            # cannot be turned into a fallback from here; every other failure is.)
             try:
                 lib.call("hb_comm_init", ctypes.create_string_buffer(token[0], 128), rank, ws, ctypes.byref(handle))
+                made = True
+            except Exception:
+                made = False
+            good = agree(made)
+            if good:
                 comm = cls(handle, rank, ws)
                 if ws > 1:
-                    # first use, checked: (rank + 1) summed over the ranks must be R (R + 1) / 2 everywhere -- a
+                    # 2. first use, checked: (rank + 1) summed over the ranks must be R (R + 1) / 2 everywhere -- a
                     # communicator that cannot do this is dropped on EVERY rank and the step keeps torch.distributed's
                     # all_reduce (the "torch-eager" exchange), instead of training on garbage
-                    import torch
+                    try:
+                        import torch
 
-                    from . import hip_ops
+                        from . import hip_ops
 
-                    x = torch.full((256,), float(rank + 1), dtype=torch.float32, device=device)
-                    torch.cuda.synchronize(device)
-                    hip_ops.allreduce_sum(x, handle)
-                    torch.cuda.synchronize(device)
-                    good = bool((x == float(ws * (ws + 1) // 2)).all().item())
-            except Exception:
-                good = False
-            if dist.is_available() and dist.is_initialized() and ws > 1:
-                votes = [None] * ws
-                dist.all_gather_object(votes, bool(good))
-                good = all(votes)
+                        x = torch.full((256,), float(rank + 1), dtype=torch.float32, device=device)
+                        torch.cuda.synchronize(device)
+                        hip_ops.allreduce_sum(x, handle)
+                        torch.cuda.synchronize(device)
+                        fine = bool((x == float(ws * (ws + 1) // 2)).all().item())
+                    except Exception:
+                        fine = False
+                    good = agree(fine)
             if not good:
                 comm = None
+                if made and handle:
+                    # release the native communicator instead of leaking it behind the cached None
+                    try:
+                        lib.call("hb_comm_destroy", handle)
+                    except Exception:
+                        pass
         cls._cached[key] = comm
         return comm
 

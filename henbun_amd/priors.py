@@ -25,3 +25,23 @@ class Normal(Prior):
 
     def __str__(self):
         return "N(0,1)"
+
+
+def _out_of_scope(name, where):
+    class _Missing(Prior):
+        def __init__(self, *args, **kwargs):
+            raise NotImplementedError(
+                "henbun_amd.priors.%s: the reference's %s (Henbun/priors.py:%s) is outside the accelerated path "
+                "(SURVEY.md section 2, INTEGRATION.md 'Not provided'); write the term with hb.densities.* inside the "
+                "objective, or use priors.Normal with a transform" % (name, name, where))
+
+    _Missing.__name__ = name
+    return _Missing
+
+
+# reference prior classes that are NOT provided: constructing one says so instead of an AttributeError
+Gaussian = _out_of_scope("Gaussian", "55-65")
+LogNormal = _out_of_scope("LogNormal", "68-78")
+Gamma = _out_of_scope("Gamma", "81-91")
+Laplace = _out_of_scope("Laplace", "94-104")
+Uniform = _out_of_scope("Uniform", "107-116")

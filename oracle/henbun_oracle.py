@@ -231,6 +231,18 @@ def rbf_K(X, X2, lengthscales):
     return torch.exp(-square_dist(X, X2, lengthscales) / 2.0)
 
 
+def rbf_K_difference(X, X2, lengthscales):
+    """NOT the reference's form: the same kernel from the scaled coordinate DIFFERENCE, sum_d ((x_d - x2_d) / ell_d)^2
+    (what the HIP kernels evaluate).  Equal to rbf_K in exact arithmetic; in float32 the reference's
+    |a|^2 + |b|^2 - 2 a.b loses ~|a|^2 * 2^-24 absolutely, which at inputs out to 256 lengthscales leaves Kmm + 1e-5 I
+    indefinite.  Used only by the float32 evaluation of the oracle that measures what fp32 allows
+    (tests/test_model_gpu.py::test_cfg2_full_size_properties_fp32)."""
+    if X2 is None:
+        X2 = X
+    d = (X[..., :, None, :] - X2[..., None, :, :]) / lengthscales
+    return torch.exp(-torch.sum(torch.square(d), -1) / 2.0)
+
+
 def csym_rbf_K(X, X2, lengthscales):
     """gp/kernels.py:122-126."""
     if X2 is None:
@@ -393,7 +405,7 @@ class AdamTF:
 # --------------------------------------------------------------------------
 # model compositions (notebooks/GaussianProcess.ipynb:109-159)
 # --------------------------------------------------------------------------
-def svgp_elbo(params, X, Y, N_total, u_noise, eps, jitter=1e-5, q_shape="diagonal", residual="diagonal"):
+def svgp_elbo(params, X, Y, N_total, u_noise, eps, jitter=1e-5, q_shape="diagonal", residual="diagonal", K=rbf_K):
     """Sparse variational GP regression ELBO at injected noise.
 
     params: dict of RAW (pre-transform) leaves
@@ -415,7 +427,7 @@ def svgp_elbo(params, X, Y, N_total, u_noise, eps, jitter=1e-5, q_shape="diagona
         xs = sample_fullrank(mu, params["q_sqrt"], u_noise)
         kl = kl_normal(params["q_sqrt"], u_noise, xs, "fullrank")
     u = xs.reshape(P, M)
-    f = sparse_samples(X, u, z, ell, jitter, residual, eps) * torch.sqrt(k_var)
+    f = sparse_samples(X, u, z, ell, jitter, residual, eps, K=K) * torch.sqrt(k_var)
     n = X.shape[0]
     ll = torch.sum(gaussian(Y.transpose(0, 1), f, var))
     return (N_total / n) * ll - kl

@@ -515,6 +515,23 @@ def test_matern_kernels_and_sparse_gp_through_them(kern_name):
         assert rel_err(grads[mine], ref[theirs].numpy()) <= 1e-6, mine
 
 
+def test_column_sums_survive_a_product_with_a_matutil_epilogue():
+    """`X^T G` paired with `reduce_sum(G, 0)` (hb_matmul_colsum) whose square result also has a single matutil
+    consumer takes the epilogue form of the GEMM -- the absorbed column sums must then still be computed."""
+    rng = np.random.RandomState(3)
+    Xh, Gh = rng.randn(256, 64), rng.randn(256, 64)
+    for dtype in ("float64", "float32"):
+        m = hb.model.Model(dtype=dtype)
+        X, Gm = G.constant(Xh), G.constant(Gh)
+        low = G.band_part(G.matmul(X, Gm, transpose_a=True), -1, 0)
+        cs = G.reduce_sum(Gm, 0)
+        w = rng.randn(64)
+        val = G.add(G.reduce_sum(low), G.reduce_sum(G.mul(cs, G.constant(w))))
+        ref = np.tril(Xh.T @ Gh).sum() + (Gh.sum(0) * w).sum()
+        got = float(m.run(val))
+        assert abs(got - ref) <= (1e-9 if dtype == "float64" else 2e-4) * max(1.0, abs(ref)), (dtype, got, ref)
+
+
 def test_vec_to_tri_ops_on_device(golden):
     """hb_vec_to_tri / hb_tri_to_vec (the reference's disabled native op pair, tf_wraps.py:50-71) against the
     reference's own LowerTriangular.forward/backward output (golden lt_*), and each as the other's gradient."""

@@ -1188,6 +1188,30 @@ def test_gauss_ll_head_writes_the_gradient_for_f_itself(H, p, n):
         assert_close(fbar, want, dict(rtol=1e-12, atol=0) if p == "f64" else dict(rtol=3e-7, atol=0))
 
 
+def test_serial_chain_flushes_before_its_argument_block_is_exhausted(H):
+    """hb_chain_push counts the argument slots of the recorded jobs and runs them before a job that would not fit
+    (five 9-pointer likelihood heads leave 19 pointer slots; the generated kernel wants 20 free at the start of a job):
+    the six calls below used to fail inside hb_chain_flush with 'argument block exhausted', after the jobs were dropped."""
+    rng = np.random.RandomState(5)
+    n = 1000
+    xs = [dev(rng.randn(1, n), torch.float32) for _ in range(6)]
+    fs = [dev(rng.randn(1, n), torch.float32) for _ in range(6)]
+    var = dev(np.array([0.7]), torch.float32)
+    ref = [H.gauss_ll(x, f, None, var) for x, f in zip(xs, fs)]
+    outs = [tuple(torch.full_like(t, float("nan")) for t in r) for r in ref]
+    H.chain_begin()
+    try:
+        for x, f, o in zip(xs, fs, outs):
+            H.gauss_ll(x, f, None, var, out=o)
+        H.chain_end()
+    finally:
+        H.chain_discard()
+    torch.cuda.synchronize()
+    for r, o in zip(ref, outs):
+        for k in (0, 1, 3):      # ll, dmu, dvar (dscale is not written without a scale)
+            assert torch.equal(r[k], o[k]), k
+
+
 @pytest.mark.parametrize("p", ["f32", "f64"])
 @pytest.mark.parametrize("R,n", [(4, 3001), (2, 64), (7, 777)])
 def test_column_program_softmax_gate(H, p, R, n):

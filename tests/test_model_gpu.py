@@ -431,13 +431,16 @@ def test_exact_resume_save_state(tmp_path):
         o2.restore_state(path)
 
 
-def test_cfg2_full_size_properties_fp32():
-    """BASELINE cfg 2 at full per-step size (M = 512, n = 8192, fp32 -- the benchmark dtype), through properties that
-    do not need a reference run: bit-determinism of the whole forward+backward, closeness to the fp64 oracle, and the
-    defining identities of the fused factor/inverse/contraction kernels (L L^T = K + jitter I, W L = I, L A = K(z,x),
-    v = 1 - colsum(A^2))."""
+@pytest.mark.parametrize("jitter", [1e-5, 1e-4])
+def test_cfg2_full_size_properties_fp32(jitter):
+    """BASELINE cfg 2 at full per-step size (M = 512, n = 8192, fp32 -- the benchmark dtype), at the jitter bench.py
+    runs with (the reference's default 1e-5, henbunrc:11) and at 1e-4, through properties that do not need a reference
+    run: bit-determinism of the whole forward+backward, closeness to the fp64 oracle, and the defining identities of the
+    fused factor/inverse/contraction kernels (L L^T = K + jitter I, W L = I, L A = K(z,x), v = 1 - colsum(A^2)).
+    Beside the kernels' distance from the fp64 oracle the test records the distance of the ORACLE ITSELF EVALUATED IN
+    FLOAT32 (torch-CPU float32, reference op order): "as good as fp32 allows" as a measured statement."""
     cfg = hb.settings.get_settings()
-    cfg.numerics.jitter_level = 1e-4
+    cfg.numerics.jitter_level = jitter
     with hb.settings.temp_settings(cfg):
         m, data = make_svgp(20000, 512, 8192, "diagonal", "float32")
         opt = m.ELBO()
@@ -445,15 +448,53 @@ def test_cfg2_full_size_properties_fp32():
         v1, g1 = opt.gradients(minibatch_size=8192, indices=data[5])
         v2, g2 = opt.gradients(minibatch_size=8192, indices=data[5])
         assert v1 == v2 and all(np.array_equal(g1[k], g2[k]) for k in g1), "same inputs must give the same bits"
-        fn, params = oracle_svgp(m, data, 1e-4, "diagonal")
+        fn, params = oracle_svgp(m, data, jitter, "diagonal")
         ref_val, ref = O.grads_of(fn, params)
-    # observed on MI355X (round 3): ELBO 6.5e-6 (inside the 1e-5 bar in fp32); worst 32-entry tile of z 1.3e-3,
-    # lengthscales 8.4e-5, q_mu 2.0e-4, q_sqrt 2.0e-4, k_var 2.7e-7, var 1.0e-5
-    observe("cfg2_fullsize_fp32/ELBO", abs(v1 - ref_val.item()) / abs(ref_val.item()), 5e-5)
-    bound = {"model.gp.z": 1e-2, "model.gp.kern.lengthscales": 6e-4, "model.u.q_mu": 1.9e-3, "model.u.q_sqrt": 1.9e-3,
-             "model.k_var": 2e-5, "model.var": 1e-4}   # k_var: a scalar, 2.7e-7 (round 3) .. 6.6e-6 (round 4, persistent Cholesky: another rounding of L)
+    tag = "cfg2_fullsize_fp32[j%g]/" % jitter
+    # observed on MI355X (round 4, profiles/r04_observed_errors.txt), jitter 1e-4 / 1e-5 (cond(Kmm) ten times larger):
+    # ELBO 5.9e-6 / 1.8e-5; worst 32-entry tile of z 1.3e-3 / 5.2e-3, lengthscales 2.4e-4 / 3.3e-4, q_mu 1.8e-4 / 5.3e-4,
+    # q_sqrt 1.6e-4 / 5.8e-4, k_var 1.4e-7 .. 6.6e-6 / 2.3e-5, var 9.5e-6 / 2.9e-5
+    observe(tag + "ELBO", abs(v1 - ref_val.item()) / abs(ref_val.item()), 5e-5)
+    if jitter >= 1e-4:
+        bound = {"model.gp.z": 1e-2, "model.gp.kern.lengthscales": 1.5e-3, "model.u.q_mu": 1.8e-3, "model.u.q_sqrt": 1.6e-3,
+                 "model.k_var": 2e-5, "model.var": 1e-4}
+    else:
+        bound = {"model.gp.z": 4e-2, "model.gp.kern.lengthscales": 3e-3, "model.u.q_mu": 5e-3, "model.u.q_sqrt": 5e-3,
+                 "model.k_var": 2e-4, "model.var": 3e-4}
+    mine_err = {}
     for mine, theirs in NAMES:
-        observe("cfg2_fullsize_fp32/" + mine, tile_err(g1[mine], ref[theirs].numpy()), bound[mine])
+        mine_err[mine] = observe(tag + mine, tile_err(g1[mine], ref[theirs].numpy()), bound[mine])
+    # ---- the oracle in float32 at the same point.  (1) the reference's own distance form |a|^2 + |b|^2 - 2 a.b: with
+    # inputs out to 256 lengthscales its float32 rounding (~4e-3 absolute in K) leaves Kmm + jitter I indefinite -- the
+    # reference graph cannot be evaluated in float32 at this configuration at all; (2) the difference form (what the HIP
+    # kernels evaluate), reference op order otherwise: its distance from the float64 oracle is the yardstick.
+    X, Y, Z, eps, u, idx = data
+    f32 = lambda a: O.T(a, dtype=torch.float32)
+    p32 = {k: v.to(torch.float32) for k, v in params.items()}
+
+    def fn32(K):
+        return lambda p: O.svgp_elbo(p, f32(X[idx]), f32(Y[idx]), float(X.shape[0]), f32(u), f32(eps[idx]), jitter=jitter,
+                                     q_shape="diagonal", residual="diagonal", K=K)
+
+    try:
+        v_ref32, _ = O.grads_of(fn32(O.rbf_K), p32)
+        ref_form = "evaluates: ELBO %.3e from fp64" % (abs(v_ref32.item() - ref_val.item()) / abs(ref_val.item()))
+    except Exception as e:      # torch.linalg.cholesky: not positive definite
+        ref_form = "fails (%s)" % type(e).__name__
+    v32, g32 = O.grads_of(fn32(O.rbf_K_difference), p32)
+    print("float32 oracle at cfg 2, jitter %g: reference distance form %s; difference form: ELBO %.3e from fp64 (HIP %.3e)"
+          % (jitter, ref_form, abs(v32.item() - ref_val.item()) / abs(ref_val.item()), abs(v1 - ref_val.item()) / abs(ref_val.item())))
+    for mine, theirs in NAMES:
+        e32 = tile_err(g32[theirs].numpy(), ref[theirs].numpy())
+        print("   %-28s float32 oracle %.3e   HIP fp32 %.3e" % (mine, e32, mine_err[mine]))
+        # (recorded beside the kernels' values in profiles/r04_observed_errors.txt; observed 1e-4 / 1e-5: z 3.3e-4 / 2.9e-3,
+        # lengthscales 5.3e-5 / 5.2e-4, q_mu 2.6e-5 / 1.3e-4, q_sqrt 3.2e-5 / 1.5e-4, k_var 4.7e-7 / 1.4e-5, var 9.7e-7 / 1.9e-5)
+        observe(tag + "oracle_f32/" + mine, e32, 10 * {"model.gp.z": 2.9e-3, "model.gp.kern.lengthscales": 5.2e-4, "model.u.q_mu": 1.3e-4,
+                                                        "model.u.q_sqrt": 1.5e-4, "model.k_var": 1.4e-5, "model.var": 1.9e-5}[mine])
+        # the kernels stay within a small multiple of what a float32 evaluation of the reference op order gives
+        # (floor: a leaf the float32 oracle happens to hit almost exactly)
+        # observed ratio HIP / float32 oracle: 0.14 .. 9.5 over the six leaves and both jitters
+        observe(tag + "vs_oracle_f32/" + mine, mine_err[mine] / max(e32, 1e-6), 30.0)
     # kernel identities at the same size
     H = m._session.H
     rng = np.random.RandomState(0)

@@ -59,6 +59,15 @@ def test_square_dist_and_rbf_kdiag(golden):
     assert close(O.rbf_Kdiag(X), g["k_rbf_diag"]) and close(O.rbf_Kdiag(Xb), g["k_rbf_diag_b"])
 
 
+def test_difference_form_of_the_rbf_kernel_is_the_reference_kernel(golden):
+    # rbf_K_difference (the float32 yardstick of test_cfg2_full_size_properties_fp32) == the executed reference RefRBF
+    g = golden
+    X, X2, l2 = T(g["k_X"]), T(g["k_X2"]), T(g["k_l2"])
+    assert close(O.rbf_K_difference(X, None, l2), g["k_rbf2_XX"], atol=1e-13)
+    assert close(O.rbf_K_difference(X, X2, l2), g["k_rbf2_XX2"], atol=1e-13)
+    assert close(O.rbf_K_difference(T(g["k_Xb"]), None, l2), g["k_rbf2_b"], atol=1e-13)
+
+
 def test_golden_provenance_and_byte_identical_regeneration(golden):
     """The fixture records which reference definitions produced it; when the reference is mounted
     (build container) regenerating it must give the committed bytes."""

@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&A, (size_t)M * M * 4); (void)hipMalloc(&L, (size_t)M * M * 4); (void)hipMalloc(&W, (size_t)M * M * 4);
   (void)hipMalloc(&ws, wse * 4); (void)hipMemset(ws, 0, wse * 4);
   (void)hipMalloc(&info, 4);
-  (void)hipMalloc(&hb_cp_stamps_buffer, (size_t)nwg * 8 * 64 * 8);
+  (void)hipMalloc(&hb_cp_stamps_buffer, ((size_t)nwg * 8 * 16 + (size_t)nwg * 8) * 8);
   (void)hipMemcpy(A, h.data(), (size_t)M * M * 4, hipMemcpyHostToDevice);
   {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -32,45 +32,32 @@ int main(int argc, char** argv) {
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     printf("hb_cholesky_inverse_f32 (stamped build), M = %d: %.1f us per call incl. the tril pass\n", M, ms * 10.0);
   }
-  (void)hipMemset(hb_cp_stamps_buffer, 0, (size_t)nwg * 8 * 64 * 8);
+  const size_t nst = (size_t)nwg * 8 * 16 + (size_t)nwg * 8;
+  (void)hipMemset(hb_cp_stamps_buffer, 0, nst * 8);
   hb_cholesky_inverse_f32(A, L, W, 1, M, info, ws, nullptr, 0, 0);
   (void)hipDeviceSynchronize();
   int hinfo; (void)hipMemcpy(&hinfo, info, 4, hipMemcpyDeviceToHost);
-  std::vector<unsigned long long> st((size_t)nwg * 8 * 64);
+  std::vector<unsigned long long> st(nst);
   (void)hipMemcpy(st.data(), hb_cp_stamps_buffer, st.size() * 8, hipMemcpyDeviceToHost);
-  unsigned long long t0 = ~0ull, t1 = 0;
-  for (auto v : st) if (v) { t0 = std::min(t0, v); t1 = std::max(t1, v); }
-  printf("info %d; first stamp -> last stamp %llu cycles (s_memtime ticks)\n", hinfo, t1 - t0);
-  auto S = [&](int ticket, int w, int slot) -> long long {   // s_memtime differs between XCDs: relative to the workgroup's own start
-    const unsigned long long v = st[((size_t)ticket * 8 + w) * 64 + slot], base = st[((size_t)ticket * 8 + 0) * 64 + 0];
+  printf("info %d.  s_memtime differs between XCDs: every number is cycles since the workgroup's own first stamp.\n", hinfo);
+  auto S = [&](int ticket, int w, int slot) -> long long {
+    const unsigned long long v = st[((size_t)ticket * 8 + w) * 16 + slot], base = st[((size_t)ticket * 8 + 0) * 16 + 0];
     return v ? (long long)(v - base) : -1;
   };
   // wave ids: diag (0,q): w = q; strip (1,q): w = 4 + (3 - q)
-  printf("critical workgroups (column block j, strip 0): cycles since the first stamp of the launch\n");
+  printf("critical workgroups (column block j, strip 0; B = 1: ticket j * nb when workgroups start in order)\n");
   for (int j = 0; j < nb; ++j) {
-    const int t = j * nb;   // B = 1: ticket = j * nb + s when workgroups start in order
-    printf(" j=%d start %6lld |", j, S(t, 0, 0));
-    if (j > 0) {
-      printf(" last panel chunks seen (diag wave q=0):");
-      for (int c = 0; c < 4; ++c) printf(" %6lld", S(t, 0, 8 + 4 * ((j - 1) & 7) + c));
-      printf(" | their MFMAs done:");
-      for (int c = 0; c < 4; ++c) printf(" %6lld", S(t, 0, 40 + c));
+    const int t = j * nb;
+    printf(" j=%d: last chunk of panel j-1 seen %6lld, its MFMAs done %6lld, updates done %6lld (diag wave q0)\n", j, S(t, 0, 5), S(t, 0, 6), S(t, 0, 1));
+    for (int q = 0; q < 4; ++q)
+      printf("      diag  q%d: followed %6lld  row-per-lane %6lld  sub-groups published %6lld %6lld %6lld %6lld\n", q, S(t, q, 2), S(t, q, 11),
+             S(t, q, 7), S(t, q, 8), S(t, q, 9), S(t, q, 10));
+    for (int q = 0; q < 4; ++q) {
+      const int w = 4 + (3 - q);
+      printf("      strip q%d: followed %6lld  row-per-lane %6lld  sub-groups published %6lld %6lld %6lld %6lld  chunk drained %6lld  flag %6lld\n", q,
+             S(t, w, 2), S(t, w, 11), S(t, w, 7), S(t, w, 8), S(t, w, 9), S(t, w, 10), S(t, w, 12), S(t, w, 3));
     }
-    printf("\n      diag waves: updates done / followed / own group done:");
-    for (int q = 0; q < 4; ++q) printf("  q%d %6lld %6lld %6lld", q, S(t, q, 1), S(t, q, 2), S(t, q, 3));
-    printf("\n      strip waves:                                        ");
-    for (int q = 0; q < 4; ++q) { const int w = 4 + (3 - q); printf("  q%d %6lld %6lld %6lld", q, S(t, w, 1), S(t, w, 2), S(t, w, 3)); }
-    printf("\n      outputs stored %6lld\n", S(t, 0, 4));
-    if (j == 1) {
-      for (int q = 0; q < 4; ++q) {
-        const int w = 4 + (3 - q);
-        printf("      pivot q%d publishes sub-groups at:", q);
-        for (int sg = 0; sg < 4; ++sg) printf(" %6lld", S(t, q, 56 + sg));
-        printf("   strip q%d per sub-group (before wait, after wait, published):", q);
-        for (int sg = 0; sg < 4; ++sg) printf("  %6lld %6lld %6lld", S(t, w, 44 + 3 * sg), S(t, w, 45 + 3 * sg), S(t, w, 46 + 3 * sg));
-        printf("\n");
-      }
-    }
+    printf("      outputs stored %6lld\n", S(t, 0, 4));
   }
   return 0;
 }

@@ -18,7 +18,7 @@ static int fails = 0;
   } while (0)
 
 int main() {
-  EXPECT(hb_version() == 1, "hb_version");
+  EXPECT(hb_version() == HB_ABI_VERSION, "hb_version");
   float dummy[64] = {0};
   float* fp = dummy;   // a host pointer standing in for device memory: nothing below dereferences it on the host
   // ---- program validator (host only)
