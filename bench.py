@@ -435,12 +435,18 @@ def main():
         shapes = "" if node is None else " ".join("x".join(str(d) for d in t.shape) or "scalar" for t in node.inputs[:4])
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
+            # the newest per-round table (tools/pmc_traffic.sh -> tools/make_traffic_json.py): PMC counters of an earlier
+            # run of this same command, regenerated with the kernels -- the source file is named in the line
+            import glob
+
+            tfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]
+            with open(tfile) as fh:
                 pmc = json.load(fh)
             rec = pmc.get(args.config, {}).get(lab)
             if rec:
-                traffic, traffic_src = rec["traffic_bytes"], "profiles/r03_pmc_traffic.json (%s)" % rec.get("kernel", lab)
-        except (OSError, KeyError, ValueError):
+                traffic = rec["traffic_bytes"]
+                traffic_src = "profiles/%s (%s)" % (os.path.basename(tfile), rec.get("kernel", lab))
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         roofline = {"kernel": "%s [%s]" % (lab, shapes), "bound": bound, "achieved": achieved, "peak": pk, "unit": unit,
                     "frac": achieved / pk, "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_us": us,

@@ -404,6 +404,7 @@ class Rng:
         self.reseed(seed, stream_id)
 
     def reseed(self, seed, stream_id=0):
+        self.seed, self.stream_id = int(seed), int(stream_id)
         _lib.lib().call("hb_rng_init", _p(self.state), self.nlanes, int(seed) & (2**64 - 1),
                         int(stream_id) & (2**64 - 1), stream())
 

@@ -60,8 +60,9 @@ def well_conditioned_gram(rng, B, M, spacing=1.5, nugget=0.1):
 # ------------------------------------------------------------------------------------------------ 1. kernels
 @pytest.mark.parametrize("B,M", [(1, 512), (2, 256), (1, 1024), (3, 64)])
 def test_fp32_cholesky_inverse_chain_against_fp64(H, B, M):
-    """hb_cholesky_inverse_f32 (chol chain kernels + fused inverse + fragment-major images) on fp32-representable
-    SPD matrices with cond ~ 10: L and W = L^-1 against numpy fp64, worst 32 x 32 tile."""
+    """hb_cholesky_inverse_f32 (round 4: ONE persistent launch, csrc/chol_persist.cuh -- factor, fused inverse and the
+    fragment-major images; the launch-chain form behind hb_debug_set chol_persist 0 as well) on fp32-representable SPD
+    matrices with cond ~ 10: L and W = L^-1 against numpy fp64, worst 32 x 32 tile."""
     rng = np.random.RandomState(100 + M)
     K, _ = well_conditioned_gram(rng, B, M)
     assert np.linalg.cond(K[0]) < 1e2
@@ -75,9 +76,22 @@ def test_fp32_cholesky_inverse_chain_against_fp64(H, B, M):
     # observed on MI355X (round 3): L 6.1e-8 .. 1.9e-7, W 9.5e-8 .. 3.3e-7
     observe("chol_inverse_f32/L[%d,%d]" % (B, M), tile_err(Lh, Lr), 2e-6)
     observe("chol_inverse_f32/W[%d,%d]" % (B, M), tile_err(Wh, Wr), 3e-6)
-    # plain factorisation: same kernels without the inverse rows
+    # the fragment-major images hold exactly the row-major W (include/henbun_hip.h: Wfrag)
+    fr = host(frag).reshape(2, B, M // 32, M // 32, 4, 2, 32, 4)     # [image][b][t][Q][v][h][li][s]
+    img = np.transpose(fr, (0, 1, 2, 6, 3, 5, 4, 7)).reshape(2, B, M, M)   # [t][li] x [Q][h][v][s] = [row][32Q + 16h + 4v + s]
+    assert np.array_equal(img[0], Wh) and np.array_equal(img[1], np.transpose(Wh, (0, 2, 1)))
+    # the launch-chain form (the fp64 / ragged-size path, forced here) against the same reference, and the plain
+    # factorisation: the chain's kernels without the inverse rows, bit for bit
+    H.debug_set("chol_persist", 0)
+    try:
+        Lc, Wc, infoc = H.cholesky_inverse(dev(K))
+    finally:
+        H.debug_set("chol_persist", 1)
+    assert not infoc.cpu().numpy().any()
+    observe("chol_inverse_f32/chain/L[%d,%d]" % (B, M), tile_err(host(Lc).reshape(B, M, M), Lr), 2e-6)
+    observe("chol_inverse_f32/chain/W[%d,%d]" % (B, M), tile_err(host(Wc).reshape(B, M, M), Wr), 3e-6)
     L2, info2 = H.cholesky(dev(K))
-    assert not info2.cpu().numpy().any() and torch.equal(L2.reshape(L.shape), L)
+    assert not info2.cpu().numpy().any() and torch.equal(L2.reshape(Lc.shape), Lc)
 
 
 def _sgp_reference(Lr, z, ell, x, u, eps, fbar, mode):

@@ -133,6 +133,121 @@ def test_svgp_adam_trajectory_matches_oracle(capture, fuse):
         assert rel_err(got[k], ref.numpy()) <= 1e-6, k
 
 
+def _two_rank_sessions(N, M, n, lr, seed=3):
+    """Two models in ONE process set up as rank 0 / rank 1 of a world of two (no second process, no process group): shard
+    of the data (parallel.shard_rows), rank-distinct `local` / `index` streams (parallel.rng_stream_ids), the global data
+    count in the objective, dp_reduce='mean', the data-parallel tail built by the optimiser (pack -> exchange -> Adam,
+    eager form).  The exchange itself -- what the all-reduce returns -- is done by the test: the two flat buffers are added."""
+    from henbun_amd import parallel
+
+    rng = np.random.RandomState(seed)
+    X, Y, Z = svgp_data(N, M, seed)
+    eps, u = rng.randn(N), rng.randn(M)
+    ranks = []
+    for r in range(2):
+        b, e = parallel.shard_rows(N, r, 2)
+        np.random.seed(seed)                       # every rank starts from the same parameters
+        m = SVGP(X=X[b:e], Y=Y[b:e], Z=Z, eps=eps[b:e], dtype="float64")
+        m.N = N                                     # the objective estimates the FULL-data ELBO on every rank
+        m.gp.kern.lengthscales = np.ones(1) * 0.9
+        m.k_var = np.ones(1) * 1.3
+        m.var = np.ones(1) * 0.4
+        m.u.inject_noise(u)                         # the global noise agrees across ranks
+        m.initialize()
+        sess = m._session
+        sess.rank, sess.world_size = r, 2           # (after the layout exists: nothing is broadcast)
+        sess.reseed(sess.seed)
+        assert sess.rngs["global"].stream_id == 0 and sess.rngs["local"].stream_id == parallel.rng_stream_ids(r)["local"]
+        idx = rng.randint(0, e - b, n)
+        opt = m.ELBO()
+        opt.compile(optimizer=tf.train.AdamOptimizer(lr), dp_reduce="mean")
+        plan = opt._get_plan("opt", n)
+        opt._apply_indices(plan, idx)
+        assert plan.dp_mode in ("rccl-eager", "torch-eager") and len(plan.eager_tail) == 3
+        ranks.append(dict(m=m, sess=sess, opt=opt, plan=plan, idx=idx, lo=b))
+    return ranks, (X, Y, Z, eps, u)
+
+
+def _two_rank_step(ranks, break_rank=None):
+    """forward + backward + pack on both ranks, the test-side sum of the two flat buffers, Adam on both ranks."""
+    for rk in ranks:
+        rk["plan"].run()
+    if break_rank is not None:       # a factorisation failed on one rank: its status word goes non-zero before the pack
+        with ranks[break_rank]["plan"]._on_stream():
+            ranks[break_rank]["plan"].info_words()[:1].fill_(7)
+    for rk in ranks:
+        with rk["plan"]._on_stream():
+            rk["plan"].eager_tail[0]()                       # hb_dp_pack
+    torch.cuda.synchronize()
+    parts = [rk["plan"].gflat.clone() for rk in ranks]
+    total = parts[0] + parts[1]                              # what ONE all-reduce(sum) of the flat buffer returns
+    for rk in ranks:
+        rk["plan"].gflat.copy_(total)
+    torch.cuda.synchronize()
+    for rk in ranks:
+        with rk["plan"]._on_stream():
+            rk["plan"].eager_tail[2]()                       # hb_adam_step with gscale = -1/2
+    torch.cuda.synchronize()
+    return parts, total
+
+
+def test_two_rank_data_parallel_step_equals_the_oracle_on_the_pooled_minibatch():
+    """the N > 1 step is the right step.  Two ranks' packed gradients, summed (the all-reduce) and
+    scaled by dp_reduce='mean' inside hb_adam_step, equal the oracle's gradient of the ELBO on the POOLED 2 n minibatch,
+    and the updated parameters equal the oracle's TF-formula Adam step on it (fp64, injected noise, <= 1e-5); both ranks
+    end bit-identical.  Then the failure case: rank 1's factorisation fails => neither rank updates, both latch it."""
+    N, M, n, lr = 3000, 48, 400, 0.01
+    cfg = hb.settings.get_settings()
+    cfg.numerics.jitter_level = 1e-5
+    cfg.runtime.force_dp = True
+    cfg.runtime.dp_exchange = "eager"
+    with hb.settings.temp_settings(cfg):
+        ranks, (X, Y, Z, eps, u) = _two_rank_sessions(N, M, n, lr)
+        s0 = ranks[0]["sess"]
+        P = s0.theta.numel()
+        theta_before = s0.theta.clone()
+        assert torch.equal(theta_before, ranks[1]["sess"].theta)
+        # the oracle on the pooled minibatch (rows of rank 0's draw, then rank 1's)
+        rows = np.concatenate([rk["lo"] + rk["idx"] for rk in ranks])
+        m0 = ranks[0]["m"]
+        params = {"z": O.T(s0.read_raw(m0.gp.z)), "ell_raw": O.T(s0.read_raw(m0.gp.kern.lengthscales)),
+                  "q_mu": O.T(s0.read_raw(m0.u.q_mu)).reshape(1, M), "q_sqrt": O.T(s0.read_raw(m0.u.q_sqrt)),
+                  "k_var_raw": O.T(s0.read_raw(m0.k_var)), "var_raw": O.T(s0.read_raw(m0.var))}
+        fn = lambda p: O.svgp_elbo(p, O.T(X[rows]), O.T(Y[rows]), float(N), O.T(u), O.T(eps[rows]), jitter=1e-5)
+        ref_val, ref_g = O.grads_of(fn, params)
+        parts, total = _two_rank_step(ranks)
+        # (1) the mean of the two ranks' objectives is the pooled ELBO; no failure flag
+        assert abs(total[P].item() / 2 - ref_val.item()) <= 1e-9 * abs(ref_val.item())
+        assert total[P + 1].item() == 0
+        # (2) summed gradient / 2 == the oracle's gradient on the pooled minibatch, leaf by leaf
+        off = {id(v): (o, sz) for v, o, sz in s0._layout}
+        leaf = {"z": m0.gp.z, "ell_raw": m0.gp.kern.lengthscales, "q_mu": m0.u.q_mu, "q_sqrt": m0.u.q_sqrt,
+                "k_var_raw": m0.k_var, "var_raw": m0.var}
+        for k, v in leaf.items():
+            o, sz = off[id(v)]
+            assert rel_err(total[o:o + sz].cpu().numpy() / 2, ref_g[k].numpy()) <= 1e-5, k
+        # ... and the two ranks' own gradients differ (different shards, different rows): the sum is not a formality
+        assert not torch.equal(parts[0][:P], parts[1][:P])
+        # (3) the update: both ranks bit-identical, equal to the oracle's TF-formula Adam step on the pooled gradient
+        assert torch.equal(s0.theta, ranks[1]["sess"].theta) and not torch.equal(s0.theta, theta_before)
+        names = list(params)
+        leaves = [params[k].clone() for k in names]
+        O.AdamTF(leaves, lr=lr).step([-ref_g[k] for k in names])
+        for k, refp in zip(names, leaves):
+            assert rel_err(s0.read_raw(leaf[k]), refp.numpy()) <= 1e-6, k
+        # (4) failure containment across ranks: rank 1's status word is non-zero => the flag slot of the SUM is non-zero on
+        # both ranks, neither updates, both latch the failure (hb_adam_step), and optimize() would raise on both
+        theta_good = s0.theta.clone()
+        _, total = _two_rank_step(ranks, break_rank=1)
+        assert total[P + 1].item() != 0
+        for rk in ranks:
+            assert torch.equal(rk["sess"].theta, theta_good)
+            step, what = (int(x) for x in rk["plan"].fail.cpu().numpy())
+            assert step != 0
+            with pytest.raises(hb.CholeskyError):
+                rk["opt"]._check_step_failure(rk["plan"])
+
+
 def test_amortised_fp64_parity_and_training():
     np.random.seed(5)
     rng = np.random.RandomState(0)

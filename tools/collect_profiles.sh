@@ -1,23 +1,23 @@
 #!/bin/bash
-# Copy the outputs of tools/final_measurements.sh (gpurun_out/r3final) into profiles/ under their round-3 names.
+# Copy the outputs of tools/final_measurements.sh (gpurun_out/r4final) into profiles/ under their round-3 names.
 set -e
-s=gpurun_out/r3final
+s=gpurun_out/r4final
 p=profiles
-cp $s/stream_peak.txt $p/r03_stream_peak.txt
-cp $s/bench_cfg2.json $p/r03_bench_cfg2_1gpu.json
-for c in cfg2_bf16x3 cfg3 cfg3_tripack cfg4 cfg5 cfg5_bf16x3; do cp $s/bench_$c.json $p/r03_bench_${c}_1gpu.json; done
-cp $s/cfg2/kernel_stats.csv $p/r03_rocprofv3_kernel_stats_bench_cfg2.csv
-cp $s/cfg2/summary.txt $p/r03_rocprofv3_summary_bench_cfg2.txt
-cp $s/cfg4/kernel_stats.csv $p/r03_rocprofv3_kernel_stats_bench_cfg4.csv
-cp $s/cfg4/summary.txt $p/r03_rocprofv3_summary_bench_cfg4.txt
-cp $s/cfg5/kernel_stats.csv $p/r03_rocprofv3_kernel_stats_bench_cfg5.csv
-cp $s/cfg5/summary.txt $p/r03_rocprofv3_summary_bench_cfg5.txt
-cp $s/plan_cfg5.txt $p/r03_plan_cfg5.txt
-grep -v amdgpu.ids $s/bench_fwd_bwd.txt > $p/r03_contractions_fwd_bwd.txt
-cp $s/bw_rows.txt $p/r03_bw_rows.txt
-cp $s/plan_cfg2.txt $p/r03_plan_cfg2.txt
-cp $s/pmc_cfg2/pmc_kernels.txt $p/r03_pmc_cfg2_kernels.txt
-cp $s/pmc_cfg4/pmc_kernels.txt $p/r03_pmc_cfg4_kernels.txt
-python tools/make_traffic_json.py cfg2=$s/pmc_cfg2 cfg4=$s/pmc_cfg4 > $p/r03_pmc_traffic.json
-cp $s/chol_stamps.txt $p/r03_chol_panel_phase_stamps.txt
+cp $s/stream_peak.txt $p/r04_stream_peak.txt
+cp $s/bench_cfg2.json $p/r04_bench_cfg2_1gpu.json
+for c in cfg2_bf16x3 cfg3 cfg3_tripack cfg4 cfg5 cfg5_bf16x3; do cp $s/bench_$c.json $p/r04_bench_${c}_1gpu.json; done
+cp $s/cfg2/kernel_stats.csv $p/r04_rocprofv3_kernel_stats_bench_cfg2.csv
+cp $s/cfg2/summary.txt $p/r04_rocprofv3_summary_bench_cfg2.txt
+cp $s/cfg4/kernel_stats.csv $p/r04_rocprofv3_kernel_stats_bench_cfg4.csv
+cp $s/cfg4/summary.txt $p/r04_rocprofv3_summary_bench_cfg4.txt
+cp $s/cfg5/kernel_stats.csv $p/r04_rocprofv3_kernel_stats_bench_cfg5.csv
+cp $s/cfg5/summary.txt $p/r04_rocprofv3_summary_bench_cfg5.txt
+cp $s/plan_cfg5.txt $p/r04_plan_cfg5.txt
+grep -v amdgpu.ids $s/bench_fwd_bwd.txt > $p/r04_contractions_fwd_bwd.txt
+cp $s/bw_rows.txt $p/r04_bw_rows.txt
+cp $s/plan_cfg2.txt $p/r04_plan_cfg2.txt
+cp $s/pmc_cfg2/pmc_kernels.txt $p/r04_pmc_cfg2_kernels.txt
+cp $s/pmc_cfg4/pmc_kernels.txt $p/r04_pmc_cfg4_kernels.txt
+python tools/make_traffic_json.py cfg2=$s/pmc_cfg2 cfg4=$s/pmc_cfg4 > $p/r04_pmc_traffic.json
+cp $s/chol_persist_stamps.txt $p/r04_chol_persist_stamps.txt
 ls -la $p | grep r03

@@ -5,7 +5,7 @@ divided by the dispatches of the chain's once-per-step kernel."""
 import json, sys
 
 GROUPS = {  # plan label -> (once-per-step kernel, kernel-name fragments of the chain)
-    "cholesky": ("tril_inplace_kernel", ["chol_", "tril_inplace_kernel"]),
+    "cholesky": ("chol_persist_kernel", ["chol_", "tril_inplace_kernel"]),   # (round 3: once-per-step kernel tril_inplace_kernel)
     "sgp": ("sgp_finish_part_kernel", ["sgp_A_", "sgp_finish_part_kernel", "sgp_fwd"]),
     "sgp_grad": ("sgp_bwd_finish_kernel", ["sgp_kbar", "sgp_strip_finish", "sgp_lbar", "sgp_bwd", "sgp_rowgrad"]),
     "matmul": ("matmul_kernel<float, false, false", ["matmul_kernel", "matmul_splitk_finish", "matmul_wgk"]),
