@@ -28,6 +28,12 @@ _SIGS = {
     "hb_debug_set": [c_char_p, L],
     "hb_debug_clear": [],
     "hb_cholesky_inverse_ws_elems": [L, L, I],
+    "hb_cholesky_persistent_shape": [L, L, I],
+    "hb_mlp2_sample_supported": [L, L, L, L, L, I],
+    "hb_mlp2_sample_ws_elems": [L, L, L],
+    "hb_mlp2_sample_fwd_f32": [P, P, P, P, P, I, P, P, L, P, P, P, P, L, L, L, P, P],
+    "hb_mlp2_sample_bwd_f32": [P, P, P, P, I, P, P, P, P, P, P, P, P, P, L, L, L, P, P],
+    "hb_gram_cholesky_inverse_f32": [I, P, L, P, L, L, L, D, P, P, L, L, P, P, P, I, P],
     "hb_last_error_string": [],
     "hb_device_info": [P, I, P],
     "hb_graph_begin_capture": [P],
@@ -62,7 +68,7 @@ _SIGS = {
     "hb_comm_destroy": [P],
 }
 _RESTYPES = {"hb_last_error_string": c_char_p, "hb_sgp_ws_elems": c_long, "hb_ewise_prog_image_bytes": c_long,
-             "hb_sgp_head_units": c_long, "hb_cholesky_inverse_ws_elems": c_long}
+             "hb_sgp_head_units": c_long, "hb_cholesky_inverse_ws_elems": c_long, "hb_mlp2_sample_ws_elems": c_long}
 
 # entry points that exist as _f32 and _f64
 _TYPED = {

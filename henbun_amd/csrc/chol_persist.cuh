@@ -40,6 +40,7 @@
 #pragma once
 #include "common.cuh"
 #include "side_jobs.cuh"
+#include "gram_value.cuh"
 
 #define CP_NB 64       // panel width = rows per row block
 #define CP_G 16        // columns per wave
@@ -59,6 +60,12 @@ struct CpArgs {
   float* X;          // exchange area, B*M*M floats
   unsigned* sync;    // CP_HDR + roundup4(B) + 4*B*nb*nb words, zero at entry, zero at exit
   int* info;
+  // A == nullptr: the matrix is K(X, X) + gdiag I of a stationary kernel, synthesised tile by tile (gram_value.cuh)
+  const float* gX;
+  const float* gell;
+  long gsX, gsEll, gdl, gd;
+  int gkind;
+  float gdiag;
   float* Wf;         // nullable: the fragment-major images of W and W^T (and the bf16x3 planes behind them)
   int bf16x3;
   int M, B, nb, total;   // total = number of workgroups of the factorisation (side-job blocks come after them)
@@ -172,7 +179,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
   const bool ydiag = stripY && irow == j;    // rows of the identity that start in this column block
 
   const size_t mm = (size_t)M * M;
-  const float* Ab = a.A + (size_t)b * mm;
+  const float* Ab = a.A ? a.A + (size_t)b * mm : nullptr;
   float* Lb = a.L + (size_t)b * mm;
   float* Wb = inv ? a.W + (size_t)b * mm : nullptr;
   unsigned* fail = a.sync + CP_HDR + b;
@@ -196,7 +203,20 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (fromA && (r == 1 || t >= q)) {   // tiles of the diagonal block strictly above the diagonal are never read
-        R[t] = *reinterpret_cast<const CpV4*>(Ab + (size_t)(CP_NB * rb + 16 * t + i16) * M + CP_NB * j + CP_G * q + 4 * g4);
+        const int row = CP_NB * rb + 16 * t + i16, col0 = CP_NB * j + CP_G * q + 4 * g4;
+        if (a.A) {
+          R[t] = *reinterpret_cast<const CpV4*>(Ab + (size_t)row * M + col0);
+        } else {
+          const float* Xb = a.gX + (size_t)b * a.gsX;
+          const float* eb = a.gell + (size_t)b * a.gsEll;
+          CpV4 kv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = gram_value<float>(a.gkind, Xb + (size_t)row * a.gd, Xb + (size_t)(col0 + e) * a.gd, eb, a.gdl, a.gd);
+            kv[e] = row == col0 + e ? v + a.gdiag : v;
+          }
+          R[t] = kv;
+        }
       } else {
         CpV4 z = {0.f, 0.f, 0.f, 0.f};
         if (r == 1 && ydiag) {

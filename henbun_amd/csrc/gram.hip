@@ -9,22 +9,7 @@
 #include "common.cuh"
 #include "../../include/henbun_hip.h"
 #include "chain.cuh"   // serial chains: the lengthscale fold may be recorded instead of launched
-
-template <typename T>
-__device__ __forceinline__ T gram_value(int kind, const T* __restrict__ xi, const T* __restrict__ xj,
-                                        const T* __restrict__ ell, long dl, long d) {
-  T r2 = T(0), r2m = T(0);
-  for (long k = 0; k < d; ++k) {
-    const T il = T(1) / ell[dl == 1 ? 0 : k];
-    const T a = xi[k] * il, b = xj[k] * il;
-    r2 += (a - b) * (a - b);
-    r2m += (a + b) * (a + b);
-  }
-  if (kind == HB_KERN_SQDIST) return r2;
-  T v = hb_exp(T(-0.5) * r2);
-  if (kind == HB_KERN_CSYM_RBF) v += hb_exp(T(-0.5) * r2m);
-  return v;
-}
+#include "gram_value.cuh"
 
 template <typename T>
 __global__ void __launch_bounds__(256) gram_fwd_kernel(int kind, const T* __restrict__ X, long sX,

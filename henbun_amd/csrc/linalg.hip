@@ -2131,10 +2131,18 @@ extern unsigned long long* hb_cp_stamps_buffer;   // diagnostic build (tools/cho
 
 // One persistent launch (chol_persist.cuh) for fp32 factor + inverse at M % 64 == 0; `ws` then carries the exchange area
 // and, behind it, the launch's sync words (zero at entry, left zero at exit: hb_cholesky_inverse_ws_elems).
-static int chol_persist_launch(const float* A, float* L, float* W, float* ws, float* Wf, int bf16x3, long B, long M, int* info,
-                               hipStream_t stream) {
+struct CpGram {   // K(X, X) + diag I to be synthesised by the launch (A == nullptr); see hb_gram_cholesky_inverse_f32
+  const float* X = nullptr;
+  const float* ell = nullptr;
+  long sX = 0, sEll = 0, dl = 0, d = 0;
+  int kind = 0;
+  float diag = 0.f;
+};
+static int chol_persist_launch(const float* A, const CpGram& g, float* L, float* W, float* ws, float* Wf, int bf16x3, long B, long M,
+                               int* info, hipStream_t stream) {
   CpArgs a;
   a.A = A, a.L = L, a.W = W, a.X = ws;
+  a.gX = g.X, a.gell = g.ell, a.gsX = g.sX, a.gsEll = g.sEll, a.gdl = g.dl, a.gd = g.d, a.gkind = g.kind, a.gdiag = g.diag;
   a.Wf = Wf, a.bf16x3 = bf16x3;
   a.sync = reinterpret_cast<unsigned*>(ws + B * M * M);
   a.info = info;
@@ -2152,6 +2160,26 @@ static int chol_persist_launch(const float* A, float* L, float* W, float* ws, fl
 }
 static inline bool chol_persist_shape(long B, long M, size_t elem) {
   return elem == 4 && M >= CP_NB && M % CP_NB == 0 && M <= 8192 && B >= 1 && B * (M / CP_NB) * (M / CP_NB) <= 65536;
+}
+extern "C" int hb_cholesky_persistent_shape(long B, long M, int elem_bytes) {
+  return chol_persist_shape(B, M, (size_t)elem_bytes) && hb_debug_get("chol_persist", 1) != 0 ? 1 : 0;
+}
+// L = chol(K(X, X) + diag_add I) and W = L^-1 without K ever being written: the persistent launch synthesises its tiles from
+// the points (same function and bits as hb_gram_fwd).  Shapes for which hb_cholesky_persistent_shape() is 0 are refused.
+extern "C" int hb_gram_cholesky_inverse_f32(int kind, const float* X, long sX, const float* ell, long sEll, long dl, long d,
+                                            double diag_add, float* L, float* W, long B, long M, int* info, float* ws,
+                                            float* Wfrag, int frag_bf16x3, void* stream) {
+  HB_REQUIRE(kind >= HB_KERN_RBF && kind < HB_KERN_SQDIST, "hb_gram_cholesky_inverse: unknown kernel kind %d", kind);
+  HB_REQUIRE(X && ell && L && W && info && ws, "hb_gram_cholesky_inverse: NULL pointer");
+  HB_REQUIRE(B >= 1 && d >= 1 && (dl == 1 || dl == d), "hb_gram_cholesky_inverse: bad extents");
+  HB_REQUIRE(sEll == 0 || sEll == dl, "hb_gram_cholesky_inverse: lengthscale batch stride must be 0 or dl");
+  HB_REQUIRE(hb_cholesky_persistent_shape(B, M, 4), "hb_gram_cholesky_inverse: fp32 with M %% 64 == 0 only (M = %ld, B = %ld)", M, B);
+  HB_REQUIRE(((uintptr_t)L % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)ws % 16 == 0) && (!Wfrag || (uintptr_t)Wfrag % 16 == 0),
+             "hb_gram_cholesky_inverse: outputs and workspace must be 16-byte aligned");
+  HB_REQUIRE(!frag_bf16x3 || Wfrag, "hb_gram_cholesky_inverse: bf16x3 images need Wfrag");
+  CpGram g;
+  g.X = X, g.ell = ell, g.sX = sX, g.sEll = sEll, g.dl = dl, g.d = d, g.kind = kind, g.diag = (float)diag_add;
+  return chol_persist_launch(nullptr, g, L, W, ws, Wfrag, frag_bf16x3, B, M, info, (hipStream_t)stream);
 }
 extern "C" long hb_cholesky_inverse_ws_elems(long B, long M, int elem_bytes) {
   if (B <= 0 || M <= 0) return 1;
@@ -2180,7 +2208,7 @@ static int cholesky_launch(const T* A, T* L, T* W, T* ws, T* Wf, int bf16x3, lon
   const bool no64 = hb_debug_get("chol_no64", 0) != 0;  // diagnostic A/B switches (hb_debug_set)
   if (sizeof(T) == 4 && fast && inv && chol_persist_shape(B, M, sizeof(T)) && hb_debug_get("chol_persist", 1) != 0) {
     // (every block of L, W and of the fragment-major images is written by the launch itself: no finishing pass)
-    return chol_persist_launch((const float*)A, (float*)L, (float*)W, (float*)ws, (float*)Wf, bf16x3, B, M, info, stream);
+    return chol_persist_launch((const float*)A, CpGram(), (float*)L, (float*)W, (float*)ws, (float*)Wf, bf16x3, B, M, info, stream);
   } else if (sizeof(T) == 4 && fast && M % C64_NB == 0 && !no64) {
     const int nrt = (int)(M / 32);
     HbSideJobs noside = {};

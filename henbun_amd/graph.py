@@ -1091,13 +1091,15 @@ def cholesky(a) -> Tensor:
 
 def _cholesky_emit(plan, node):
     H = plan.H
-    a, out = plan.buf(node.inputs[0]), plan.out(node.outputs[0])
+    # (the matrix itself does not exist when the Gram launch was folded into this one: plan._gram_for_chol)
+    a = None if node.id in plan._gram_for_chol else plan.buf(node.inputs[0])
+    out = plan.out(node.outputs[0])
     B = int(np.prod(node.outputs[0].shape[:-2])) if len(node.outputs[0].shape) > 2 else 1
     info = plan.new_info(B, "cholesky#%d" % node.id)
     # trinv(cholesky(a)) -- SparseGP's whitening, the Cholesky VJP -- is lowered to the fused
     # factor+inverse launches: the inverse rides along for free (csrc/linalg.hip)
     inv_node = next((c for c in plan._consumers.get(node.outputs[0], ()) if c.op == "trinv"), None)
-    if inv_node is not None and a.data_ptr() != out.data_ptr():
+    if inv_node is not None and (a is None or a.data_ptr() != out.data_ptr()):
         w = plan.out(inv_node.outputs[0])
         # exchange area + sync words of the persistent launch: zero-filled once, left zero by every call
         ws = plan.torch.zeros((max(H.cholesky_ws_elems(B, node.outputs[0].shape[-1], plan.dtype), 1),), dtype=plan.dtype,
@@ -1119,7 +1121,13 @@ def _cholesky_emit(plan, node):
             plan._wfrag[inv_node.outputs[0]] = (frag, bf3)
         # launch 0 of the 64-column chain hosts pending side jobs (minibatch gather, the sample of q(u))
         host = plan.dtype == plan.torch.float32 and M % 64 == 0 and plan.attach_side(node)
-        plan.steps.append(lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws, frag=frag, frag_bf16x3=bf3))
+        gk = plan._gram_for_chol.get(node.id)
+        if gk is not None:
+            gX, gell, gkind, gjit = gk
+            plan.steps.append(lambda: H.gram_cholesky_inverse(gX, gell, gjit, kind=gkind, out=out, inv=w, info=info, ws=ws, frag=frag,
+                                                              frag_bf16x3=bf3))
+        else:
+            plan.steps.append(lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws, frag=frag, frag_bf16x3=bf3))
         if host:
             plan.steps.append(lambda: H.side_flush())
         return
@@ -1295,6 +1303,139 @@ defop("diag_sample_kl", _diag_skl_emit, _diag_skl_vjp)
 defop("diag_sample_kl_grad", _diag_skl_grad_emit, None)
 
 
+# ------------------------------------------------------------------------------
+# the amortised encoder as one op: two MatBias layers feeding a LOCAL diagonal Normal (csrc/mlp.hip)
+# ------------------------------------------------------------------------------
+def mlp2_sample_kl(y, w0, b0, w1, b1, act, u=None, stream="local"):
+    """(x, kl, u, o):  o = act(y w0 + b0) w1 + b1 = [mu | s];  x = mu + exp(s) u;  kl = -0.5 sum(2 s + u^2 - x^2)
+    (reference nn.py:31-32,73-84 feeding variationals.py:121-129,138-142,225-230).  The hidden layer is an internal of the
+    op: the fused kernels never write it, the backward recomputes it.  No gradient flows into `y` (a data operand)."""
+    y, w0, b0, w1, b1 = (as_tensor(t) for t in (y, w0, b0, w1, b1))
+    n, L2 = y.shape[0], w1.shape[-1]
+    assert len(y.shape) == 2 and L2 % 2 == 0 and w0.shape[0] == y.shape[1] and w1.shape[0] == w0.shape[1]
+    ins = (y, w0, b0, w1, b1) if u is None else (y, w0, b0, w1, b1, as_tensor(u))
+    nd = make("mlp2_sample_kl", ins, {"act": act, "stream": stream}, [(n, L2 // 2), (1,), (n, L2 // 2), (n, L2)], unique=u is None)
+    return nd.outputs[0], nd.outputs[1], nd.outputs[2], nd.outputs[3]
+
+
+def _mlp2_dims(node):
+    n, din = node.inputs[0].shape
+    return n, din, node.inputs[1].shape[1], node.inputs[3].shape[1]
+
+
+def _mlp2_emit(plan, node):
+    H = plan.H
+    y, w0, b0, w1, b1 = (plan.buf(t) for t in node.inputs[:5])
+    u_in = plan.buf(node.inputs[5]) if len(node.inputs) > 5 else None
+    x, kl, u, o = (plan.out(t) for t in node.outputs)
+    act = node.attrs["act"]
+    n, din, hid, L2 = _mlp2_dims(node)
+    rng = None if u_in is not None else plan.rng(node.attrs["stream"])
+    from ._settings import settings as _st
+
+    fused = (plan.dtype == plan.torch.float32 and bool(getattr(_st.runtime, "fused_encoder", True))
+             and H.mlp2_sample_supported(n, din, hid, L2, rng.nlanes if rng is not None else 0, u_in is not None))
+    plan._mlp2[node.id] = {"fused": fused}
+    if fused:
+        ws = plan.torch.empty(H.mlp2_sample_ws_elems(n, din, hid), dtype=plan.dtype, device=plan.device)
+        plan._mlp2[node.id]["ws"] = ws
+        plan.steps.append(lambda: H.mlp2_sample_fwd(y, w0, b0, w1, b1, act, u_in=u_in, rng=rng, out=(x, kl, u, o), ws=ws))
+        return
+    # lowered form (fp64, shapes the fused kernels do not take): the op-by-op launches, hidden layer in a scratch buffer
+    h = plan.scratch((n, hid))
+    plan._mlp2[node.id]["h"] = h
+    L = L2 // 2
+    of = o.reshape(-1)
+
+    def step():
+        H.matmul(y, w0, bias=b0, act=act, out=h)
+        H.matmul(h, w1, bias=b1, out=o)
+        H.diag_sample_kl_fwd(of[0:], of[L:], u_in=u_in, rng=rng, out=(x, kl, u), rows=(n, L, L2, L2))
+
+    plan.steps.append(step)
+
+
+def _mlp2_vjp(node, gs):
+    gx, gkl = gs[0], gs[1]
+    if gs[2] is not None or gs[3] is not None:
+        raise NotImplementedError("gradients through the noise / encoder-output results of mlp2_sample_kl")
+    if gx is None and gkl is None:
+        return [None] * len(node.inputs)
+    y, w0, b0, w1, b1 = node.inputs[:5]
+    x, kl, u, o = node.outputs
+    ins = [y, w0, b0, w1, o, u, x] + ([gx] if gx is not None else []) + ([gkl] if gkl is not None else [])
+    g = make("mlp2_sample_kl_grad", tuple(ins), {"act": node.attrs["act"], "has_x": gx is not None, "has_kl": gkl is not None},
+             [w0.shape, b0.shape, w1.shape, b1.shape])
+    return [None, g.outputs[0], g.outputs[1], g.outputs[2], g.outputs[3]] + [None] * (len(node.inputs) - 5)
+
+
+def _mlp2_grad_emit(plan, node):
+    H = plan.H
+    y, w0, b0, w1, o, u, x = (plan.buf(t) for t in node.inputs[:7])
+    k = 7
+    xbar = klbar = None
+    if node.attrs["has_x"]:
+        xbar = plan.buf(node.inputs[k])
+        k += 1
+    if node.attrs["has_kl"]:
+        klbar = plan.buf(node.inputs[k])
+    dw0, db0, dw1, db1 = (plan.out(t) for t in node.outputs)
+    act = node.attrs["act"]
+    fwd = node.inputs[4].node
+    n, din, hid, L2 = _mlp2_dims(fwd)
+    rec = plan._mlp2[fwd.id]
+    if rec["fused"]:
+        ws = rec["ws"]
+        plan.steps.append(lambda: H.mlp2_sample_bwd(y, w0, b0, w1, act, o, u, x, xbar, klbar,
+                                                    out=(dw0, db0.reshape(-1), dw1, db1.reshape(-1)), ws=ws))
+        return
+    h, L = rec["h"], L2 // 2
+    do, dh = plan.scratch((n, L2)), plan.scratch((n, hid))
+    of, dof = o.reshape(-1), do.reshape(-1)
+
+    def step():
+        H.diag_sample_kl_bwd(of[L:], u, x, xbar, klbar, out=(dof[0:], dof[L:]), rows=(n, L, L2, L2))
+        H.matmul_colsum(h, do, out=dw1, colsum=db1.reshape(-1))
+        H.matmul(do, w1, transB=True, act=act, actgrad=h, out=dh)
+        H.matmul_colsum(y, dh, out=dw0, colsum=db0.reshape(-1))
+
+    plan.steps.append(step)
+
+
+defop("mlp2_sample_kl", _mlp2_emit, _mlp2_vjp)
+defop("mlp2_sample_kl_grad", _mlp2_grad_emit, None)
+
+
+def match_mlp2_encoder(mu, sq):
+    """(y, w0, b0, w1, b1, act) when `mu` / `sq` are the two column halves of o = matmul(matmul(y, w0, b0, act), w1, b1) with
+    `y` a data operand (no gradient path into it) -- the amortised-encoder pattern mlp2_sample_kl replaces -- else None."""
+    def base(t):
+        while t.node.op == "reshape" and tuple(t.node.inputs[0].shape) == tuple(t.shape):
+            t = t.node.inputs[0]
+        return t
+
+    bm, bs = base(mu), base(sq)
+    if bm.node.op != "strided" or bs.node.op != "strided" or len(mu.shape) != 2 or tuple(mu.shape) != tuple(sq.shape):
+        return None
+    o = bm.node.inputs[0]
+    cm, cs = _column_block(bm.node), _column_block(bs.node)
+    L = mu.shape[1]
+    if bs.node.inputs[0] is not o or cm != (L, 2 * L, 0) or cs != (L, 2 * L, L) or tuple(bm.shape) != tuple(mu.shape):
+        return None
+    n2 = o.node
+    if n2.op != "matmul" or len(n2.inputs) != 3 or n2.attrs["ta"] or n2.attrs["tb"] or n2.attrs["act"] != "none" or n2.attrs.get("actgrad"):
+        return None
+    h, w1, b1 = n2.inputs
+    n1 = h.node
+    if (n1.op != "matmul" or len(n1.inputs) != 3 or n1.attrs["ta"] or n1.attrs["tb"] or n1.attrs.get("actgrad")
+            or n1.attrs["act"] not in ("sigmoid", "relu", "tanh")):
+        return None
+    y, w0, b0 = n1.inputs
+    if len(y.shape) != 2 or len(w0.shape) != 2 or len(w1.shape) != 2 or y.node.op not in ("leaf:minibatch", "leaf:data", "leaf:const"):
+        return None
+    return y, w0, b0, w1, b1, n1.attrs["act"]
+
+
 def fullrank_sample_kl(mu, S, u=None, stream="global", packed=False) -> Tuple[Tensor, Tensor, Tensor]:
     """(x, kl, u):  x = mu + tril(S) u ; kl = -0.5 sum(log S_kk^2 + u^2 - x^2)
     (reference variationals.py:144-146, :186, :225-230).  packed: S holds the lower triangle only,
@@ -1421,9 +1562,25 @@ def _gram_emit(plan, node):
     cons = plan._consumers.get(y, [])
     if (len(cons) == 1 and cons[0].op == "matutil" and cons[0].attrs["mode"] == 1 and y.shape[-1] == y.shape[-2]
             and y not in plan.outputs and y not in plan._bind):
+        jit = cons[0].attrs["alpha"]
+        # K(z, z) + jitter I whose ONLY reader is a factor + inverse in persistent form (fp32, M % 64 == 0): the Cholesky
+        # launch synthesises its tiles from the points (hb_gram_cholesky_inverse), K is never written, this launch goes
+        kj = cons[0].outputs[0]
+        cc = plan._consumers.get(kj, [])
+        M = y.shape[-1]
+        Bk = int(np.prod(y.shape[:-2])) if len(y.shape) > 2 else 1
+        from ._settings import settings as _st
+
+        if (bool(getattr(_st.runtime, "fold_gram", True)) and node.inputs[0] is node.inputs[1] and len(cc) == 1
+                and cc[0].op == "cholesky" and kj not in plan.outputs
+                and kj not in plan._bind and plan.dtype == plan.torch.float32 and k in (H.KERN_RBF, H.KERN_CSYM_RBF)
+                and any(c.op == "trinv" for c in plan._consumers.get(cc[0].outputs[0], ()))
+                and H.cholesky_persistent_shape(Bk, M, plan.dtype)):
+            plan._fused_matutil.add(cons[0].id)
+            plan._gram_for_chol[cc[0].id] = (X, ell, k, jit)
+            return
         out = plan.out(cons[0].outputs[0])
         plan._fused_matutil.add(cons[0].id)
-        jit = cons[0].attrs["alpha"]
         plan.steps.append(lambda: H.gram_fwd(X, X2, ell, kind=k, out=out, diag_add=jit))
         return
     out = plan.out(y)
@@ -2145,6 +2302,8 @@ class Plan:
         # Weight gradient + bias gradient of a MatBias layer from one pass over the incoming gradient G: a 2-D product
         # X^T G whose right operand is also column-summed (reduce over axis 0) becomes hb_matmul_colsum -- the GEMM folds
         # the columns of G while it streams them, and the stand-alone reduction launches (two per layer) disappear.
+        self._gram_for_chol: Dict[int, tuple] = {}   # cholesky node id -> (points, lengthscales, kind, jitter) of its folded Gram
+        self._mlp2: Dict[int, dict] = {}             # mlp2_sample_kl node id -> {fused, ws | h}
         self._colsum_of: Dict[int, Node] = {}    # matmul node id -> the reduce node it absorbs
         self._fused_colsum = set()               # ids of absorbed reduce nodes
         for n in order:

@@ -703,6 +703,52 @@ def matmul_colsum(A, B, out=None, colsum=None):
     return out, colsum
 
 
+ACTS = {"none": 0, "sigmoid": 1, "relu": 2, "tanh": 3}
+
+
+def mlp2_sample_supported(n, din, hid, nout, rng_lanes=0, has_u=True):
+    return bool(_lib.lib().raw("hb_mlp2_sample_supported")(n, din, hid, nout, int(rng_lanes), int(bool(has_u))))
+
+
+def mlp2_sample_ws_elems(n, din, hid):
+    return int(_lib.lib().raw("hb_mlp2_sample_ws_elems")(n, din, hid))
+
+
+def mlp2_sample_ws(n, din, hid, device):
+    return _empty(mlp2_sample_ws_elems(n, din, hid), dtype=torch.float32, device=device)
+
+
+def mlp2_sample_fwd(y, w0, b0, w1, b1, act, u_in=None, rng=None, out=None, ws=None):
+    """(x, kl, u, o) of the fused two-layer encoder + LOCAL diagonal sample + MC-KL (hb_mlp2_sample_fwd_f32)."""
+    _chk(y), _chk(w0), _chk(w1)
+    n, din = y.shape
+    hid = w0.shape[1]
+    if out is None:
+        out = (_empty((n, 16), dtype=y.dtype, device=y.device), _empty(1, dtype=y.dtype, device=y.device),
+               _empty((n, 16), dtype=y.dtype, device=y.device), _empty((n, 32), dtype=y.dtype, device=y.device))
+    x, kl, u, o = out
+    if ws is None:
+        ws = mlp2_sample_ws(n, din, hid, y.device)
+    _lib.lib().call("hb_mlp2_sample_fwd_f32", _p(y), _p(w0), _p(b0), _p(w1), _p(b1), ACTS[act], _p(u_in),
+                    _p(rng.state) if (rng is not None and u_in is None) else None, rng.nlanes if rng is not None else 0,
+                    _p(x), _p(kl), _p(u), _p(o), n, din, hid, _p(ws), stream())
+    return x, kl, u, o
+
+
+def mlp2_sample_bwd(y, w0, b0, w1, act, o, u, x, xbar, klbar, out=None, ws=None):
+    """(dw0, db0, dw1, db1) of the fused encoder + sampler (hb_mlp2_sample_bwd_f32): h recomputed from y."""
+    n, din = y.shape
+    hid = w0.shape[1]
+    if out is None:
+        out = (_empty_like(w0), _empty(hid, dtype=y.dtype, device=y.device), _empty_like(w1), _empty(32, dtype=y.dtype, device=y.device))
+    dw0, db0, dw1, db1 = out
+    if ws is None:
+        ws = mlp2_sample_ws(n, din, hid, y.device)
+    _lib.lib().call("hb_mlp2_sample_bwd_f32", _p(y), _p(w0), _p(b0), _p(w1), ACTS[act], _p(o), _p(u), _p(x), _p(xbar), _p(klbar),
+                    _p(dw0), _p(db0), _p(dw1), _p(db1), n, din, hid, _p(ws), stream())
+    return dw0, db0, dw1, db1
+
+
 def cholesky(A, out=None, info=None):
     """L = chol(A) (lower), batched over leading dims.  Returns (L, info[B] int32 device tensor)."""
     _chk(A)
@@ -772,6 +818,41 @@ def cholesky_inverse(A, out=None, inv=None, info=None, ws=None, frag=None, frag_
         assert frag.numel() >= (5 if frag_bf16x3 else 2) * B * M * M and M % 32 == 0 and frag.dtype == A.dtype
     _lib.lib().call("hb_cholesky_inverse" + _suf(A), _p(A), _p(out), _p(inv), B, M, _p(info), _p(ws), _p(frag),
                     int(bool(frag_bf16x3 and frag is not None)), stream())
+    return out, inv, info
+
+
+def cholesky_persistent_shape(B, M, dtype):
+    """hb_cholesky_inverse takes its one-launch persistent form for this (B, M, dtype)."""
+    return bool(_lib.lib().raw("hb_cholesky_persistent_shape")(B, M, 4 if dtype == torch.float32 else 8))
+
+
+def gram_cholesky_inverse(X, ell, diag_add, kind=KERN_RBF, out=None, inv=None, info=None, ws=None, frag=None, frag_bf16x3=False):
+    """(L, W, info) of K(X, X) + diag_add I without K being written: hb_gram_cholesky_inverse_f32 (the persistent
+    Cholesky synthesises its tiles from the points).  X: [M, d] or [B, M, d]; ell as in gram_fwd."""
+    _chk(X), _chk(ell)
+    assert X.dtype == torch.float32
+    BX, M, d = _batch_view(X)
+    B = BX
+    if ell.dim() >= 2 and ell.shape[0] > 1:
+        B = max(B, ell.shape[0])
+    assert BX in (1, B)
+    sX = M * d if (BX == B and B > 1) else 0
+    sEll, dl = _ell_layout(ell, B, d)
+    batched = X.dim() > 2 or sEll != 0
+    shape = ((B,) if batched else ()) + (M, M)
+    if out is None:
+        out = _empty(shape, dtype=X.dtype, device=X.device)
+    if inv is None:
+        inv = _empty(shape, dtype=X.dtype, device=X.device)
+    if info is None:
+        info = _empty(max(B, 1), dtype=torch.int32, device=X.device)
+    if ws is None:
+        ws = cholesky_workspace(X.dtype, X.device, B, M)
+    assert ws.numel() >= cholesky_ws_elems(B, M, X.dtype)
+    if frag is not None:
+        assert frag.numel() >= (5 if frag_bf16x3 else 2) * B * M * M and frag.dtype == X.dtype
+    _lib.lib().call("hb_gram_cholesky_inverse_f32", kind, _p(X), sX, _p(ell), sEll, dl, d, float(diag_add), _p(out), _p(inv), B, M,
+                    _p(info), _p(ws), _p(frag), int(bool(frag_bf16x3 and frag is not None)), stream())
     return out, inv, info
 
 

@@ -94,6 +94,14 @@ class Variational(Parameterized):
         if u is not None:
             u = G.reshape(G.as_tensor(u), mu.shape)
         if self.q_shape == "diagonal":
+            if self.is_local and bool(getattr(settings.runtime, "fused_encoder", True)):
+                # fed by a two-layer encoder on a data operand (the amortised model, SURVEY.md App. C cfg 4): encoder,
+                # sample and KL become ONE op whose kernels never write the hidden layer (csrc/mlp.hip)
+                pat = G.match_mlp2_encoder(mu, sq)
+                if pat is not None:
+                    y, w0, b0, w1, b1, act = pat
+                    x, kl, uu, _ = G.mlp2_sample_kl(y, w0, b0, w1, b1, act, u=u, stream=stream)
+                    return x, kl, uu
             return G.diag_sample_kl(mu, sq, u, stream=stream)
         return G.fullrank_sample_kl(mu, sq, u, stream=stream, packed=self.packed)
 

@@ -371,6 +371,25 @@ int hb_matmul_colsum_f32(const float* A, const float* B, float* C, float* colsum
 int hb_matmul_colsum_f64(const double* A, const double* B, double* C, double* colsum, long M, long N, long K, long lda,
                          long ldb, long ldc, double* ws, long ws_elems, void* stream);
 
+/* ---- K7 fused: the amortised encoder in one launch per direction (csrc/mlp.hip; round 4).
+ * o = act(y w0 + b0) w1 + b1   [n, 32] = [q_mu (16) | q_sqrt = log-std (16)]   (NeuralNet of two MatBias layers,
+ * reference nn.py:31-32,73-84, fed to a LOCAL diagonal Normal, variationals.py:121-129), x = mu + exp(s) u and
+ * kl = -0.5 sum(2 s + u^2 - x^2) (variationals.py:138-142,225-230); the hidden layer is never written.  The backward
+ * recomputes it from y and returns the four weight gradients (no gradient for y: a data operand).
+ * fp32; hb_mlp2_sample_supported(n, din, hid, nout, rng_lanes, has_u) == 1: din in {32, 64}, hid in {128, 256}, nout = 32,
+ * n % 32 == 0 and, for in-kernel noise, rng_lanes >= 2 n (one generator lane per row and half: its draw differs from
+ * hb_diag_sample_kl's lane assignment).  u_in nullable -> drawn from rng; u_out receives the noise used.
+ * ws: hb_mlp2_sample_ws_elems(n, din, hid) elements (KL partials; the backward's per-chunk partial sums). */
+int hb_mlp2_sample_supported(long n, long din, long hid, long nout, long rng_lanes, int has_u);
+long hb_mlp2_sample_ws_elems(long n, long din, long hid);
+int hb_mlp2_sample_fwd_f32(const float* y, const float* w0, const float* b0, const float* w1, const float* b1, int act,
+                           const float* u_in, uint64_t* rng, long rng_lanes, float* x, float* kl, float* u_out, float* o,
+                           long n, long din, long hid, float* ws, void* stream);
+/* xbar [n,16] (nullable) and klbar [1] (nullable): gradients w.r.t. x and kl; o, u, x: the forward's outputs. */
+int hb_mlp2_sample_bwd_f32(const float* y, const float* w0, const float* b0, const float* w1, int act, const float* o,
+                           const float* u, const float* x, const float* xbar, const float* klbar, float* dw0, float* db0,
+                           float* dw1, float* db1, long n, long din, long hid, float* ws, void* stream);
+
 /* K4: L = chol(A), lower, batched [B,M,M]; the strict upper triangle of L is
  * zeroed; info[B] (device) receives 0 or k+1.  Replaces tf.cholesky
  * (reference gp/kernels.py:101; gp/gp.py:135).  A and L must NOT alias (workgroups
@@ -400,6 +419,15 @@ int hb_cholesky_f64(const double* A, double* L, long B, long M, int* info, void*
  * operand images of W and W^T (3 + 3 planes of B*M*M bf16: each fp32 entry split into hi + mid + lo bf16 terms;
  * [term][B][t][Q][k16-step q][64 lanes][8] = X[32t+li][32Q+16q+8h+j]) for the HB_PREC_BF16X3 contractions. */
 long hb_cholesky_inverse_ws_elems(long B, long M, int elem_bytes);
+/* 1 when hb_cholesky_inverse_f32 takes the persistent launch for this (B, M) (and the diagnostic switch leaves it on). */
+int hb_cholesky_persistent_shape(long B, long M, int elem_bytes);
+/* hb_gram_fwd with X2 = X and a diag_add, followed by hb_cholesky_inverse, as one launch: the persistent kernel synthesises its tiles of
+ * K(X, X) + diag_add I from the points (the same per-entry function as hb_gram_fwd: the same bits), K itself is never
+ * written.  kern.Cholesky(z) feeding SparseGP's whitening, reference gp/kernels.py:93-101 + gp/gp.py:159-162.
+ * Only where hb_cholesky_persistent_shape(B, M, 4) is 1; X [B or 1][M, d] (sX = 0: shared), ell as in hb_gram_fwd. */
+int hb_gram_cholesky_inverse_f32(int kind, const float* X, long sX, const float* ell, long sEll, long dl, long d,
+                                 double diag_add, float* L, float* W, long B, long M, int* info, float* ws,
+                                 float* Wfrag, int frag_bf16x3, void* stream);
 int hb_cholesky_inverse_f32(const float* A, float* L, float* W, long B, long M, int* info, float* ws,
                             float* Wfrag, int frag_bf16x3, void* stream);
 int hb_cholesky_inverse_f64(const double* A, double* L, double* W, long B, long M, int* info,

@@ -152,6 +152,36 @@ def evaluate(outputs, leaf_values, noise=None):
             qs = "diagonal" if op == "diag_sample_kl" else "fullrank"
             x = O.sample_diag(mu, s, u) if qs == "diagonal" else O.sample_fullrank(mu, s, u)
             outs = [x, O.kl_normal(s, u, x, qs).reshape(1), u]
+        elif op == "mlp2_sample_kl":
+            # the amortised encoder as one op (graph.mlp2_sample_kl): evaluated op by op with the oracle's pieces
+            y, w0, b0, w1, b1 = ins[:5]
+            actf = {"sigmoid": torch.sigmoid, "relu": torch.relu, "tanh": torch.tanh}[at["act"]]
+            o = actf(y @ w0 + b0.reshape(1, -1)) @ w1 + b1.reshape(1, -1)
+            L = o.shape[1] // 2
+            mu, s = o[:, :L], o[:, L:]
+            if len(ins) > 5:
+                u = ins[5].reshape(mu.shape)
+            else:
+                u = torch.as_tensor(noise[n.id] if n.id in noise else rng.randn(*mu.shape), dtype=DT).reshape(mu.shape)
+            x = O.sample_diag(mu, s, u)
+            outs = [x, O.kl_normal(s, u, x, "diagonal").reshape(1), u, o]
+        elif op == "mlp2_sample_kl_grad":
+            y, w0, b0, w1, o, u, x = ins[:7]
+            k = 7
+            xbar, klbar = torch.zeros_like(x), torch.zeros(1, dtype=DT)
+            if at["has_x"]:
+                xbar = ins[k]
+                k += 1
+            if at["has_kl"]:
+                klbar = ins[k]
+            L = o.shape[1] // 2
+            mb = xbar + klbar * x
+            do = torch.cat([mb, mb * torch.exp(o[:, L:]) * u - klbar], dim=1)
+            actf = {"sigmoid": torch.sigmoid, "relu": torch.relu, "tanh": torch.tanh}[at["act"]]
+            h = actf(y @ w0 + b0.reshape(1, -1))
+            dact = {"sigmoid": h * (1 - h), "relu": (h > 0).to(DT), "tanh": 1 - h * h}[at["act"]]
+            dh = (do @ w1.T) * dact
+            outs = [y.T @ dh, dh.sum(0).reshape(b0.shape), h.T @ do, do.sum(0).reshape(n.outputs[3].shape)]
         elif op in ("diag_sample_kl_grad", "fullrank_sample_kl_grad"):
             s, u, x = ins[:3]
             k = 3

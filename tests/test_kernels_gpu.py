@@ -1188,6 +1188,58 @@ def test_gauss_ll_head_writes_the_gradient_for_f_itself(H, p, n):
         assert_close(fbar, want, dict(rtol=1e-12, atol=0) if p == "f64" else dict(rtol=3e-7, atol=0))
 
 
+@pytest.mark.parametrize("n,din,hid,act", [(4096, 64, 256, "sigmoid"), (256, 32, 128, "tanh"), (1024, 64, 128, "relu"),
+                                             (32, 32, 256, "sigmoid")])
+@pytest.mark.parametrize("inject", [True, False])
+def test_fused_encoder_forward_and_backward(H, n, din, hid, act, inject):
+    """hb_mlp2_sample_fwd / _bwd (csrc/mlp.hip): the two-layer encoder (reference nn.py:31-32,73-84) feeding a LOCAL diagonal
+    Normal (variationals.py:121-129,138-142,225-230) in one launch per direction, the hidden layer never written -- against
+    the oracle's op-by-op evaluation (neural_net, feed_split, sample_diag, kl_normal) and torch autograd, in fp64."""
+    rng = np.random.RandomState(n + din)
+    L = 16
+    y = rng.randn(n, din)
+    w0, b0 = rng.randn(din, hid) / np.sqrt(din), 0.1 * rng.randn(1, hid)
+    w1, b1 = rng.randn(hid, 2 * L) / np.sqrt(hid), 0.1 * rng.randn(1, 2 * L)
+    d32 = lambda a: dev(a, torch.float32)
+    Y, W0, B0, W1, B1 = d32(y), d32(w0), d32(b0), d32(w1), d32(b1)
+    if inject:
+        u = rng.randn(n, L)
+        x, kl, uo, o = H.mlp2_sample_fwd(Y, W0, B0, W1, B1, act, u_in=d32(u))
+        assert torch.equal(uo, d32(u))
+    else:
+        if not H.mlp2_sample_supported(n, din, hid, 32, 65536, False):
+            pytest.skip("needs 2 n generator lanes")
+        r1, r2 = H.Rng(5, stream_id=3), H.Rng(5, stream_id=3)
+        x, kl, uo, o = H.mlp2_sample_fwd(Y, W0, B0, W1, B1, act, rng=r1)
+        x2, kl2, uo2, o2 = H.mlp2_sample_fwd(Y, W0, B0, W1, B1, act, rng=r2)
+        assert torch.equal(uo, uo2) and torch.equal(x, x2) and torch.equal(kl, kl2)          # a pure function of the state
+        u = host(uo)
+        assert abs(u.mean()) < 5.0 / np.sqrt(u.size) and abs(u.std() - 1.0) < 0.02 + 5.0 / np.sqrt(u.size)
+        x3 = H.mlp2_sample_fwd(Y, W0, B0, W1, B1, act, rng=r1)[0]
+        assert not torch.equal(x, x3)                                                       # and the state has advanced
+    actf = {"sigmoid": torch.sigmoid, "tanh": torch.tanh, "relu": torch.relu}[act]
+    T = lambda a_: torch.as_tensor(a_, dtype=torch.float64)
+    tw0, tb0, tw1, tb1 = [T(a_).clone().requires_grad_(True) for a_ in (w0, b0, w1, b1)]
+    oo = actf(T(y) @ tw0 + tb0) @ tw1 + tb1
+    mu, sv = O.feed_split(oo, [L, L])
+    xs = O.sample_diag(mu, sv, T(u))
+    klr = O.kl_normal(sv, T(u), xs, "diagonal")
+    assert_close(o, oo.detach(), dict(rtol=2e-4, atol=2e-5))
+    assert_close(x, xs.detach(), dict(rtol=2e-4, atol=5e-5))
+    assert abs(kl.item() - klr.item()) <= 2e-5 * abs(klr.item()) + 1e-3
+    # backward: gradients of  sum(xbar * x) + klbar * kl
+    xbar, klbar = rng.randn(n, L) / np.sqrt(n), np.array([-1.0])
+    (xs * T(xbar)).sum().add(klr * klbar[0]).backward()
+    dw0, db0, dw1, db1 = H.mlp2_sample_bwd(Y, W0, B0, W1, act, o, uo, x, d32(xbar), d32(klbar))
+    for got, ref, name in ((dw0, tw0.grad, "dw0"), (db0, tb0.grad.reshape(-1), "db0"), (dw1, tw1.grad, "dw1"),
+                           (db1, tb1.grad.reshape(-1), "db1")):
+        observe("mlp2_fused[%d,%d,%d,%s]/%s" % (n, din, hid, act, name), tile_err(host(got), ref.numpy()), 2e-4)
+    # only the KL gradient / only the sample gradient
+    dw0k = H.mlp2_sample_bwd(Y, W0, B0, W1, act, o, uo, x, None, d32(klbar))[0]
+    dw0x = H.mlp2_sample_bwd(Y, W0, B0, W1, act, o, uo, x, d32(xbar), None)[0]
+    assert tile_err(host(dw0k + dw0x), host(dw0)) <= 2e-5      # linear in (xbar, klbar), up to fp32 summation order
+
+
 def test_serial_chain_flushes_before_its_argument_block_is_exhausted(H):
     """hb_chain_push counts the argument slots of the recorded jobs and runs them before a job that would not fit
     (five 9-pointer likelihood heads leave 19 pointer slots; the generated kernel wants 20 free at the start of a job):
