@@ -2186,6 +2186,9 @@ class Plan:
         self._info_used = 0
         self.stream = stream          # torch.cuda.Stream the plan runs on (None = current)
         self.side_effect_steps = set()  # steps skipped by the capture warm-up (e.g. the Adam update)
+        self.param_only_steps = []      # elementwise programs whose every operand is a parameter leaf
+        self.prologue = []              # ... moved behind the optimiser update (they then serve the NEXT replay)
+        self.trail_version = None       # session.param_version the moved steps' outputs correspond to
         self.chain_kind: Dict[int, str] = {}    # id(step) -> "full" | "tail": what a serial chain may take of it (fuse_chains)
         self.chain_members: Dict[int, list] = {}   # id(fused step) -> the steps it runs between hb_chain_begin / hb_chain_end
         self._chains_fused = False
@@ -2625,6 +2628,10 @@ class Plan:
         step = prog.launch
         self.steps.append(step)
         self.step_labels[id(step)] = "ew_cluster[%d]" % len(c.nodes)
+        if in_regs and all(t.node.op in ("leaf:param", "leaf:const") for t in in_regs):
+            # every operand is a parameter: the start-of-step transforms (softplus of the raw hyper-parameters, ...).  An
+            # optimiser may run this step at the END of its plan instead, for the next replay (model.py: trailing transforms)
+            self.param_only_steps.append(step)
         if prog.image is None:
             self.chain_kind[id(step)] = "full"   # compiled programs record themselves into a serial chain
 

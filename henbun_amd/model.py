@@ -319,6 +319,22 @@ class Optimizer:
                     plan.eager_tail = [pack, lambda: parallel.allreduce_gradient(gflat), adam]
                     plan.dp_mode = "torch-eager"
                 plan.dp_comm = comm
+        plan.sess = sess
+        if (kind != "run" and not plan.eager_tail and plan.param_only_steps
+                and bool(getattr(settings.runtime, "trailing_transforms", True))):
+            # Trailing transforms: the elementwise programs that only read parameters (softplus of the raw hyper-parameters
+            # and the like: a ~4.4 us launch of its own at the head of every step) run at the END of the step instead, right
+            # behind the Adam update and inside its serial chain -- they produce the values of the NEXT replay.  The
+            # session's parameter version says when that is not enough (first replay, a host-side assignment, another
+            # plan's update, restore): _run_steps then runs them once, eagerly, before launching.
+            for st in plan.param_only_steps:
+                plan.steps.remove(st)
+                plan.steps.append(st)
+            plan.prologue = list(plan.param_only_steps)
+            with plan._on_stream():
+                for st in plan.prologue:
+                    st()
+            plan.trail_version = sess.param_version
         if settings.runtime.graph_capture:
             plan.capture()
         self._plans[key] = plan
@@ -371,6 +387,15 @@ class Optimizer:
     def _run_steps(plan, k):
         """`k` asynchronous optimisation steps of a compiled 'opt' plan (one graph launch each; plus the eager
         exchange + update when the data-parallel tail could not be captured)."""
+        sess = getattr(plan, "sess", None)
+        if plan.prologue and plan.trail_version != sess.param_version:
+            # the values the trailing transforms left behind are not those of the current parameters
+            with plan._on_stream():
+                for st in plan.prologue:
+                    st()
+        if sess is not None and getattr(plan, "adam", None) is not None:
+            sess.param_version += k
+            plan.trail_version = sess.param_version
         if not plan.eager_tail:
             for _ in range(k):
                 plan.run()
@@ -457,6 +482,7 @@ class Optimizer:
             slots = self._optimizer.slots(sess)
             torch.cuda.synchronize()
             sess.theta.copy_(torch.as_tensor(f["theta"]).to(sess.theta.dtype))
+            sess.param_version += 1
             slots["m"].copy_(torch.as_tensor(f["adam_m"]).to(slots["m"].dtype))
             slots["v"].copy_(torch.as_tensor(f["adam_v"]).to(slots["v"].dtype))
             slots["t"].copy_(torch.as_tensor(f["adam_t"]))

@@ -58,6 +58,7 @@ class Session:
         self._data_bufs: Dict[int, object] = {}
         self.rank, self.world_size = 0, 1
         self.injected_indices = None
+        self.param_version = 0           # bumped by every write to the flat parameter buffer (host writes, optimiser steps)
 
     # ------------------------------------------------------------------ device bring-up
     def _ensure_device(self):
@@ -141,6 +142,7 @@ class Session:
         self._layout = layout
         self._offsets = {id(v): (o, s) for v, o, s in layout}
         self.layout_version += 1
+        self.param_version += 1
 
     def initialize(self):
         """Upload pending (assigned) values; afterwards nothing is pending."""
@@ -169,6 +171,7 @@ class Session:
         self.torch.cuda.synchronize()
         self.theta[o:o + s].copy_(self.torch.as_tensor(arr.reshape(-1)).to(self.device))
         self.torch.cuda.synchronize()
+        self.param_version += 1
 
     def read_value(self, v):
         self.ensure_layout()

@@ -133,6 +133,32 @@ def test_svgp_adam_trajectory_matches_oracle(capture, fuse):
         assert rel_err(got[k], ref.numpy()) <= 1e-6, k
 
 
+def test_trailing_transforms_follow_host_side_parameter_writes():
+    """The start-of-step transforms run at the END of a step for the next replay (model.py: trailing transforms).  A
+    host-side assignment, a restore, or another plan's update between two replays makes those values stale: the
+    session's parameter version makes the optimiser recompute them first.  Same call sequence with the mechanism on and
+    off => bit-identical parameters; and the plan really has the transform step behind the update."""
+    res = {}
+    for trailing in (True, False):
+        cfg = hb.settings.get_settings()
+        cfg.numerics.jitter_level = 1e-4
+        cfg.runtime.trailing_transforms = trailing
+        with hb.settings.temp_settings(cfg):
+            m, data = make_svgp(3000, 64, 512, "diagonal", "float32", seed=11)
+            opt = m.ELBO()
+            opt.compile(optimizer=tf.train.AdamOptimizer(0.01))
+            opt.optimize(maxiter=3, minibatch_size=512, indices=data[5])
+            m.k_var = np.ones(1) * 0.7                     # deferred host assignment between two replays
+            opt.optimize(maxiter=2, minibatch_size=512, indices=data[5])
+            v = opt.run(minibatch_size=512, indices=data[5])      # another plan reads the parameters in between
+            m.gp.kern.lengthscales = np.ones(1) * 1.1
+            opt.optimize(maxiter=2, minibatch_size=512, indices=data[5])
+            plan = opt.last_plan
+            assert bool(plan.prologue) == trailing
+            res[trailing] = (m._session.theta.clone(), v)
+    assert torch.equal(res[True][0], res[False][0]) and res[True][1] == res[False][1]
+
+
 def _two_rank_sessions(N, M, n, lr, seed=3):
     """Two models in ONE process set up as rank 0 / rank 1 of a world of two (no second process, no process group): shard
     of the data (parallel.shard_rows), rank-distinct `local` / `index` streams (parallel.rng_stream_ids), the global data
