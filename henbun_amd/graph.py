@@ -1121,6 +1121,8 @@ def _cholesky_emit(plan, node):
             plan._wfrag[inv_node.outputs[0]] = (frag, bf3)
         # launch 0 of the 64-column chain hosts pending side jobs (minibatch gather, the sample of q(u))
         host = plan.dtype == plan.torch.float32 and M % 64 == 0 and plan.attach_side(node)
+        plan.note("factor + inverse in one persistent launch (chol_persist_kernel)", node,
+                  H.cholesky_persistent_shape(B, M, plan.dtype), "needs fp32 and M % 64 == 0: the launch-chain form runs")
         gk = plan._gram_for_chol.get(node.id)
         if gk is not None:
             gX, gell, gkind, gjit = gk
@@ -1336,6 +1338,9 @@ def _mlp2_emit(plan, node):
     fused = (plan.dtype == plan.torch.float32 and bool(getattr(_st.runtime, "fused_encoder", True))
              and H.mlp2_sample_supported(n, din, hid, L2, rng.nlanes if rng is not None else 0, u_in is not None))
     plan._mlp2[node.id] = {"fused": fused}
+    plan.note("fused encoder (hb_mlp2_sample_fwd / _bwd)", node, fused,
+              "" if fused else "needs fp32, Din in {32, 64}, H in {128, 256}, 2 L = 32 outputs, n % 32 == 0, 2 n generator "
+              "lanes for in-kernel noise and settings.runtime.fused_encoder: lowered to the op-by-op launches")
     if fused:
         ws = plan.torch.empty(H.mlp2_sample_ws_elems(n, din, hid), dtype=plan.dtype, device=plan.device)
         plan._mlp2[node.id]["ws"] = ws
@@ -1578,7 +1583,11 @@ def _gram_emit(plan, node):
                 and H.cholesky_persistent_shape(Bk, M, plan.dtype)):
             plan._fused_matutil.add(cons[0].id)
             plan._gram_for_chol[cc[0].id] = (X, ell, k, jit)
+            plan.note("Gram folded into the persistent Cholesky (hb_gram_cholesky_inverse)", node, True)
             return
+        plan.note("Gram folded into the persistent Cholesky (hb_gram_cholesky_inverse)", node, False,
+                  "needs fp32, K(z, z) with one reader (a factor + inverse), an RBF-family kernel, M % 64 == 0 and "
+                  "settings.runtime.fold_gram")
         out = plan.out(cons[0].outputs[0])
         plan._fused_matutil.add(cons[0].id)
         plan.steps.append(lambda: H.gram_fwd(X, X2, ell, kind=k, out=out, diag_add=jit))
@@ -2186,6 +2195,7 @@ class Plan:
         self._info_used = 0
         self.stream = stream          # torch.cuda.Stream the plan runs on (None = current)
         self.side_effect_steps = set()  # steps skipped by the capture warm-up (e.g. the Adam update)
+        self.explain = []               # (pass, node label, fired, why): the planner's fusion decisions (tools/dump_plan.py --explain)
         self.param_only_steps = []      # elementwise programs whose every operand is a parameter leaf
         self.prologue = []              # ... moved behind the optimiser update (they then serve the NEXT replay)
         self.trail_version = None       # session.param_version the moved steps' outputs correspond to
@@ -2235,6 +2245,13 @@ class Plan:
                     if post is not None and not any(m.id in self._absorbed for m in post[2]):
                         self._gll_post[n.id] = post
                         self._absorbed.update(m.id for m in post[2])
+                        self.note("likelihood head writes dobjective/df (hb_gauss_ll_post)", n, True)
+                    else:
+                        self.note("likelihood head writes dobjective/df (hb_gauss_ll_post)", n, False,
+                                  "dmu is not followed by exactly scale * (post * dmu) feeding nothing else" if post is None
+                                  else "its elementwise tail is already absorbed by another head")
+        else:
+            self.note("elementwise fusion", None, False, "settings.runtime.fuse_elementwise is off")
         # column programs first (short-and-wide spaces with row reductions inside: they need the compiled form), then
         # the plain elementwise clusters over what is left
         self._colclusters = cluster_columns(order, outputs=self.outputs, skip=self._absorbed,
@@ -2273,15 +2290,22 @@ class Plan:
                 while ft.node.op == "reshape":
                     ft = ft.node.inputs[0]
                 sg = ft.node
+                hp = "likelihood head inside the forward contraction (hb_sgp_fwd_gauss)"
                 if sg.op != "sgp" or ft is not sg.outputs[0] or sg.id in self._sgp_head or sg.inputs[5].shape[-2] != 1:
+                    self.note(hp, n, False, "f is not the single latent function of an sgp draw" if sg.op != "sgp" or ft is not sg.outputs[0]
+                              else ("the draw already carries a head" if sg.id in self._sgp_head else "more than one latent function (P > 1)"))
                     continue
                 if n.inputs[0].size != ft.size:
+                    self.note(hp, n, False, "y and f differ in size (a broadcast)")
                     continue
                 pos = self._order_pos[sg.id]
                 others = [n.inputs[0], n.inputs[2]] + list(n.inputs[3:4])
                 if all(emitted_before(t, pos) for t in others):
                     self._sgp_head[sg.id] = n
                     self._gll_in_sgp[n.id] = sg
+                    self.note(hp, n, True)
+                else:
+                    self.note(hp, n, False, "y / var / scale are produced after the draw is launched")
         # Concatenation in place: the parts of a concat along its leading non-unit axis are contiguous blocks of the
         # result, so a part that a fused program (or a single elementwise launch) produces is WRITTEN there -- the
         # gradient of a batched GP draw whose expert / gate halves come out of one column program needs no
@@ -2327,6 +2351,7 @@ class Plan:
                     continue       # somebody reads the sums before the GEMM has run
                 self._colsum_of[n.id] = r
                 self._fused_colsum.add(r.id)
+                self.note("weight + bias gradient from one pass (hb_matmul_colsum)", n, True)
                 break
         self._emitted: List[Node] = []      # nodes in emission order
         self._side_cands: List[dict] = []   # small independent steps that may ride on a later host launch (side jobs)
@@ -2443,7 +2468,7 @@ class Plan:
         (`cell["defer"]` turns True when a later host launch adopts the step).  `outs`: the tensors it writes (a list
         that may still grow)."""
         cell = {"defer": False}
-        self._side_cands.append(dict(cell=cell, outs=outs, epos=len(self._emitted)))
+        self._side_cands.append(dict(cell=cell, outs=outs, epos=len(self._emitted), node=outs[0].node if outs else None))
         return cell
 
     def attach_side(self, host_node):
@@ -2468,12 +2493,19 @@ class Plan:
                     break
             if busy or any(t in outs for t in host_node.inputs):
                 c["dead"] = True   # somebody needs it before any later host could run it
+                self.note("side job rides on a host launch", c.get("node"), False, "its output is read before (or by) the next host launch")
                 continue
             c["cell"]["defer"] = True
+            self.note("side job rides on a host launch", c.get("node"), True, "host: " + host_node.op)
             adopted += 1
             if adopted == 3:
                 break
         return adopted > 0
+
+    def note(self, pass_name, node, fired, why=""):
+        """Record a fusion decision of the planner: which pass looked at which node, whether it fired, and why not."""
+        lab = "%s#%d%s" % (node.op, node.id, "x".join(str(d) for d in node.outputs[0].shape).join(("[", "]"))) if node is not None else "-"
+        self.explain.append((pass_name, lab, bool(fired), why))
 
     def pin_side_reads(self, tensors):
         """A step about to be emitted reads `tensors` although they are not inputs of its node (operands of a fused
@@ -2761,10 +2793,15 @@ class Plan:
                 while j < len(steps) and self.chain_kind.get(id(steps[j])) == "full":
                     j += 1
             if j - i < 2:
+                if kind in ("tail", "full"):
+                    self.explain.append(("serial chain", self.step_labels.get(id(steps[i]), "other"), False,
+                                         "no chainable step directly behind it (chain-aware small launches only: compiled "
+                                         "elementwise programs, likelihood head, folds, one-workgroup Adam)"))
                 out.append(steps[i])
                 i += 1
                 continue
             members = steps[i:j]
+            self.explain.append(("serial chain", "+".join(self.step_labels.get(id(m), "other") for m in members), True, ""))
 
             def fused(members=members):
                 H.chain_begin()

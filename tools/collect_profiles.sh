@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copy the outputs of tools/final_measurements.sh (gpurun_out/r4final) into profiles/ under their round-3 names.
+# Copy the outputs of tools/final_measurements.sh (gpurun_out/r4final) into profiles/ under their round-4 names.
 set -e
 s=gpurun_out/r4final
 p=profiles
@@ -20,4 +20,6 @@ cp $s/pmc_cfg2/pmc_kernels.txt $p/r04_pmc_cfg2_kernels.txt
 cp $s/pmc_cfg4/pmc_kernels.txt $p/r04_pmc_cfg4_kernels.txt
 python tools/make_traffic_json.py cfg2=$s/pmc_cfg2 cfg4=$s/pmc_cfg4 > $p/r04_pmc_traffic.json
 cp $s/chol_persist_stamps.txt $p/r04_chol_persist_stamps.txt
-ls -la $p | grep r03
+cp $s/mlp_stamps.txt $p/r04_mlp_bwd_stamps.txt
+cp $s/xlane_cost.txt $p/r04_xlane_cost.txt
+ls -la $p | grep r04

@@ -19,5 +19,5 @@ python tools/bw_rows.py > $o/bw_rows.txt 2>/dev/null
 python tools/dump_plan.py cfg2 > $o/plan_cfg2.txt 2>/dev/null
 tools/pmc_traffic.sh r4final/pmc_cfg2 > /dev/null 2>&1
 tools/pmc_traffic.sh r4final/pmc_cfg4 --config cfg4 > /dev/null 2>&1
-for t in chol_persist_stamps; do [ -x tools/_bin/$t ] && (timeout -k 5 60 tools/_bin/$t > $o/$t.txt 2>&1 || true); done
+for t in chol_persist_stamps mlp_stamps xlane_cost; do [ -x tools/_bin/$t ] && (timeout -k 5 60 tools/_bin/$t > $o/$t.txt 2>&1 || true); done
 head -c 300 $o/bench_cfg2.json
