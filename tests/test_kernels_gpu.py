@@ -1233,7 +1233,7 @@ def test_fused_encoder_forward_and_backward(H, n, din, hid, act, inject):
     dw0, db0, dw1, db1 = H.mlp2_sample_bwd(Y, W0, B0, W1, act, o, uo, x, d32(xbar), d32(klbar))
     for got, ref, name in ((dw0, tw0.grad, "dw0"), (db0, tb0.grad.reshape(-1), "db0"), (dw1, tw1.grad, "dw1"),
                            (db1, tb1.grad.reshape(-1), "db1")):
-        observe("mlp2_fused[%d,%d,%d,%s]/%s" % (n, din, hid, act, name), tile_err(host(got), ref.numpy()), 2e-4)
+        observe("mlp2_fused[%d,%d,%d,%s]/%s" % (n, din, hid, act, name), tile_err(host(got), ref.numpy()), 5e-6)    # observed 6.6e-8 .. 6.0e-7 over the eight cases
     # only the KL gradient / only the sample gradient
     dw0k = H.mlp2_sample_bwd(Y, W0, B0, W1, act, o, uo, x, None, d32(klbar))[0]
     dw0x = H.mlp2_sample_bwd(Y, W0, B0, W1, act, o, uo, x, d32(xbar), None)[0]

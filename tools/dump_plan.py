@@ -38,7 +38,7 @@ for c in {id(c): c for c in plan._clusters.values()}.values():
 if explain:
     print("\nfusion ledger (pass | node | fired | why not):")
     for pass_name, lab, fired, why in plan.explain:
-        print("  %-72s %-34s %-5s %s" % (pass_name, lab, "yes" if fired else "NO", why))
+        print("  %-72s %-34s %-5s %s" % (pass_name, lab, "yes" if fired else "NO", why if (not fired or why.startswith("host:")) else ""))
     for c in plan._side_cands:
         if not c["cell"]["defer"] and not c.get("dead"):
             nd = c.get("node")
