@@ -45,6 +45,10 @@ _SIGS = {
     "hb_sgp_ws_elems": [L, L, L, L, L],
     "hb_sgp_strip_path": [L, L, L, L, L, I],
     "hb_sgp_head_units": [L, L, L, L, L, I, I, I, L],
+    "hb_sgp_rider_supported": [L, L, L, L, L, I, I, I, L],
+    "hb_sgp_rider_begin": [],
+    "hb_sgp_rider_pending": [],
+    "hb_sgp_rider_flush": [P],
     "hb_sgp_fwd_gauss_f32": [I, I, P, L, P, P, L, P, P, I, P, P, P, L, P, P, P, P, P, L, L, L, L, L, P, P, P, P, D, P, P, P, L, P],
     "hb_ewise_prog_image_bytes": [],
     "hb_ewise_prog_build": [I, P, P, I, P, P, I, P, P, P, I, P, P, P, P],

@@ -69,13 +69,20 @@ struct CpArgs {
   float* Wf;         // nullable: the fragment-major images of W and W^T (and the bf16x3 planes behind them)
   int bf16x3;
   int M, B, nb, total;   // total = number of workgroups of the factorisation (side-job blocks come after them)
+  // early-start consumers in the same launch (csrc/sgp.hip: chol_sgp_fwd_kernel).  early != 0: the W image is stored
+  // write-through and every identity-strip workgroup of column block j raises wready[b][j] behind its stores (row block j
+  // of W is final after panel j: j + 1 contributions); `arrive` workgroups take part in the arrival count (the
+  // factorisation's plus the consumers'), `nside` side-job workgroups raise sync[3] when their outputs are released.
+  int early, nside, arrive;
+  int poll_naps;   // consumers: naps of 512 cycles between two polls of a row-block counter
   unsigned long long* stamps;   // diagnostic builds only (HB_CP_STAMPS)
 };
 
-static inline long cp_sync_words(long B, long M) {
-  const long nb = M / CP_NB;
-  return CP_HDR + ((B + 3) / 4) * 4 + 4 * B * nb * nb;
-}
+// (the row-block counters of the early-start consumers sit in cache lines of their own: they are polled by every consumer
+// workgroup, the panel flags in front of them are the factorisation's critical path)
+__host__ __device__ static inline long cp_wready_off(long B, long nb) { return ((CP_HDR + ((B + 3) / 4) * 4 + 4 * B * nb * nb + 31) / 32) * 32 + 32; }
+__host__ __device__ static inline long cp_sync_words_nb(long B, long nb) { return cp_wready_off(B, nb) + ((B * nb + 31) / 32) * 32; }
+static inline long cp_sync_words(long B, long M) { return cp_sync_words_nb(B, M / CP_NB); }
 static inline int cp_strips(int nb, int j, int inv) {
   const int n = (nb - 1 - j) + (inv ? j + 1 : 0);
   return n > 0 ? n : 1;
@@ -113,10 +120,10 @@ struct CpWait {
   unsigned* tmo;               // the launch's timeout word
   unsigned long long deadline;
   bool dead;
-  __device__ __forceinline__ void wait(const unsigned* f) {
+  __device__ __forceinline__ void wait(const unsigned* f, unsigned atleast = 1u) {
     if (dead) return;
     unsigned spins = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < atleast) {
       __builtin_amdgcn_s_sleep(2);
       if ((++spins & 127u) == 0u) {
         if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
@@ -131,18 +138,41 @@ struct CpWait {
   }
 };
 
-__global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJobs side) {
-  if ((int)blockIdx.x >= a.total) {
-    // small independent launches of the step ride here as extra workgroups (side_jobs.cuh); their bodies are written
-    // for 256-thread blocks: the upper half of this block leaves
-    if (threadIdx.x < 256) hb_side_run(side, (int)blockIdx.x - a.total);
-    return;
-  }
-  __shared__ __attribute__((aligned(16))) float colbuf[2][CP_NB][CP_LD];   // [diag | strip][column][row]
-  __shared__ __attribute__((aligned(16))) float pibuf[CP_NB];              // reciprocal pivots
-  __shared__ int done[2];     // columns of the diagonal block (0) / of the strip (1) that are published
-  __shared__ unsigned s_ticket, s_last;
+// LDS of one factorisation workgroup (the kernels that host the body declare the bytes and hand them in, so that a
+// launch with other roles -- csrc/sgp.hip -- can overlay them with its own)
+struct CpLds {
+  float colbuf[2][CP_NB][CP_LD];   // [diag | strip][column][row]
+  float pibuf[CP_NB];              // reciprocal pivots
+  int done[2];                     // columns of the diagonal block (0) / of the strip (1) that are published
+  unsigned s_last;
+};
 
+// arrival of one workgroup (any role); the LAST one writes info[] and leaves the sync words zero for the next call
+__device__ __forceinline__ void cp_arrive(const CpArgs& a, unsigned& s_last) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&a.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (old == (unsigned)a.arrive - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last) {
+    const unsigned tmo = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int bb = tid; bb < a.B; bb += 512) {
+      const unsigned f = __hip_atomic_load(&a.sync[CP_HDR + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.info[bb] = tmo ? -1 : (f ? (int)(CP_FAILBIG - f) : 0);
+    }
+    __syncthreads();
+    const long nw = cp_sync_words_nb(a.B, a.nb);
+    for (long t = tid; t < nw; t += 512) __hip_atomic_store(&a.sync[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// One factorisation workgroup; `ticket` = its identity in start order (the hosting kernel draws it from sync[0]).
+__device__ __forceinline__ void chol_persist_body(const CpArgs& a, CpLds& sh, const unsigned ticket) {
+  float (&colbuf)[2][CP_NB][CP_LD] = sh.colbuf;
+  float (&pibuf)[CP_NB] = sh.pibuf;
+  int (&done)[2] = sh.done;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = w >> 2;                                   // 0: diagonal block, 1: strip
@@ -152,12 +182,8 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
   const int i16 = lane & 15, g4 = lane >> 4;              // MFMA 16x16x4 lane coordinates
   const int M = a.M, nb = a.nb, inv = a.W != nullptr;
 
-  if (tid == 0) {
-    done[0] = 0, done[1] = 0;
-    s_ticket = __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (tid == 0) done[0] = 0, done[1] = 0;
   __syncthreads();
-  const unsigned ticket = s_ticket;
   // ticket -> (column block j, matrix b, strip s), column block major
   int j = 0, b, s;
   {
@@ -501,6 +527,27 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
       }
     }
   } else if (stripY) {
+    if (Wf && a.early) {
+      // Early-start consumers (csrc/sgp.hip) read row block j of the W image as soon as it is final: written first,
+      // write-through, drained, then this workgroup's contribution to the row block's counter.
+      const __amdgpu_buffer_rsrc_t wfr = __builtin_amdgcn_make_buffer_rsrc(Wf, 0, (int)(mm * sizeof(float)), 0x00020000);
+      for (int idx = tid; idx < 4 * 256; idx += 512) {
+        const int sub = idx >> 8, g = idx & 255, v4 = g >> 6, l6 = g & 63, li = l6 & 31, h = l6 >> 5;
+        const int tsub = sub >> 1, qsub = sub & 1;
+        const int c = 32 * tsub + li, r4 = 32 * qsub + 16 * h + 4 * v4;
+        CpV4 v = *reinterpret_cast<const CpV4*>(&colbuf[1][c][r4]);
+        if (ydiag) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (r4 + e > c) v[e] = 0.f;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(CpU4, v), wfr, (int)(frag_off(2 * j + tsub, 2 * irow + qsub, g) * 4), 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_fetch_add(a.sync + cp_wready_off(a.B, nb) + (size_t)b * nb + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // W(j, irow) = Y(irow, j)^T: row c of the block is the published column c
     for (int idx = tid; idx < CP_NB * (CP_NB / 4); idx += 512) {
       const int c = idx >> 4, r4 = (idx & 15) * 4;
@@ -517,7 +564,7 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
       for (int idx = tid; idx < 4 * 256; idx += 512) {
         const int sub = idx >> 8, g = idx & 255, v4 = g >> 6, l6 = g & 63, li = l6 & 31, h = l6 >> 5;
         const int tsub = sub >> 1, qsub = sub & 1;
-        {
+        if (!a.early) {
           // W image: row 32 (2j + tsub) + li = column 32 tsub + li of the block; k = 64 i' + 32 qsub + 16 h + 4 v4 + s
           const int c = 32 * tsub + li, r4 = 32 * qsub + 16 * h + 4 * v4;
           CpV4 v = *reinterpret_cast<const CpV4*>(&colbuf[1][c][r4]);
@@ -587,20 +634,5 @@ __global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJo
 #endif
 
   // ---- arrival; the last workgroup writes info[] and leaves the sync words zero for the next call
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(&a.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (old == (unsigned)a.total - 1u) ? 1u : 0u;
-  }
-  __syncthreads();
-  if (s_last) {
-    const unsigned tmo = __hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int bb = tid; bb < a.B; bb += 512) {
-      const unsigned f = __hip_atomic_load(&a.sync[CP_HDR + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a.info[bb] = tmo ? -1 : (f ? (int)(CP_FAILBIG - f) : 0);
-    }
-    __syncthreads();
-    const long nw = CP_HDR + ((a.B + 3) / 4) * 4 + 4l * a.B * nb * nb;
-    for (long t = tid; t < nw; t += 512) __hip_atomic_store(&a.sync[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  cp_arrive(a, sh.s_last);
 }

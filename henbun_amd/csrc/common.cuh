@@ -168,3 +168,24 @@ __host__ __device__ static inline uint64_t hb_splitmix64(uint64_t& x) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
+
+// l = sqrt(d), inv = 1/l.  fp32: one v_rsq_f32 (1 ulp) + one multiply instead of the IEEE sqrt and
+// divide sequences (~25 instructions on the critical path of every column); fp64 keeps the exact forms.
+__device__ __forceinline__ void pivot_sqrt(float d, float& l, float& inv) {
+  inv = __builtin_amdgcn_rsqf(d);
+  l = d * inv;
+}
+__device__ __forceinline__ void pivot_sqrt(double d, double& l, double& inv) {
+  l = sqrt(d);
+  inv = 1.0 / l;
+}
+
+// fp32 -> three bf16 terms hi + mid + lo (each rounded to nearest even of what is left): the operand form of the
+// "bf16x3" contractions, whose six significant cross products reproduce the fp32-operand result to fp32 accuracy
+// (profiles/r01_bf16_split_study.txt) at the bf16 MFMA rate.
+__device__ __forceinline__ void hb_split_bf16x3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = (__bf16)x;
+  const float r1 = x - (float)hi;
+  mid = (__bf16)r1;
+  lo = (__bf16)(r1 - (float)mid);
+}

@@ -1131,17 +1131,6 @@ extern "C" int hb_matmul_f64(const double* A, const double* B, double* C, long b
                                sBias, act, flags, ws, ws_elems, (hipStream_t)stream);
 }
 
-// l = sqrt(d), inv = 1/l.  fp32: one v_rsq_f32 (1 ulp) + one multiply instead of the IEEE sqrt and
-// divide sequences (~25 instructions on the critical path of every column); fp64 keeps the exact forms.
-__device__ __forceinline__ void pivot_sqrt(float d, float& l, float& inv) {
-  inv = __builtin_amdgcn_rsqf(d);
-  l = d * inv;
-}
-__device__ __forceinline__ void pivot_sqrt(double d, double& l, double& inv) {
-  l = sqrt(d);
-  inv = 1.0 / l;
-}
-
 // Finishing pass of the factorisation: clears the strict upper triangles of L (and W = L^-1), and -- when `Wf` is
 // given (M % 32 == 0) -- also leaves two FRAGMENT-MAJOR copies of W for the M^2 n contractions (csrc/sgp.hip):
 //   Wf  [B][M/32 row tiles][M/32 k chunks][4][64 lanes][4]:  element (t, Q, v, lane = (li, h), s) = W [32t+li][32Q+16h+4v+s]
@@ -1151,15 +1140,6 @@ __device__ __forceinline__ void pivot_sqrt(double d, double& l, double& inv) {
 // row-major matrix the same instruction touches 32 different lines for 32 bytes each, and the CU's texture
 // addresser / L1 -- 64 B per clock -- was as busy as the matrix pipes (profiles/r01_strip_ablation.txt: loads alone
 // 12.4 us against MFMAs alone 16.3 us).
-// fp32 -> three bf16 terms hi + mid + lo (each rounded to nearest even of what is left): the operand form of the
-// "bf16x3" contractions, whose six significant cross products reproduce the fp32-operand result to fp32 accuracy
-// (profiles/r01_bf16_split_study.txt) at the bf16 MFMA rate.
-__device__ __forceinline__ void hb_split_bf16x3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
-  hi = (__bf16)x;
-  const float r1 = x - (float)hi;
-  mid = (__bf16)r1;
-  lo = (__bf16)(r1 - (float)mid);
-}
 
 template <typename T>
 __global__ void __launch_bounds__(256) tril_inplace_kernel(T* __restrict__ L, T* __restrict__ W, T* __restrict__ Wf, int bf16x3,
@@ -2138,6 +2118,25 @@ struct CpGram {   // K(X, X) + diag I to be synthesised by the launch (A == null
   int kind = 0;
   float diag = 0.f;
 };
+__global__ void __launch_bounds__(512, 2) chol_persist_kernel(CpArgs a, HbSideJobs side) {
+  if ((int)blockIdx.x >= a.total) {
+    // small independent launches of the step ride here as extra workgroups (side_jobs.cuh); their bodies are written
+    // for 256-thread blocks: the upper half of this block leaves
+    if (threadIdx.x < 256) hb_side_run(side, (int)blockIdx.x - a.total);
+    return;
+  }
+  __shared__ __attribute__((aligned(16))) char lds[sizeof(CpLds)];
+  __shared__ unsigned s_ticket;
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  chol_persist_body(a, *reinterpret_cast<CpLds*>(lds), s_ticket);
+}
+
+// csrc/sgp.hip: a recorded forward contraction (hb_sgp_rider_begin) that this factorisation feeds starts inside the same
+// launch.  1: launched (factorisation included); 0: nothing recorded or not compatible; < 0: error.
+int hb_sgp_rider_launch_with(CpArgs& a, const HbSideJobs& sj, hipStream_t stream);
+int hb_sgp_rider_launch_alone(hipStream_t stream);   // a recorded forward that could not ride: launched on its own now
+
 static int chol_persist_launch(const float* A, const CpGram& g, float* L, float* W, float* ws, float* Wf, int bf16x3, long B, long M,
                                int* info, hipStream_t stream) {
   CpArgs a;
@@ -2148,15 +2147,18 @@ static int chol_persist_launch(const float* A, const CpGram& g, float* L, float*
   a.info = info;
   a.M = (int)M, a.B = (int)B, a.nb = (int)(M / CP_NB);
   a.total = (int)cp_total(B, a.nb, 1);
+  a.early = 0, a.nside = 0, a.arrive = a.total, a.poll_naps = 1;
 #ifdef HB_CP_STAMPS
   a.stamps = hb_cp_stamps_buffer;   // diagnostic build (tools/chol_persist_stamps.hip)
 #else
   a.stamps = nullptr;
 #endif
   const HbSideJobs sj = hb_side_take();   // pending side jobs of this thread ride on this launch
+  const int rr = hb_sgp_rider_launch_with(a, sj, stream);
+  if (rr != 0) return rr < 0 ? rr : 0;
   hipLaunchKernelGGL(chol_persist_kernel, dim3((unsigned)(a.total + sj.total)), dim3(512), 0, stream, a, sj);
   HB_LAUNCH_CHECK();
-  return 0;
+  return hb_sgp_rider_launch_alone(stream);
 }
 static inline bool chol_persist_shape(long B, long M, size_t elem) {
   return elem == 4 && M >= CP_NB && M % CP_NB == 0 && M <= 8192 && B >= 1 && B * (M / CP_NB) * (M / CP_NB) <= 65536;

@@ -20,6 +20,7 @@
 #include "common.cuh"
 #include "sgp_strip.cuh"  // strip constants, sgp_store_frag_tile
 #include "chain.cuh"      // serial chains: the finishing pass may be recorded instead of launched
+#include "chol_persist.cuh"  // the early-start form runs inside the persistent factorisation's launch
 #include <type_traits>
 #include "gemm_tile.cuh"
 #include "rng_pairs.cuh"
@@ -833,6 +834,108 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs
   HB_SSTAMP(3);
 }
 
+__device__ __forceinline__ float sgp_ag_load(const float* p) {   // agent-scope load (data written earlier in the SAME launch)
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define SGP_RED_LD 260   // floats per (quantity, column) in the end-of-kernel fold: 8 waves x 32 lanes + 4 (bank skew)
+// Epilogue of the third strip form (also the early-start form below): fold the per-lane statistics over the 256 (wave,
+// row-lane) contributions of every column, then -- a.fin -- the finishing pass and the likelihood head of the strip.
+// AG: y was written by a side job of the SAME launch (early-start form): read it with agent-scope loads.
+template <bool AG>
+__device__ __forceinline__ void sgp_2t_epilogue(const SgpArgs<float>& a, float* lds_raw, const float (&csq)[16], const float (&cu)[16],
+                                                const long e, const int bx, const int col0, const int n, const bool means) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  if (a.part) {
+    __syncthreads();  // every wave is done reading the K block
+    float* red = lds_raw;   // [2 quantities][32 columns][SGP_RED_LD]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
+      red[(0 * SGP_SN + c) * SGP_RED_LD + 32 * w + li] = csq[r];
+      if (means) red[(1 * SGP_SN + c) * SGP_RED_LD + 32 * w + li] = cu[r];
+    }
+    __syncthreads();
+    // 8 threads per (quantity, column): 32 contributions each in a fixed order, then a fixed 3-level tree
+    const int pair = tid >> 3, g = tid & 7;           // pair = quantity * 32 + column
+    const float* rp = red + pair * SGP_RED_LD + 32 * g;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const V4 q = *reinterpret_cast<const V4*>(rp + 4 * i);
+      sum += (q[0] + q[1]) + (q[2] + q[3]);
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    const int q = pair >> 5, c = pair & 31;
+    if (!a.fin) {
+      if (g == 0 && col0 + c < n && (q == 0 || means)) a.part[e * 5 * a.n + (long)q * n + col0 + c] = sum;
+      return;
+    }
+    // The finishing pass, here: one workgroup owns ALL rows of its 32 columns, so the totals just folded are final --
+    // v = 1 - sum A^2, f = u A + sqrt|v| eps for the strip (the residual noise drawn from the same per-pair RNG lanes
+    // and in the same pair order as the stand-alone pass, sgp_finish_part_kernel, whose launch -- 4.9 us of the cfg-2
+    // step for 64 KB of work -- disappears).  Same operations in the same order: same bits.
+    __syncthreads();                     // every thread is done reading the fold buffer
+    float* tot = lds_raw;                // [2][32]
+    if (g == 0) tot[q * 32 + c] = (q == 0 || means) ? sum : 0.f;
+    __syncthreads();
+    float h_ll = 0.f, h_sc = 0.f, h_vr = 0.f;
+    if (tid < 16) {
+      const long j0 = col0 + 2 * tid;    // (n is even: a pair is wholly inside or outside)
+      if (j0 < n) {
+        const long idx0 = e * (long)a.n + j0, pidx = idx0 >> 1;
+        float z0 = 0.f, z1 = 0.f;
+        if (a.fin_rng) {
+          HbRng gen = rng_load(a.fin_rng, a.fin_lanes, pidx);
+          gen.normal2(z0, z1);
+          rng_store(a.fin_rng, a.fin_lanes, pidx, gen);
+        } else if (a.fin_eps_in) {
+          z0 = AG ? sgp_ag_load(a.fin_eps_in + idx0) : a.fin_eps_in[idx0];
+          z1 = AG ? sgp_ag_load(a.fin_eps_in + idx0 + 1) : a.fin_eps_in[idx0 + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float s2 = 0.f + tot[2 * tid + i];
+          const float vv = 1.f - s2;
+          const float zi = i ? z1 : z0;
+          a.fin_v[idx0 + i] = vv;
+          if (a.fin_eps_out && a.fin_eps_out != a.fin_eps_in) a.fin_eps_out[idx0 + i] = zi;
+          const float scale = a.fin_diag ? hb_sqrt(hb_abs(vv)) * zi : 0.f;
+          const float fj = (0.f + tot[32 + 2 * tid + i]) + scale;
+          if (a.P > 0) a.fin_f[(e * a.P) * (long)a.n + j0 + i] = fj;
+          if (a.head) {
+            // the likelihood head of this point (same operations as hb_gauss_ll's kernels)
+            const float hs = a.hscale ? a.hscale[0] : 1.f, hv = a.hvar[0];
+            const float iv = 1.f / hv, lc = -0.91893853320467274178f - 0.5f * hb_log(hv);
+            float gg;
+            hb_gauss_point<float>(AG ? sgp_ag_load(a.hy + idx0 + i) : a.hy[idx0 + i], fj, hs, iv, lc, gg, h_ll, h_sc, h_vr);
+            a.hdmu[idx0 + i] = gg;
+            if (a.hfbar) a.hfbar[idx0 + i] = hs * (a.hpost * gg);
+          }
+        }
+      }
+    }
+    if (a.head && tid < 64) {
+      // the strip's partial sums: the sixteen pair threads sit in lanes 0..15 of wave 0 (fixed order)
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        h_ll += __shfl_xor(h_ll, off, 16);
+        h_sc += __shfl_xor(h_sc, off, 16);
+        h_vr += __shfl_xor(h_vr, off, 16);
+      }
+      if (tid == 0) {
+        const long unit = e * (long)((n + SGP_SN - 1) / SGP_SN) + bx;
+        a.hpart[unit] = h_ll;
+        a.hpart[a.hunits + unit] = h_sc;
+        a.hpart[2 * a.hunits + unit] = h_vr;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Column-strip contraction, third form (round 3): transposed accumulators, two workgroups per CU.
 //
@@ -847,7 +950,6 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs
 // form; the column sums are taken in another (fixed) order.  Handles P <= 1 column means (the registers of more would
 // not fit): the launcher keeps the second form for the rest.
 // ---------------------------------------------------------------------------------------------------------------
-#define SGP_RED_LD 260   // floats per (quantity, column) in the end-of-kernel fold: 8 waves x 32 lanes + 4 (bank skew)
 template <int D>
 __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(SgpArgs<float> a) {
   typedef float V4 __attribute__((ext_vector_type(4)));
@@ -1006,93 +1108,359 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
     }
   }
 
-  // ---- epilogue: fold the per-lane statistics over the 256 (wave, row-lane) contributions of every column
-  if (a.part) {
-    __syncthreads();  // every wave is done reading the K block
-    float* red = lds_raw;   // [2 quantities][32 columns][SGP_RED_LD]
+  sgp_2t_epilogue<false>(a, lds_raw, csq, cu, e, bx, col0, n, means);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Early-start form (round 4): the forward contraction inside the persistent Cholesky's launch.
+//
+// The persistent factorisation (chol_persist.cuh) is a chain of 512 dependent pivot columns: 60 us at M = 512 on nb^2 = 64
+// workgroups, with three quarters of the chip idle, and A = W K(z, x) used to start only when its launch had ended.  But
+// row block j of W = L^-1 (64 rows) is FINAL as soon as panel j is factored (W(j, c) = Y(c, j)^T; the elimination of
+// [A; I] finishes column block j of Y in panel j).  So the strips of the forward contraction ride in the same grid: a
+// strip workgroup synthesises its K block at once, then takes the row tiles of A in the order in which their rows of
+// the W image become final -- a per-(matrix, row block) counter raised by the factorisation's workgroups behind
+// write-through stores of the image, polled here, the image read with agent-scope loads (cdna_hip_programming.md
+// Guideline 16 R1, as for the panels) -- and only the LAST row block's work remains when the factorisation ends.  That
+// remainder (2 tiles x nT k-steps) is split three ways over six waves (k-steps p, p + 3, ...; partial accumulators
+// meet through one 4 KB LDS slot per tile, owner + helper 1 + helper 2 in that order: fixed summation order).
+//   Roles come from the launch's ticket counter in START order: factorisation first, then the side jobs of the launch
+// (minibatch gather, sample of q(u): this form reads their outputs, so they release them and raise sync[3]), then the
+// strips -- every wait is for a lower ticket, i.e. for a workgroup that is already running (no residency assumption),
+// and every wait is bounded (CpWait).  All roles take part in the arrival count that ends in info[] and zeroed sync words.
+//   Every tile of A but the last two keeps the bits of sgp_A_strip2t_kernel; those two differ by the order of three partial sums.
+// ---------------------------------------------------------------------------------------------------------------
+#define SGP_E_DMAX 2
+#define SGP_E_RAW_BYTES (2 * SGP_SN * SGP_RED_LD * 4)                    // K block / fold buffer (the larger of the two)
+#define SGP_E_ZS_OFF SGP_E_RAW_BYTES
+#define SGP_E_RED_OFF (SGP_E_ZS_OFF + SGP_SM_MAX * SGP_E_DMAX * 4)
+#define SGP_E_CTL_OFF (SGP_E_RED_OFF + 2 * 4096)
+#define SGP_E_LDS_BYTES (SGP_E_CTL_OFF + 64)     // control words: [0], [1] slot states, [3] arrival, [4] poll lock, [8 + j] row block j known ready
+static_assert(SGP_SN * SGP_SLD * 4 <= SGP_E_RAW_BYTES, "K block must fit the raw area");
+static_assert(sizeof(CpLds) <= SGP_E_LDS_BYTES, "the factorisation's LDS is overlaid on the strip form's");
+static_assert(2 * SGP_E_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+template <int D>
+__device__ __forceinline__ void sgp_early_body(const SgpArgs<float>& a, const CpArgs& ca, char* lds, const int unit) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  typedef Mma<float> MM;
+  float* lds_raw = reinterpret_cast<float*>(lds);
+  float (*Ks)[SGP_SLD] = reinterpret_cast<float (*)[SGP_SLD]>(lds_raw);
+  float* zs = reinterpret_cast<float*>(lds + SGP_E_ZS_OFF);
+  float* red3 = reinterpret_cast<float*>(lds + SGP_E_RED_OFF);     // [tile of the last row block][4 v][64 lanes][4]
+  int* ctl = reinterpret_cast<int*>(lds + SGP_E_CTL_OFF);           // (see SGP_E_LDS_BYTES)
+  const int M = (int)a.M, n = (int)a.n, nT = M / 32, nb = ca.nb;
+  const int nS = (n + SGP_SN - 1) / SGP_SN;
+  const long e = unit / nS;
+  const int bx = unit - (int)e * nS;
+  const float* __restrict__ x = a.x + e * a.sx;
+  const float* __restrict__ z = a.z + e * a.M * D;
+  const float* __restrict__ ell = a.ell + e * a.dl;
+  float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
+  const int col0 = bx * SGP_SN;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool means = a.part && a.P > 0;
+  CpWait wt = {ca.sync + 2, __builtin_amdgcn_s_memrealtime() + CP_TIMEOUT_TICKS, false};
+  if (tid < 16) ctl[tid] = 0;
+  // the side jobs of this launch have released x, u, y (ONE polling wave per workgroup: two thousand waves polling one
+  // word starve the factorisation's own flag traffic)
+  if (ca.nside > 0 && w == 0) wt.wait(ca.sync + 3, (unsigned)ca.nside);
+  __syncthreads();
+
+  // ---- K(z, x[strip]) -> LDS (as in the other forms: difference first, then the exp2 scale)
+  {
+    const int c = tid & 31, kq = tid >> 5;
+    const int cc = col0 + c < n ? col0 + c : n - 1;
+    float sc[D], xs[D];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
-      red[(0 * SGP_SN + c) * SGP_RED_LD + 32 * w + li] = csq[r];
-      if (means) red[(1 * SGP_SN + c) * SGP_RED_LD + 32 * w + li] = cu[r];
+    for (int dd = 0; dd < D; ++dd) {
+      sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
+      xs[dd] = sgp_ag_load(x + cc * D + dd);
+    }
+    constexpr int NTH = SGP_STRIP_THREADS;
+    constexpr int ZIT = (SGP_SM_MAX * D) / NTH;
+    float zt[ZIT];
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + NTH * it;
+      zt[it] = z[i < M * D ? i : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < ZIT; ++it) {
+      const int i = tid + NTH * it;
+      if (i < M * D) zs[i] = zt[it];
     }
     __syncthreads();
-    // 8 threads per (quantity, column): 32 contributions each in a fixed order, then a fixed 3-level tree
-    const int pair = tid >> 3, g = tid & 7;           // pair = quantity * 32 + column
-    const float* rp = red + pair * SGP_RED_LD + 32 * g;
-    float sum = 0.f;
+#pragma unroll 4
+    for (int k4 = kq * 4; k4 < M; k4 += NTH / 8) {
+      float zq[4 * D];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const V4 q = *reinterpret_cast<const V4*>(rp + 4 * i);
-      sum += (q[0] + q[1]) + (q[2] + q[3]);
-    }
-    sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
-    sum += __shfl_xor(sum, 4);
-    const int q = pair >> 5, c = pair & 31;
-    if (!a.fin) {
-      if (g == 0 && col0 + c < n && (q == 0 || means)) a.part[e * 5 * a.n + (long)q * n + col0 + c] = sum;
-      return;
-    }
-    // The finishing pass, here: one workgroup owns ALL rows of its 32 columns, so the totals just folded are final --
-    // v = 1 - sum A^2, f = u A + sqrt|v| eps for the strip (the residual noise drawn from the same per-pair RNG lanes
-    // and in the same pair order as the stand-alone pass, sgp_finish_part_kernel, whose launch -- 4.9 us of the cfg-2
-    // step for 64 KB of work -- disappears).  Same operations in the same order: same bits.
-    __syncthreads();                     // every thread is done reading the fold buffer
-    float* tot = lds_raw;                // [2][32]
-    if (g == 0) tot[q * 32 + c] = (q == 0 || means) ? sum : 0.f;
-    __syncthreads();
-    float h_ll = 0.f, h_sc = 0.f, h_vr = 0.f;
-    if (tid < 16) {
-      const long j0 = col0 + 2 * tid;    // (n is even: a pair is wholly inside or outside)
-      if (j0 < n) {
-        const long idx0 = e * (long)a.n + j0, pidx = idx0 >> 1;
-        float z0 = 0.f, z1 = 0.f;
-        if (a.fin_rng) {
-          HbRng gen = rng_load(a.fin_rng, a.fin_lanes, pidx);
-          gen.normal2(z0, z1);
-          rng_store(a.fin_rng, a.fin_lanes, pidx, gen);
-        } else if (a.fin_eps_in) {
-          z0 = a.fin_eps_in[idx0], z1 = a.fin_eps_in[idx0 + 1];
+      for (int q = 0; q < 4 * D; q += 4) {
+        const V4 zz = *reinterpret_cast<const V4*>(&zs[k4 * D + q]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) zq[q + s] = zz[s];
+      }
+      V4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float r2 = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          const float tt = (zq[q * D + dd] - xs[dd]) * sc[dd];
+          r2 += tt * tt;
         }
+        v[q] = hb_exp2_neg<float>(r2);
+      }
+      *reinterpret_cast<V4*>(&Ks[c][k4]) = v;
+    }
+  }
+  __syncthreads();
+
+  float csq[16], cu[16];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const float s2 = 0.f + tot[2 * tid + i];
-          const float vv = 1.f - s2;
-          const float zi = i ? z1 : z0;
-          a.fin_v[idx0 + i] = vv;
-          if (a.fin_eps_out && a.fin_eps_out != a.fin_eps_in) a.fin_eps_out[idx0 + i] = zi;
-          const float scale = a.fin_diag ? hb_sqrt(hb_abs(vv)) * zi : 0.f;
-          const float fj = (0.f + tot[32 + 2 * tid + i]) + scale;
-          if (a.P > 0) a.fin_f[(e * a.P) * (long)a.n + j0 + i] = fj;
-          if (a.head) {
-            // the likelihood head of this point (same operations as hb_gauss_ll's kernels)
-            const float hs = a.hscale ? a.hscale[0] : 1.f, hv = a.hvar[0];
-            const float iv = 1.f / hv, lc = -0.91893853320467274178f - 0.5f * hb_log(hv);
-            float gg;
-            hb_gauss_point<float>(a.hy[idx0 + i], fj, hs, iv, lc, gg, h_ll, h_sc, h_vr);
-            a.hdmu[idx0 + i] = gg;
-            if (a.hfbar) a.hfbar[idx0 + i] = hs * (a.hpost * gg);
+  for (int r = 0; r < 16; ++r) csq[r] = 0.f, cu[r] = 0.f;
+  typename MM::Acc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wf) + e * a.M * a.M, 0,
+                                                                      (int)(a.M * a.M * sizeof(float)), 0x00020000);
+  const unsigned* wready = ca.sync + cp_wready_off(ca.B, nb) + e * nb;
+
+  auto load = [&](V4 (&f)[4], int tile, int Q) {
+    const int off = ((tile * nT + Q) << 12) + 16 * lane;      // bytes
+#pragma unroll
+    // (agent-scope loads, as for everything another workgroup of the same launch has written; measured against plain
+    // L2-cached loads -- which would be safe here, the image being written through before its counter is raised and every
+    // L2 having been invalidated when the launch started -- the time is the same: profiles/r04_early_forward_check_*.txt)
+    for (int v = 0; v < 4; ++v) f[v] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(wr, off + 1024 * v, 0, 16));
+  };
+  auto mma_step = [&](const V4 (&f)[4], int Q) {
+    V4 bv[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bv[v] = *reinterpret_cast<const V4*>(&Ks[li][32 * Q + 16 * h + 4 * v]);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = MM::mma(bv[v][s], f[v][s], acc);   // transposed tile: rows on the lanes
+  };
+  // k-steps q0, q0 + dq, ... <= tile of one row tile, operands in two register sets used alternately
+  auto run = [&](int tile, int q0, int dq) {
+    if (q0 > tile || (ca.early & 4)) return;
+    const int ns = (tile - q0) / dq + 1;
+    V4 fa[4], fb[4];
+    load(fa, tile, q0);
+#pragma nounroll
+    for (int i = 0; i < ns; i += 2) {
+      const int Q0 = q0 + i * dq, Q1 = Q0 + dq, Q2 = Q1 + dq;
+      load(fb, tile, Q1 <= tile ? Q1 : Q0);             // past the end: re-read (never used)
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(fa, Q0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(fa, tile, Q2 <= tile ? Q2 : Q0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < ns) mma_step(fb, Q1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // a complete tile: statistics from the registers as they stand, then the row-per-lane view and the stores
+  auto retire = [&](int tile, float um) {
+    if (a.part) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        csq[r] += acc[r] * acc[r];
+        cu[r] += um * acc[r];
+      }
+    }
+    sgp_acc_t_settle(acc);
+    float row16[16];
+    sgp_acc_t_rows(acc, row16);
+    if (a.Af) sgp_store_frag_rows(a.Af, row16, e, nT, nS, tile, bx, col0, n, lane);
+    if (A) {
+      float* ap = A + (long)(32 * tile + li) * n + col0 + 16 * h;
+      if ((n & 3) == 0 && col0 + SGP_SN <= n) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          V4 q;
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) q[s2] = row16[4 * v + s2];
+          *reinterpret_cast<V4*>(ap + 4 * v) = q;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (col0 + 16 * h + i < n) ap[i] = row16[i];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  };
+  // row block j of the W image is final.  At most one wave of the workgroup polls the global counter at a time (LDS
+  // lock), the others watch the LDS copy of the answer.
+  auto wait_ready = [&](int j) {
+    if (wt.dead) return;
+    unsigned spins = 0;
+    for (;;) {
+      if (__hip_atomic_load(ctl + 8 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
+      if (__hip_atomic_exchange(ctl + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+        const unsigned c = __hip_atomic_load(wready + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = c >= (unsigned)j + 1u;
+        if (ok) __hip_atomic_store(ctl + 8 + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bool give_up = false;
+        if (!ok && (++spins & 31u) == 0u &&
+            (__hip_atomic_load(wt.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || __builtin_amdgcn_s_memrealtime() > wt.deadline)) {
+          __hip_atomic_store(wt.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(ctl + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          give_up = true;
+        }
+        __hip_atomic_store(ctl + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (ok) break;
+        if (give_up) { wt.dead = true; return; }
+        for (int nap = 0; nap < ca.poll_naps; ++nap) __builtin_amdgcn_s_sleep(8);
+      } else {
+        if (__hip_atomic_load(ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { wt.dead = true; return; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the image loads below the poll
+  };
+  auto lds_wait = [&](const int* p, int v) {
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+  const float* up = a.u + e * a.P * a.M;
+
+  // ---- row blocks 0 .. nb - 2: tile t belongs to wave t & 7, whole
+  const int last0 = nT - 2;
+#pragma unroll 1
+  for (int tile = w; tile < last0; tile += SGP_STRIP_THREADS / 64) {
+    wait_ready(tile >> 1);
+    const float um = means ? sgp_ag_load(up + 32 * tile + li) : 0.f;
+    run(tile, 0, 1);
+    retire(tile, um);
+  }
+  // ---- the last row block: tile last0 + th is split over the waves (last0 + th + 2 p) & 7, p = 0 (owner), 1, 2
+  {
+    const int th = w & 1, tile = last0 + th;
+    const int p = ((w - th - last0) & 7) >> 1;
+    if (p < 3 && p <= tile) {
+      wait_ready(nb - 1);
+      const float um = (means && p == 0) ? sgp_ag_load(up + 32 * tile + li) : 0.f;
+      run(tile, p, 3);
+      float* slot = red3 + th * 1024;
+      int* st = ctl + th;
+      if (p == 0) {
+#pragma unroll 1
+        for (int hp = 1; hp <= 2 && hp <= tile; ++hp) {
+          lds_wait(st, 2 * hp - 1);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const V4 q = *reinterpret_cast<const V4*>(&slot[(v * 64 + lane) * 4]);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc[4 * v + s2] += q[s2];
           }
+          asm volatile("" ::: "memory");
+          __hip_atomic_store(st, 2 * hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS runs a wave's operations in order)
+          asm volatile("" ::: "memory");
         }
-      }
-    }
-    if (a.head && tid < 64) {
-      // the strip's partial sums: the sixteen pair threads sit in lanes 0..15 of wave 0 (fixed order)
+        retire(tile, um);
+      } else {
+        lds_wait(st, 2 * (p - 1));
 #pragma unroll
-      for (int off = 8; off > 0; off >>= 1) {
-        h_ll += __shfl_xor(h_ll, off, 16);
-        h_sc += __shfl_xor(h_sc, off, 16);
-        h_vr += __shfl_xor(h_vr, off, 16);
-      }
-      if (tid == 0) {
-        const long unit = e * (long)((n + SGP_SN - 1) / SGP_SN) + bx;
-        a.hpart[unit] = h_ll;
-        a.hpart[a.hunits + unit] = h_sc;
-        a.hpart[2 * a.hunits + unit] = h_vr;
+        for (int v = 0; v < 4; ++v) {
+          const V4 q = {acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]};
+          *reinterpret_cast<V4*>(&slot[(v * 64 + lane) * 4]) = q;
+        }
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(st, 2 * p - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
       }
     }
   }
+
+  sgp_2t_epilogue<true>(a, lds_raw, csq, cu, e, bx, col0, n, means);
+  cp_arrive(ca, *reinterpret_cast<unsigned*>(ctl + 3));
+}
+
+// One launch, three roles by ticket (start order): the persistent factorisation, the launch's side jobs, the strips.
+template <int D>
+__global__ void __launch_bounds__(512, 4) chol_sgp_fwd_kernel(CpArgs ca, HbSideJobs side, SgpArgs<float> a) {
+  __shared__ __attribute__((aligned(16))) char lds[SGP_E_LDS_BYTES];
+  __shared__ unsigned s_ticket;
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ca.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned t = s_ticket;
+  if (t < (unsigned)ca.total) {
+    chol_persist_body(ca, *reinterpret_cast<CpLds*>(lds), t);
+    return;
+  }
+  if (t < (unsigned)(ca.total + ca.nside)) {
+    // (the job bodies are written for 256-thread blocks: the upper half of this block leaves)
+    if (threadIdx.x >= 256) return;
+    hb_side_run(side, (int)t - ca.total);
+    __syncthreads();   // every wave's stores have left for L2
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&ca.sync[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // L2 write-back, then the count
+    return;
+  }
+  if (ca.early & 2) {   // (diagnostic: the strips leave at once)
+    cp_arrive(ca, s_ticket);
+    return;
+  }
+  sgp_early_body<D>(a, ca, lds, (int)t - ca.total - ca.nside);
+}
+
+// ---- the recorded forward ("rider"): hb_sgp_rider_begin() ... hb_sgp_fwd_* ... hb_cholesky_inverse_f32 / hb_gram_cholesky_inverse_f32
+struct SgpRider {
+  bool armed = false, valid = false;
+  SgpArgs<float> a;
+  long E = 0;
+};
+static thread_local SgpRider g_rider;
+static int sgp_A_strip_launch(SgpArgs<float> a, long E, hipStream_t stream);
+static inline bool sgp_fused_finish_ok(long E, long n, long M, long d, long P, int prec, bool has_wfrag, bool draw, long rng_lanes);
+
+extern "C" int hb_sgp_rider_supported(long E, long n, long M, long d, long P, int prec, int has_wfrag, int draw, long rng_lanes) {
+  if (hb_debug_get("sgp_early", 1) == 0) return 0;
+  return sgp_fused_finish_ok(E, n, M, d, P, prec, has_wfrag != 0, draw != 0, rng_lanes) && d <= SGP_E_DMAX && M % CP_NB == 0 &&
+                 hb_cholesky_persistent_shape(E, M, 4)
+             ? 1
+             : 0;
+}
+extern "C" int hb_sgp_rider_begin(void) {
+  HB_REQUIRE(!g_rider.valid, "hb_sgp_rider_begin: a recorded forward is still pending (hb_sgp_rider_flush)");
+  g_rider.armed = true;
+  return 0;
+}
+extern "C" int hb_sgp_rider_pending(void) { return g_rider.valid ? 1 : 0; }
+int hb_sgp_rider_launch_alone(hipStream_t stream) {
+  g_rider.armed = false;
+  if (!g_rider.valid) return 0;
+  g_rider.valid = false;
+  return sgp_A_strip_launch(g_rider.a, g_rider.E, stream);
+}
+extern "C" int hb_sgp_rider_flush(void* stream) { return hb_sgp_rider_launch_alone((hipStream_t)stream); }
+
+int hb_sgp_rider_launch_with(CpArgs& ca, const HbSideJobs& sj, hipStream_t stream) {
+  if (!g_rider.valid) return 0;
+  const SgpArgs<float>& a = g_rider.a;
+  const long E = g_rider.E, nS = hb_cdiv(a.n, SGP_SN);
+  static int cus = 0;   // (one device per process)
+  if (cus == 0 && (hb_device_info(nullptr, 0, &cus) || cus <= 0)) cus = 256;
+  const bool ok = a.Wf == ca.Wf && !ca.bf16x3 && E == ca.B && a.M == ca.M && a.M <= SGP_SM_MAX && a.d >= 1 && a.d <= SGP_E_DMAX &&
+                  a.fin && !a.W3 && (long)ca.total + sj.total + E * nS <= 2L * cus && hb_debug_get("sgp_early", 1) != 0;
+  if (!ok) return 0;   // (the caller launches the factorisation alone, then hb_sgp_rider_launch_alone)
+  ca.early = 1 | ((int)(hb_debug_get("sgp_early_diag", 0) & 3) << 1), ca.nside = sj.total, ca.arrive = ca.total + (int)(E * nS);   // (diag: timing variants)
+  g_rider.valid = false, g_rider.armed = false;
+  ca.poll_naps = (int)hb_debug_get("sgp_early_poll_naps", 1);
+  long nunits = E * nS;
+  if (hb_debug_get("sgp_early_diag", 0) == 4) nunits = 0, ca.arrive = ca.total;   // (diagnostic: the fused binary without its strips)
+  const dim3 grid((unsigned)(ca.total + sj.total + nunits));
+  if (a.d == 1)
+    hipLaunchKernelGGL((chol_sgp_fwd_kernel<1>), grid, dim3(512), 0, stream, ca, sj, a);
+  else
+    hipLaunchKernelGGL((chol_sgp_fwd_kernel<2>), grid, dim3(512), 0, stream, ca, sj, a);
+  HB_LAUNCH_CHECK();
+  return 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1557,6 +1925,15 @@ static int sgp_fwd(int kind, int mode, const T* x, long sx, const T* z, const T*
         }
       }
       HB_REQUIRE(!head || a.fin, "hb_sgp_fwd_gauss: this call cannot carry the head (hb_sgp_head_units(...) == 0)");
+      if constexpr (std::is_same<T, float>::value) {
+        if (g_rider.armed) {
+          // recorded, not launched: the factorisation that produces W / Wfrag launches it inside its own grid (early-start form)
+          HB_REQUIRE(a.fin && !a.W3 && d <= SGP_E_DMAX, "hb_sgp_fwd after hb_sgp_rider_begin: this call cannot ride (hb_sgp_rider_supported)");
+          sgp_grid(hb_cdiv(a.n, SGP_SN), 1, E, a.efast);
+          g_rider.a = a, g_rider.E = E, g_rider.valid = true, g_rider.armed = false;
+          return 0;
+        }
+      }
       rc = sgp_A_strip_launch(a, E, stream);
       if (rc) return rc;
       if (a.fin) return 0;

@@ -1126,10 +1126,28 @@ def _cholesky_emit(plan, node):
         gk = plan._gram_for_chol.get(node.id)
         if gk is not None:
             gX, gell, gkind, gjit = gk
-            plan.steps.append(lambda: H.gram_cholesky_inverse(gX, gell, gjit, kind=gkind, out=out, inv=w, info=info, ws=ws, frag=frag,
-                                                              frag_bf16x3=bf3))
+            factor = lambda: H.gram_cholesky_inverse(gX, gell, gjit, kind=gkind, out=out, inv=w, info=info, ws=ws, frag=frag,
+                                                     frag_bf16x3=bf3)
         else:
-            plan.steps.append(lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws, frag=frag, frag_bf16x3=bf3))
+            factor = lambda: H.cholesky_inverse(a, out=out, inv=w, info=info, ws=ws, frag=frag, frag_bf16x3=bf3)
+        # Early-start forward (csrc/sgp.hip): _sgp_emit may hand the forward contraction that consumes this inverse to
+        # this step -- it is then recorded first and launched INSIDE the persistent factorisation's grid.
+        cell = {"rider": None}
+
+        def chol_step():
+            r = cell["rider"]
+            if r is None:
+                return factor()
+            H.sgp_rider_begin()
+            r()                       # recorded, not launched
+            factor()                  # ONE launch: factorisation + pending side jobs + the recorded forward
+            H.sgp_rider_flush()       # (a no-op unless the factorisation could not take it)
+
+        cell["step"] = chol_step
+        cell["epos"] = len(plan._emitted)
+        if frag is not None and not bf3 and H.cholesky_persistent_shape(B, M, plan.dtype):
+            plan._chol_rider[inv_node.outputs[0]] = cell
+        plan.steps.append(chol_step)
         if host:
             plan.steps.append(lambda: H.side_flush())
         return
@@ -1722,6 +1740,34 @@ def _sgp_emit(plan, node):
             plan.pin_side_reads([g.inputs[0], g.inputs[2]] + ([g.inputs[3]] if len(g.inputs) > 3 else []))
     step = lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps_in, rng=rng, mode=mode, out=outs, wfrag=wfrag,
                              prec=prec, a_frag=a_frag, skip_a=skip_a, head=head)
+    # Early-start form: the contraction starts inside the launch of the persistent factorisation that produces W, when
+    # everything else it reads exists before that launch (or is written by a side job riding on it)
+    ep = "forward contraction starts inside the persistent Cholesky's launch (hb_sgp_rider_begin)"
+    cell = plan._chol_rider.get(_through_stop_gradient(node.inputs[4]))
+    from ._settings import settings as _st
+    if not bool(getattr(_st.runtime, "early_forward", False)):
+        cell = None
+    if cell is not None and cell["rider"] is None:
+        if not H.sgp_rider_supported(x, z, u, prec, wfrag is not None, eps_in is None and mode == 1, rng):
+            plan.note(ep, node, False, "needs the fused finishing pass (fp32, one latent function, d <= 2, M % 64 == 0)")
+        else:
+            reads = [node.inputs[0], node.inputs[1], node.inputs[2], node.inputs[5]] + list(node.inputs[6:])
+            if head is not None:
+                reads += [g.inputs[0], g.inputs[2]] + list(g.inputs[3:4])
+            early_nodes = {id(nd) for nd in plan._emitted[:cell["epos"]]}
+
+            def ready(t):
+                while t.node.op in ("reshape", "stop_gradient") and t.node.inputs:
+                    t = t.node.inputs[0]
+                return t.node.op.startswith("leaf:") or id(t.node) in early_nodes
+
+            if all(ready(t) for t in reads):
+                cell["rider"] = step
+                plan.step_labels[id(cell["step"])] = "cholesky+sgp"
+                plan.step_riders[id(cell["step"])] = node
+                plan.note(ep, node, True)
+                return
+            plan.note(ep, node, False, "an operand is produced after the factorisation has been launched")
     plan.steps.append(step)
     plan.chain_kind[id(step)] = "tail"       # its finishing pass may open a serial chain
 
@@ -2330,6 +2376,8 @@ class Plan:
         # X^T G whose right operand is also column-summed (reduce over axis 0) becomes hb_matmul_colsum -- the GEMM folds
         # the columns of G while it streams them, and the stand-alone reduction launches (two per layer) disappear.
         self._gram_for_chol: Dict[int, tuple] = {}   # cholesky node id -> (points, lengthscales, kind, jitter) of its folded Gram
+        self._chol_rider: Dict[Tensor, dict] = {}    # inverse tensor -> the persistent factorisation step's rider cell (_cholesky_emit)
+        self.step_riders: Dict[int, Node] = {}       # id(step closure) -> node whose work rides in that step's launch
         self._mlp2: Dict[int, dict] = {}             # mlp2_sample_kl node id -> {fused, ws | h}
         self._colsum_of: Dict[int, Node] = {}    # matmul node id -> the reduce node it absorbs
         self._fused_colsum = set()               # ids of absorbed reduce nodes

@@ -899,6 +899,31 @@ def sgp_head_units(x, z, u, prec, has_wfrag, draw, rng):
                                                   rng.nlanes if rng is not None else 0))
 
 
+def sgp_rider_supported(x, z, u, prec, has_wfrag, draw, rng):
+    """1 when this forward call can be recorded (sgp_rider_begin) and start inside the launch of the persistent
+    factorisation that produces its W (hb_sgp_rider_supported)."""
+    E, n, M, d, P, _ = _sgp_dims(x, z, u)
+    if x.dtype != torch.float32:
+        return False
+    return bool(_lib.lib().raw("hb_sgp_rider_supported")(E, n, M, d, P, int(prec), int(bool(has_wfrag)), int(bool(draw)),
+                                                         rng.nlanes if rng is not None else 0))
+
+
+def sgp_rider_begin():
+    """The next sgp_fwd call of this thread is recorded instead of launched; the next cholesky_inverse /
+    gram_cholesky_inverse launches it inside its own grid (include/henbun_hip.h: early-start forward)."""
+    _lib.lib().call("hb_sgp_rider_begin")
+
+
+def sgp_rider_flush():
+    """Launch a recorded forward that no factorisation picked up (a no-op otherwise)."""
+    _lib.lib().call("hb_sgp_rider_flush", stream())
+
+
+def sgp_rider_pending():
+    return int(_lib.lib().raw("hb_sgp_rider_pending")())
+
+
 def gauss_ll_fold(part, nb, ll, ds, dv):
     """(ll, dscale, dvar) from the partial sums part[3][nb] of a head whose per-point part ran elsewhere (hb_gauss_ll_fold)."""
     _lib.lib().call("hb_gauss_ll_fold" + _suf(part), _p(part), int(nb), _p(ll), _p(ds), _p(dv), stream())

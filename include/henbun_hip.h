@@ -488,6 +488,21 @@ int hb_sgp_fwd_gauss_f32(int kind, int mode, const float* x, long sx, const floa
                          long E, long n, long M, long d, long P, float* ws, const float* y, const float* scale,
                          const float* var, double post, float* dmu, float* fbar, float* head_part, long units,
                          void* stream);
+/* Early-start forward (round 4): the forward contraction INSIDE the launch of the factorisation that feeds it.  Row block j
+ * of W = L^-1 is final as soon as panel j of the persistent factorisation is done, so the strips of A = W K(z, x) can
+ * take their row tiles while the factorisation is still running on a quarter of the chip (csrc/sgp.hip, early-start form).
+ * Protocol, per thread:  hb_sgp_rider_begin();  ONE hb_sgp_fwd_f32 / hb_sgp_fwd_gauss_f32 call -- recorded, not launched
+ * (its W / Wfrag are the buffers the factorisation is about to write; hb_sgp_rider_supported(...) must be 1 for its
+ * arguments, otherwise the call fails);  then hb_cholesky_inverse_f32 / hb_gram_cholesky_inverse_f32 with the same
+ * Wfrag: ONE launch runs the factorisation, this thread's pending side jobs and the recorded forward.  If the
+ * factorisation cannot take it (other buffers, batch, size; bf16x3 images; more workgroups than two per CU) it launches
+ * as usual and the recorded forward right behind it, so the results never depend on whether the ride happened (bits of A:
+ * the last two row tiles are summed in three partial sums when it did).  hb_sgp_rider_flush launches a recorded
+ * forward that no factorisation picked up.  Reference: gp/gp.py:159-172 (L^-1 K(z, x) behind tf.cholesky). */
+int hb_sgp_rider_supported(long E, long n, long M, long d, long P, int prec, int has_wfrag, int draw, long rng_lanes);
+int hb_sgp_rider_begin(void);
+int hb_sgp_rider_pending(void);
+int hb_sgp_rider_flush(void* stream);
 int hb_gauss_ll_fold_f32(const float* partial, long nb, float* ll, float* dscale, float* dvar, void* stream);
 int hb_gauss_ll_fold_f64(const double* partial, long nb, double* ll, double* dscale, double* dvar, void* stream);
 /* The contraction alone, A = W k(z,x) (posterior-prediction callers; isolated timing). */

@@ -1167,6 +1167,81 @@ def test_likelihood_head_inside_the_forward_contraction(H, M, n):
             assert abs(float(a_) - float(b_)) <= 2e-6 * max(abs(float(a_)), float(n) ** 0.5), (float(a_), float(b_))   # observed <= 3e-7 relative
 
 
+@pytest.mark.parametrize("M,n,E", [(512, 8192, 1), (128, 1000, 1), (256, 2048, 2), (64, 64, 1)])
+def test_forward_contraction_inside_the_persistent_cholesky_launch(H, M, n, E):
+    """Early-start form (hb_sgp_rider_begin; csrc/sgp.hip chol_sgp_fwd_kernel): the forward contraction recorded and
+    launched INSIDE the persistent factorisation's grid, taking its row tiles as the rows of W become final -- against the
+    two launches it replaces: L, W and the images keep their bits, f / v / A / the head's outputs agree to fp32 rounding
+    (the last two row tiles are summed as three partial sums), info is reported, a failed factorisation does not hang, the
+    sync words are left zero (the workspace is reused call after call), and a call the factorisation cannot take
+    (different image buffer) still runs, behind it."""
+    dt = torch.float32
+    rng = np.random.RandomState(M + n + E)
+    lead = (E,) if E > 1 else ()
+    z = dev(np.sort(rng.uniform(0, M / 2.0, lead + (M, 1)), axis=-2), dt)
+    x = dev(rng.uniform(0, M / 2.0, (n, 1)), dt)
+    ell = dev(np.ones(lead + (1,)), dt)
+    u, eps, y = dev(rng.randn(*(lead + (1, M))), dt), dev(rng.randn(*(lead + (n,))), dt), dev(rng.randn(*(lead + (n,))), dt)
+    var = dev(np.array([0.3]), dt)
+    K = torch.exp(-0.5 * (z - z.transpose(-1, -2)) ** 2) + 1e-3 * torch.eye(M, device="cuda")
+    assert H.cholesky_persistent_shape(E, M, dt)
+
+    def run(early, Kmat, other_frag=False):
+        L, W = torch.empty_like(Kmat), torch.empty_like(Kmat)
+        frag = torch.empty(2 * E * M * M, dtype=dt, device="cuda")
+        info = torch.zeros(E, dtype=torch.int32, device="cuda")
+        afrag = torch.full((H.sgp_frag_elems(E, n, M, H.PREC_NATIVE),), float("nan"), dtype=dt, device="cuda")
+        units = H.sgp_head_units(x, z, u, H.PREC_NATIVE, True, False, None)
+        head = dict(y=y, var=var, scale=None, post=0.5, dmu=torch.empty_like(y), fbar=torch.empty_like(y),
+                    part=torch.empty(3 * units, dtype=dt, device="cuda"), units=units) if E == 1 else None
+        out = (torch.empty(lead + (1, n), device="cuda"), torch.empty(lead + (M, n), device="cuda"),
+               torch.empty(lead + (n,), device="cuda"), torch.empty(lead + (n,), device="cuda"))
+        fwd = lambda: H.sgp_fwd(x, z, ell, W, u, eps_in=eps, mode=1, out=out, wfrag=frag, prec=H.PREC_NATIVE, a_frag=afrag,
+                                skip_a=True, head=head)
+        if early:
+            assert H.sgp_rider_supported(x, z, u, H.PREC_NATIVE, True, False, None)
+            H.sgp_rider_begin()
+            fwd()
+            assert H.sgp_rider_pending() == 1
+            # (other_frag: the factorisation writes its images elsewhere, so it cannot take the recorded forward; the
+            # forward then reads an image nobody wrote -- only the sequencing is checked in that case)
+            H.cholesky_inverse(Kmat, out=L, inv=W, info=info, frag=torch.empty_like(frag) if other_frag else frag)
+            assert H.sgp_rider_pending() == 0
+            H.sgp_rider_flush()
+        else:
+            H.cholesky_inverse(Kmat, out=L, inv=W, info=info, frag=frag)
+            fwd()
+        torch.cuda.synchronize()
+        r = dict(L=L, W=W, frag=frag, info=info, f=out[0], v=out[2], afrag=afrag)
+        if head is not None:
+            r.update(dmu=head["dmu"], fbar=head["fbar"], part=head["part"])
+        return r
+
+    ref, got = run(False, K), run(True, K)
+    assert ref["info"].tolist() == [0] * E and got["info"].tolist() == [0] * E
+    for k in ("L", "W", "frag"):
+        assert torch.equal(ref[k], got[k]), k
+    for k in ("f", "v", "afrag") + (("dmu", "fbar", "part") if E == 1 else ()):
+        a_, b_ = ref[k].double(), got[k].double()
+        err = float((a_ - b_).abs().max() / a_.abs().max())
+        assert err <= 2e-5, (k, err)     # observed <= 9.4e-6 (f), 2e-6 (A): three partial sums in the last two row tiles
+    for _ in range(3):                   # the workspace (sync words) is reused call after call
+        again = run(True, K)
+        assert torch.equal(again["f"], got["f"]) and torch.equal(again["afrag"], got["afrag"])
+    Kbad = K.clone()
+    Kbad[..., M // 3, M // 3] = -1.0
+    gb = run(True, Kbad)
+    assert gb["info"].tolist() == [M // 3 + 1] * E
+    ok = run(True, K)
+    assert ok["info"].tolist() == [0] * E and torch.equal(ok["f"], got["f"])
+    run(True, K, other_frag=True)        # not taken: the factorisation, then the forward on its own -- no error, nothing pending
+    H.debug_set("sgp_early", 0)          # the switch that keeps the forward a launch of its own
+    try:
+        assert not H.sgp_rider_supported(x, z, u, H.PREC_NATIVE, True, False, None)
+    finally:
+        H.debug_clear()
+
+
 @pytest.mark.parametrize("p", ["f32", "f64"])
 @pytest.mark.parametrize("n", [300, 8192, 40000])
 def test_gauss_ll_head_writes_the_gradient_for_f_itself(H, p, n):

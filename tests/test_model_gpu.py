@@ -159,6 +159,31 @@ def test_trailing_transforms_follow_host_side_parameter_writes():
     assert torch.equal(res[True][0], res[False][0]) and res[True][1] == res[False][1]
 
 
+def test_early_start_forward_through_the_model_api():
+    """settings.runtime.early_forward (opt-in): the compiled step launches the forward contraction inside the persistent
+    Cholesky's grid -- together with the side jobs of that launch (minibatch gather, sample of q(u)), whose outputs the
+    forward reads after their release.  Same minibatches, same noise streams: the training trajectory stays within fp32
+    rounding of the two-launch form, the plan really carries the fused step, and replays of the captured graph are
+    repeatable."""
+    res = {}
+    for early in (True, False):
+        cfg = hb.settings.get_settings()
+        cfg.numerics.jitter_level = 1e-4
+        cfg.runtime.early_forward = early
+        with hb.settings.temp_settings(cfg):
+            m, data = make_svgp(6000, 128, 2048, "diagonal", "float32", seed=5)
+            opt = m.ELBO()
+            opt.compile(optimizer=tf.train.AdamOptimizer(0.01))
+            opt.optimize(maxiter=8, minibatch_size=2048)
+            plan = opt.last_plan
+            labels = [plan.step_labels.get(id(s), "other") for s in plan.steps]
+            assert ("cholesky+sgp" in " ".join(labels)) == early, labels
+            res[early] = m._session.theta.clone()
+    a, b = res[True].double(), res[False].double()
+    # eight Adam steps of 0.01 each: a parameter moves by up to 0.08; the two forms differ by fp32 rounding in A
+    assert float((a - b).abs().max()) <= 5e-4                      # observed 4.6e-5 (one hyper-parameter), 4e-6 elsewhere
+
+
 def _two_rank_sessions(N, M, n, lr, seed=3):
     """Two models in ONE process set up as rank 0 / rank 1 of a world of two (no second process, no process group): shard
     of the data (parallel.shard_rows), rank-distinct `local` / `index` streams (parallel.rng_stream_ids), the global data
