@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix), spec
 PEAK_F64_MFMA_TFLOPS = 78.6
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 matrix peak (the sparsity figure is twice that and is never used)
 PEAK_HBM_GBS = 8000.0         # same guide: HBM3E peak BW, spec (6.29 TB/s measured copy)
 
 CONFIGS = {
@@ -448,10 +449,17 @@ def main():
                 traffic_src = "profiles/%s (%s)" % (os.path.basename(tfile), rec.get("kernel", lab))
         except (OSError, KeyError, ValueError, IndexError):
             pass
+        peaks_16bit = None
+        if bound == "mfma" and args.contraction == "bf16x3" and lab in ("sgp", "sgp_grad"):
+            # the M^2 n contractions run on the bf16 matrix pipe: SIX bf16 MFMAs (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi)
+            # per fp32-equivalent product, so their own ceiling is the dense bf16 peak / 6; both fractions are reported
+            pk = PEAK_BF16_MFMA_TFLOPS / 6.0
+            peaks_16bit = {"bf16_dense_peak": PEAK_BF16_MFMA_TFLOPS, "divisor": 6, "frac_of_bf16x3_effective_peak": achieved / pk,
+                           "frac_of_16bit_peak": achieved / PEAK_BF16_MFMA_TFLOPS, "frac_of_fp32_mfma_peak": achieved / peak}
         roofline = {"kernel": "%s [%s]" % (lab, shapes), "bound": bound, "achieved": achieved, "peak": pk, "unit": unit,
                     "frac": achieved / pk, "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_us": us,
                     "share_of_step": us / total if total else None, "flops_per_launch": f,
-                    "algorithmic_bytes_per_launch": b,
+                    "algorithmic_bytes_per_launch": b, "bf16x3": peaks_16bit,
                     "how": "largest of all plan steps, each timed stand-alone with HIP events on the plan's stream "
                            "(%d back-to-back calls); a step may be a short chain of launches" % 40}
     except Exception as e:  # never lose the headline over the diagnostics

@@ -46,6 +46,8 @@ _SIGS = {
     "hb_sgp_strip_path": [L, L, L, L, L, I],
     "hb_sgp_head_units": [L, L, L, L, L, I, I, I, L],
     "hb_sgp_rider_supported": [L, L, L, L, L, I, I, I, L],
+    "hb_matmul_gauss_units": [L, L, L],
+    "hb_matmul_gauss_f32": [P, L, P, L, P, P, P, P, D, P, P, P, L, L, L, L, P],
     "hb_sgp_rider_begin": [],
     "hb_sgp_rider_pending": [],
     "hb_sgp_rider_flush": [P],
@@ -72,7 +74,7 @@ _SIGS = {
     "hb_comm_destroy": [P],
 }
 _RESTYPES = {"hb_last_error_string": c_char_p, "hb_sgp_ws_elems": c_long, "hb_ewise_prog_image_bytes": c_long,
-             "hb_sgp_head_units": c_long, "hb_cholesky_inverse_ws_elems": c_long, "hb_mlp2_sample_ws_elems": c_long}
+             "hb_sgp_head_units": c_long, "hb_matmul_gauss_units": c_long, "hb_cholesky_inverse_ws_elems": c_long, "hb_mlp2_sample_ws_elems": c_long}
 
 # entry points that exist as _f32 and _f64
 _TYPED = {

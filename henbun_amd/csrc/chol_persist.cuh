@@ -453,6 +453,13 @@ __device__ __forceinline__ void chol_persist_body(const CpArgs& a, CpLds& sh, co
         asm volatile("" ::: "memory");
         __hip_atomic_store(&done[1], cq + 4 * sg + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
+        // the four finished columns ARE k-quad sg of the chunk: on their way to the later column blocks at once (only the
+        // last quad's store is still in flight when the chunk's flag is due)
+        if (j < nb - 1) {
+          const CpV4 o = {xx[2 * sg][0], xx[2 * sg][1], xx[2 * sg + 1][0], xx[2 * sg + 1][1]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(CpU4, o), xr,
+                                                 (j * nb + s) * (CP_NB * CP_NB * 4) + ((q * 4 + sg) * CP_NB + lane) * 16, 0, 16);
+        }
         CP_STAMP(7 + sg);
       }
     }
@@ -461,12 +468,6 @@ __device__ __forceinline__ void chol_persist_body(const CpArgs& a, CpLds& sh, co
     if (r == 1) {
       // ---- hand the finished chunk to the later column blocks (write-through stores, drained, then its flag)
       if (j < nb - 1) {
-        const int off = (j * nb + s) * (CP_NB * CP_NB * 4) + ((q * 4) * CP_NB + lane) * 16;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const CpV4 o = {x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(CpU4, o), xr, off + v * CP_NB * 16, 0, 16);
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CP_STAMP(12);
         __hip_atomic_store(flags + ((size_t)j * nb + s) * 4 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

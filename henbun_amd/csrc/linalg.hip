@@ -686,8 +686,21 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) matmul_rows_kernel(M
 // switch), 3 the sigmoid's gradient from the layer's output, 4 the gradient of the activation in a.act.  With the
 // activation switched per ELEMENT at run time the kernel was 13 000 lines of ISA in 2 500 basic blocks (tanhf inlined
 // sixteen times per epilogue copy).
+// EPI 5 (round 4): the Gaussian likelihood head of the product -- f = alpha A B + bias never leaves the registers: with y
+// of the same shape the epilogue writes dmu = (y - f s) / var into C (and fbar = s (post dmu) into hd.fbar) and keeps the
+// lane's partial sums of (ll, dscale, dvar); one partial triple per wave in hd.part[3][units], folded by hb_gauss_ll_fold.
+// The per-point arithmetic is hb_gauss_point (chain_bodies.cuh): dmu / fbar agree with hb_gauss_ll to fp32 rounding.
+struct MmHead {
+  const float* y = nullptr;
+  const float* scale = nullptr;
+  const float* var = nullptr;
+  float post = 0.f;
+  float* fbar = nullptr;
+  float* part = nullptr;
+  long units = 0;
+};
 template <bool TB, int G, int KC, int EPI>
-__global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
+__global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a, MmHead hd) {
 
   typedef float V4 __attribute__((ext_vector_type(4)));
   typedef Mma<float> MM;
@@ -722,6 +735,10 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
     }
   }
   const float bias = (a.bias && !(a.flags & HB_MM_ACTGRAD) && col < N) ? a.bias[col] : 0.f;
+  float h_ll = 0.f, h_sc = 0.f, h_vr = 0.f;     // EPI 5
+  const float hs = (EPI == 5 && hd.scale) ? hd.scale[0] : 1.f;
+  const float hv = EPI == 5 ? hd.var[0] : 1.f;
+  const float hiv = 1.f / hv, hlc = -0.91893853320467274178f - 0.5f * hb_log(hv);
   auto load = [&](V4 (&f)[KC][G / 4], int rt) {
     const int rtc = rt < nrt ? rt : nrt - 1;
     const int row = 32 * rtc + li;
@@ -743,7 +760,24 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) acc = MM::mma(f[c][v][s2], bf[c][4 * v + s2], acc);
     const int r0 = 32 * rt;
-    if (EPI >= 3 && r0 + 32 <= M && col < N) {
+    if (EPI == 5) {
+      float y[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + MM::acc_row(lane, r);
+        y[r] = hd.y[(long)(row < M ? row : M - 1) * N + colc];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + MM::acc_row(lane, r);
+        if (row < M && col < N) {
+          float gg;
+          hb_gauss_point<float>(y[r], a.alpha * acc[r] + bias, hs, hiv, hlc, gg, h_ll, h_sc, h_vr);
+          a.C[(long)row * ldc + col] = gg;
+          if (hd.fbar) hd.fbar[(long)row * ldc + col] = hs * (hd.post * gg);
+        }
+      }
+    } else if (EPI >= 3 && r0 + 32 <= M && col < N) {
       const float* __restrict__ yp = a.bias + (long)(r0 + 4 * h) * N + col;
       float* __restrict__ cp = a.C + (long)(r0 + 4 * h) * ldc + col;
       float y[16];
@@ -788,19 +822,29 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a) {
     }
   };
   int rt = gw / nct;
-  if (rt >= nrt) return;
-  V4 fa[KC][G / 4], fb[KC][G / 4];
-  load(fa, rt);
+  if (rt < nrt) {
+    V4 fa[KC][G / 4], fb[KC][G / 4];
+    load(fa, rt);
 #pragma nounroll
-  for (; rt < nrt; rt += 2 * rstride) {
-    load(fb, rt + rstride);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(fa, rt);
-    __builtin_amdgcn_sched_barrier(0);
-    load(fa, rt + 2 * rstride);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(fb, rt + rstride);
-    __builtin_amdgcn_sched_barrier(0);
+    for (; rt < nrt; rt += 2 * rstride) {
+      load(fb, rt + rstride);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fa, rt);
+      __builtin_amdgcn_sched_barrier(0);
+      load(fa, rt + 2 * rstride);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(fb, rt + rstride);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (EPI == 5) {
+    // this wave's partial sums (fixed order inside the wave; a wave without tiles contributes zeros)
+    h_ll = wave_sum(h_ll), h_sc = wave_sum(h_sc), h_vr = wave_sum(h_vr);
+    if (lane == 0 && gw < hd.units) {
+      hd.part[gw] = h_ll;
+      hd.part[hd.units + gw] = h_sc;
+      hd.part[2 * hd.units + gw] = h_vr;
+    }
   }
 }
 
@@ -817,8 +861,8 @@ static inline bool matmul_rowsreg_ok(const MmArgs<float>& a, int& G, int& KC) {
   KC = (int)(a.K / 32);
   return a.K % 32 == 0 && (KC == 1 || KC == 2 || KC == 4);
 }
-static int matmul_rowsreg_launch(const MmArgs<float>& a, int transB, int G, int KC, hipStream_t stream) {
-  const long nct = hb_cdiv(a.N, 32), nrt = hb_cdiv(a.M, 32);
+static inline long matmul_rowsreg_wgs(long M, long N, int KC) {
+  const long nct = hb_cdiv(N, 32), nrt = hb_cdiv(M, 32);
   // enough waves to fill the chip at this register count, at least ~2 row tiles each; a multiple of nct waves
   const long occ = KC >= 4 ? 2 : (KC == 2 ? 3 : 4);
   long wgs = hb_cdiv(nrt * nct, 8);
@@ -828,10 +872,14 @@ static int matmul_rowsreg_launch(const MmArgs<float>& a, int transB, int G, int 
   unit /= 4;
   wgs = (wgs / unit) * unit;
   if (wgs < unit) wgs = unit;
-  dim3 grid((unsigned)wgs, 1, 1);
+  return wgs;
+}
+static int matmul_rowsreg_launch(const MmArgs<float>& a, int transB, int G, int KC, hipStream_t stream, const MmHead* head = nullptr) {
+  dim3 grid((unsigned)matmul_rowsreg_wgs(a.M, a.N, KC), 1, 1);
   const bool ag = (a.flags & HB_MM_ACTGRAD) != 0;
-  const int epi = ag ? (a.act == HB_ACT_SIGMOID ? 3 : 4) : (a.act == HB_ACT_NONE ? 0 : (a.act == HB_ACT_SIGMOID ? 1 : 2));
-#define HB_RR3(TB_, G_, KC_, E_) hipLaunchKernelGGL((matmul_rowsreg_kernel<TB_, G_, KC_, E_>), grid, dim3(256), 0, stream, a)
+  const int epi = head ? 5 : (ag ? (a.act == HB_ACT_SIGMOID ? 3 : 4) : (a.act == HB_ACT_NONE ? 0 : (a.act == HB_ACT_SIGMOID ? 1 : 2)));
+  const MmHead hd = head ? *head : MmHead();
+#define HB_RR3(TB_, G_, KC_, E_) hipLaunchKernelGGL((matmul_rowsreg_kernel<TB_, G_, KC_, E_>), grid, dim3(256), 0, stream, a, hd)
 #define HB_RR2(TB_, G_, KC_)     \
   do {                           \
     if (epi == 0)                \
@@ -842,8 +890,10 @@ static int matmul_rowsreg_launch(const MmArgs<float>& a, int transB, int G, int 
       HB_RR3(TB_, G_, KC_, 2);   \
     else if (epi == 3)           \
       HB_RR3(TB_, G_, KC_, 3);   \
-    else                         \
+    else if (epi == 4)           \
       HB_RR3(TB_, G_, KC_, 4);   \
+    else                         \
+      HB_RR3(TB_, G_, KC_, 5);   \
   } while (0)
 #define HB_RR1(TB_)           \
   do {                        \
@@ -1123,6 +1173,37 @@ extern "C" int hb_matmul_f32(const float* A, const float* B, float* C, long batc
   return matmul_launch<float>(A, B, C, batch, M, N, K, lda, ldb, ldc, sA, sB, sC, transA, transB, alpha, beta, bias,
                               sBias, act, flags, ws, ws_elems, (hipStream_t)stream);
 }
+// The Gaussian likelihood head of a MatBias layer (reference nn.py:31-32 feeding densities.py:25-27 under tf.reduce_sum):
+// f = A B + bias is consumed in the epilogue of the row-streaming product, never written (EPI 5 above).
+static inline bool matmul_gauss_shape(long n, long K, long N, int& G, int& KC) {
+  if (hb_debug_get("mm_no_gauss_head", 0) != 0) return false;
+  if (n < 2048 || N <= 32 || N > 256 || n * N >= 2147483647L) return false;
+  MmArgs<float> t = {};
+  t.N = N, t.K = K;
+  return matmul_rowsreg_ok(t, G, KC);
+}
+extern "C" long hb_matmul_gauss_units(long n, long K, long N) {
+  int G, KC;
+  if (!matmul_gauss_shape(n, K, N, G, KC)) return 0;
+  return 4 * matmul_rowsreg_wgs(n, N, KC);
+}
+extern "C" int hb_matmul_gauss_f32(const float* A, long lda, const float* B, long ldb, const float* bias, const float* y,
+                                   const float* scale, const float* var, double post, float* dmu, float* fbar, float* part,
+                                   long units, long n, long K, long N, void* stream) {
+  int G, KC;
+  HB_REQUIRE(A && B && y && var && dmu && part, "hb_matmul_gauss: NULL pointer");
+  HB_REQUIRE(matmul_gauss_shape(n, K, N, G, KC) && units == 4 * matmul_rowsreg_wgs(n, N, KC),
+             "hb_matmul_gauss: units must be hb_matmul_gauss_units(n, K, N) > 0 (n = %ld, K = %ld, N = %ld)", n, K, N);
+  HB_REQUIRE((uintptr_t)A % 16 == 0 && lda % 4 == 0 && lda >= K && ldb >= N, "hb_matmul_gauss: A must be 16-byte aligned with lda %% 4 == 0");
+  MmArgs<float> a = {};
+  a.A = A, a.B = B, a.C = dmu, a.bias = bias;
+  a.M = n, a.N = N, a.K = K, a.lda = lda, a.ldb = ldb, a.ldc = N;
+  a.batch = 1, a.alpha = 1.f, a.beta = 0.f, a.act = HB_ACT_NONE, a.flags = 0;
+  MmHead hd;
+  hd.y = y, hd.scale = scale, hd.var = var, hd.post = (float)post, hd.fbar = fbar, hd.part = part, hd.units = units;
+  return matmul_rowsreg_launch(a, 0, G, KC, (hipStream_t)stream, &hd);
+}
+
 extern "C" int hb_matmul_f64(const double* A, const double* B, double* C, long batch, long M, long N, long K,
                              long lda, long ldb, long ldc, long sA, long sB, long sC, int transA, int transB,
                              double alpha, double beta, const double* bias, long sBias, int act, int flags, double* ws,

@@ -975,6 +975,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
   const int d1 = w <= t1 ? t1 + 1 : 0;
   const int nts = d0 + d1;
   const bool means = a.part && a.P > 0;
+  HB_SSTAMP(0);
   // this lane's u_m for its two tiles (row li of each), requested before anything else
   float u0 = 0.f, u1 = 0.f;
   if (means) {
@@ -982,7 +983,6 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
     if (d0) u0 = up[32 * t0 + li];
     if (d1) u1 = up[32 * t1 + li];
   }
-
   // ---- K(z, x[strip]) -> LDS (as in the other forms: difference first, then the exp2 scale)
   {
     const int c = tid & 31, kq = tid >> 5;
@@ -1031,6 +1031,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
     }
   }
   __syncthreads();
+  HB_SSTAMP(1);
 
   // per-lane column statistics in ACCUMULATOR order: register r of lane (li, h) is column (r & 3) + 8 (r >> 2) + 4 h
   float csq[16], cu[16];
@@ -1108,7 +1109,9 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
     }
   }
 
+  HB_SSTAMP(2);
   sgp_2t_epilogue<false>(a, lds_raw, csq, cu, e, bx, col0, n, means);
+  HB_SSTAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

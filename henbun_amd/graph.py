@@ -924,6 +924,29 @@ def _matmul_emit(plan, node):
     bias = plan.buf(node.inputs[2]) if len(node.inputs) > 2 else None
     at = node.attrs
     y = node.outputs[0]
+    g = getattr(plan, "_mm_head", {}).get(node.id)
+    if g is not None:
+        # the Gaussian likelihood head of this layer runs in the product's epilogue (hb_matmul_gauss): f is never written
+        units = H.matmul_gauss_units(y.shape[0], node.inputs[0].shape[1], y.shape[1], plan.dtype)
+        ok = (units > 0 and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and b.stride(1) == 1
+              and (bias is None or bias.numel() == y.shape[1]))
+        if ok:
+            def early(t):
+                shp = t.shape
+                while t.node.op == "reshape" and t not in plan._buf:
+                    t = t.node.inputs[0]
+                return plan.buf(t).view(shp)
+
+            post = plan._gll_post.get(g.id)
+            head = dict(y=early(g.inputs[0]), var=early(g.inputs[2]), scale=early(g.inputs[3]) if len(g.inputs) > 3 else None,
+                        dmu=plan.out(g.outputs[1]), post=post[0] if post else 0.0, fbar=plan.out(post[1]) if post else None,
+                        part=plan.scratch((3 * units,)), units=units)
+            plan._gll_fused[g.id] = (head["part"], units)
+            plan.pin_side_reads([g.inputs[0], g.inputs[2]] + list(g.inputs[3:4]))
+            plan.steps.append(lambda: H.matmul_gauss(a, b, bias, head))
+            return
+        # (the head was paired at plan time but this call cannot carry it: the plain product, and the head as a launch of its own)
+        plan._gll_in_sgp.pop(g.id, None)
     # a triangular / Phi / symmetrising matutil that is the only consumer becomes the GEMM's epilogue
     cons = plan._consumers.get(y, [])
     epi = 0
@@ -2352,6 +2375,38 @@ class Plan:
                     self.note(hp, n, True)
                 else:
                     self.note(hp, n, False, "y / var / scale are produced after the draw is launched")
+            # The same head riding in the MatBias product that produces its f (hb_matmul_gauss: a decoder layer feeding
+            # densities.gaussian): f is then never written.  Conditions: a plain 2-D product (bias allowed, no activation,
+            # nothing transposed) whose result feeds ONLY this head, and the head's other operands exist before it.
+            self._mm_head: Dict[int, Node] = {}       # matmul node id -> gauss_ll node
+            if bool(getattr(_st.runtime, "head_in_decoder", True)):
+                hp = "likelihood head inside the layer's product (hb_matmul_gauss)"
+                for n in order:
+                    if n.op != "gauss_ll" or n.id in self._gll_in_sgp or len(n.inputs[1].shape) != 2:
+                        continue
+                    ft, single = n.inputs[1], True
+                    while ft.node.op == "reshape":
+                        single = single and len(consumers.get(ft, [])) == 1
+                        ft = ft.node.inputs[0]
+                    mm = ft.node
+                    if mm.op != "matmul" or ft is not mm.outputs[0]:
+                        continue      # (not a layer's output: nothing to report)
+                    at = mm.attrs
+                    why = None
+                    if at["ta"] or at["tb"] or at.get("actgrad") or at["act"] != "none" or len(mm.inputs[0].shape) != 2 or len(mm.inputs[1].shape) != 2:
+                        why = "the product is transposed, batched or carries an activation"
+                    elif not single or len(consumers.get(ft, [])) != 1 or ft in self.outputs or ft in self._bind:
+                        why = "f is read by something else as well"
+                    elif n.inputs[0].shape != n.inputs[1].shape or mm.id in self._mm_head:
+                        why = "y and f differ in shape"
+                    elif not all(emitted_before(t, self._order_pos[mm.id]) for t in [n.inputs[0], n.inputs[2]] + list(n.inputs[3:4])):
+                        why = "y / var / scale are produced after the product is launched"
+                    elif hip_ops.matmul_gauss_units(ft.shape[0], mm.inputs[0].shape[1], ft.shape[1], dtype) == 0:
+                        why = "shape outside the row-streaming form (fp32, n >= 2048, 32 < N <= 256, K = 16 / 32 / 64 / 128)"
+                    if why is None:
+                        self._mm_head[mm.id] = n
+                        self._gll_in_sgp[n.id] = mm      # (same deferral of the fold as for a head riding in an sgp draw)
+                    self.note(hp, n, why is None, why or "")
         # Concatenation in place: the parts of a concat along its leading non-unit axis are contiguous blocks of the
         # result, so a part that a fused program (or a single elementwise launch) produces is WRITTEN there -- the
         # gradient of a batched GP draw whose expert / gate halves come out of one column program needs no

@@ -899,6 +899,25 @@ def sgp_head_units(x, z, u, prec, has_wfrag, draw, rng):
                                                   rng.nlanes if rng is not None else 0))
 
 
+def matmul_gauss_units(n, K, N, dtype):
+    """Partial-sum units of hb_matmul_gauss for an [n, K] x [K, N] MatBias layer feeding a Gaussian head (0: not this shape)."""
+    if dtype != torch.float32:
+        return 0
+    return int(_lib.lib().raw("hb_matmul_gauss_units")(int(n), int(K), int(N)))
+
+
+def matmul_gauss(x, w, bias, head):
+    """The Gaussian likelihood head of x @ w + bias in the product's own launch (hb_matmul_gauss_f32): head = dict(y, scale,
+    var, post, dmu, fbar, part, units); writes head['dmu'] (and head['fbar']) and the partial sums head['part']."""
+    for t in (x, w):
+        _chk(t)
+    n, K = x.shape
+    N = w.shape[1]
+    _lib.lib().call("hb_matmul_gauss_f32", _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(head["y"]), _p(head.get("scale")),
+                    _p(head["var"]), float(head.get("post") or 0.0), _p(head["dmu"]), _p(head.get("fbar")), _p(head["part"]),
+                    int(head["units"]), int(n), int(K), int(N), stream())
+
+
 def sgp_rider_supported(x, z, u, prec, has_wfrag, draw, rng):
     """1 when this forward call can be recorded (sgp_rider_begin) and start inside the launch of the persistent
     factorisation that produces its W (hb_sgp_rider_supported)."""

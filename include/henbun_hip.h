@@ -503,6 +503,17 @@ int hb_sgp_rider_supported(long E, long n, long M, long d, long P, int prec, int
 int hb_sgp_rider_begin(void);
 int hb_sgp_rider_pending(void);
 int hb_sgp_rider_flush(void* stream);
+/* The Gaussian likelihood head of a MatBias layer in the layer's own launch (round 4; reference nn.py:31-32 feeding
+ * densities.py:25-27 under tf.reduce_sum): f = A[n, K] B[K, N] + bias[N] is consumed in the epilogue of the row-streaming
+ * product and never written -- dmu[n, N] = (y - f s) / var, fbar = s (post dmu) when fbar != NULL, and one partial triple
+ * of (ll, dscale, dvar) per wave in part[3][units] for hb_gauss_ll_fold.  units = hb_matmul_gauss_units(n, K, N); 0: this
+ * shape takes the product and the head as two launches.  Supported: fp32, n >= 2048, 32 < N <= 256, K == 16 or K in {32, 64, 128}.  dmu / fbar agree
+ * with hb_gauss_ll on the materialised f to fp32 rounding (the same per-point arithmetic on an f that was never rounded
+ * through memory); the three sums are taken in another (fixed) order. */
+long hb_matmul_gauss_units(long n, long K, long N);
+int hb_matmul_gauss_f32(const float* A, long lda, const float* B, long ldb, const float* bias, const float* y,
+                        const float* scale, const float* var, double post, float* dmu, float* fbar, float* part,
+                        long units, long n, long K, long N, void* stream);
 int hb_gauss_ll_fold_f32(const float* partial, long nb, float* ll, float* dscale, float* dvar, void* stream);
 int hb_gauss_ll_fold_f64(const double* partial, long nb, double* ll, double* dscale, double* dvar, void* stream);
 /* The contraction alone, A = W k(z,x) (posterior-prediction callers; isolated timing). */

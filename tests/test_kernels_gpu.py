@@ -1167,6 +1167,41 @@ def test_likelihood_head_inside_the_forward_contraction(H, M, n):
             assert abs(float(a_) - float(b_)) <= 2e-6 * max(abs(float(a_)), float(n) ** 0.5), (float(a_), float(b_))   # observed <= 3e-7 relative
 
 
+@pytest.mark.parametrize("n,K,N", [(32768, 16, 64), (4096, 32, 96), (2048 + 17, 64, 256), (8192, 128, 33)])
+@pytest.mark.parametrize("with_scale,with_bias,post", [(True, True, 3.25), (False, False, None)])
+def test_likelihood_head_inside_the_layer_product(H, n, K, N, with_scale, with_bias, post):
+    """hb_matmul_gauss + hb_gauss_ll_fold: the Gaussian head of a MatBias layer (reference nn.py:31-32 ->
+    densities.py:25-27) computed in the epilogue of the row-streaming product, f never written -- against hb_matmul followed
+    by hb_gauss_ll: dmu / fbar and the three sums agree to fp32 rounding (same per-point arithmetic, hb_gauss_point)."""
+    dt = torch.float32
+    rng = np.random.RandomState(n + K + N)
+    x, w = dev(rng.randn(n, K), dt), dev(rng.randn(K, N) / np.sqrt(K), dt)
+    b = dev(rng.randn(1, N), dt) if with_bias else None
+    y = dev(rng.randn(n, N), dt)
+    scale = dev(np.abs(rng.randn(1)) + 0.5, dt) if with_scale else None
+    var = dev(np.abs(rng.randn(1)) + 0.3, dt)
+    units = H.matmul_gauss_units(n, K, N, dt)
+    assert units > 0
+    f = H.matmul(x, w, bias=b)
+    fb0 = torch.empty(n, N, dtype=dt, device="cuda") if post else None
+    ll0, dmu0, ds0, dv0 = H.gauss_ll(y, f, scale, var, **(dict(post=post, fbar=fb0) if post else {}))
+    dmu1 = torch.full((n, N), float("nan"), dtype=dt, device="cuda")
+    fb1 = torch.full((n, N), float("nan"), dtype=dt, device="cuda") if post else None
+    part = torch.full((3 * units,), float("nan"), dtype=dt, device="cuda")
+    H.matmul_gauss(x, w, b, dict(y=y, scale=scale, var=var, post=post, dmu=dmu1, fbar=fb1, part=part, units=units))
+    ll1, ds1, dv1 = (torch.empty(1, dtype=dt, device="cuda") for _ in range(3))
+    H.gauss_ll_fold(part, units, ll1, ds1, dv1)
+    # (f = x w + b is rounded once more on its way through memory in the two-launch form and may be contracted differently
+    # in the two kernels: dmu agrees to a few ulp of f / var, not bit for bit)
+    tol = 4e-7 * float(f.abs().max()) / float(var)
+    assert float((dmu0 - dmu1).abs().max()) <= tol, (float((dmu0 - dmu1).abs().max()), tol)
+    if post:
+        assert float((fb0 - fb1).abs().max()) <= tol * abs(post) * float(scale if scale is not None else 1.0)
+    for a_, b_ in ((ll0, ll1), (ds0, ds1), (dv0, dv1)):
+        assert abs(float(a_) - float(b_)) <= 3e-6 * max(abs(float(a_)), float(n * N) ** 0.5), (float(a_), float(b_))
+    assert H.matmul_gauss_units(1024, K, N, dt) == 0 and H.matmul_gauss_units(n, K, 16, dt) == 0    # shapes it leaves to two launches
+
+
 @pytest.mark.parametrize("M,n,E", [(512, 8192, 1), (128, 1000, 1), (256, 2048, 2), (64, 64, 1)])
 def test_forward_contraction_inside_the_persistent_cholesky_launch(H, M, n, E):
     """Early-start form (hb_sgp_rider_begin; csrc/sgp.hip chol_sgp_fwd_kernel): the forward contraction recorded and

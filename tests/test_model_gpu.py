@@ -181,7 +181,7 @@ def test_early_start_forward_through_the_model_api():
             res[early] = m._session.theta.clone()
     a, b = res[True].double(), res[False].double()
     # eight Adam steps of 0.01 each: a parameter moves by up to 0.08; the two forms differ by fp32 rounding in A
-    assert float((a - b).abs().max()) <= 5e-4                      # observed 4.6e-5 (one hyper-parameter), 4e-6 elsewhere
+    assert bool(((a - b).abs() <= 5e-4 + 1e-4 * b.abs()).all())    # observed: 2e-5 of the largest inducing point, 4.6e-5 in one hyper-parameter
 
 
 def _two_rank_sessions(N, M, n, lr, seed=3):

@@ -1,6 +1,6 @@
 """Time the training-path forward contraction hb_sgp_fwd (fragment-major W in, fragment-major A + column partials out,
 finishing pass included) at cfg-2 and cfg-5 sizes.  HIP events, 50 launches.  Extra argv entries NAME=VALUE are
-environment switches to compare against the default (each timed in the same process)."""
+hb_debug_set switches (integers) to compare against the default (each timed in the same process)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -42,8 +42,8 @@ for name, E, M, n in (("cfg2", 1, 512, 8192), ("cfg5", 8, 512, 65536)):
     out = H.sgp_bwd(x, zz, ell, W, u, eps, None, v, fbar, wfrag=frag, a_frag=af, kbar_frag=kf)
     outs = (None,) + tuple(out[:4]) + (None,)
     for lab, env in [("default", None)] + [("%s=%s" % (k, val), (k, val)) for k, val in switches]:
-        if env: os.environ[env[0]] = env[1]
+        if env: H.debug_set(env[0], int(env[1]))
         us = t(lambda: H.sgp_fwd(x, zz, ell, W, u, eps_in=eps, wfrag=frag, a_frag=af))
         ub = t(lambda: H.sgp_bwd(x, zz, ell, W, u, eps, None, v, fbar, wfrag=frag, a_frag=af, kbar_frag=kf, out=outs))
-        if env: del os.environ[env[0]]
+        if env: H.debug_clear()
         print("%s  %-22s fwd %8.1f us  %6.1f TFLOP/s   bwd %8.1f us  %6.1f TFLOP/s (2 M^2 n)" % (name, lab, us, fl / us * 1e-6, ub, 2 * fl / ub * 1e-6), flush=True)

@@ -21,16 +21,20 @@ int hb_chain_push(const HbChainJob&, hipStream_t) { return 0; }
 int hb_chain_flush(hipStream_t) { return 0; }
 #include <algorithm>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 // the in-step form: hb_sgp_fwd with the fragment-major A only (no row-major A), statistics and finish
 static float *g_u, *g_eps, *g_Af, *g_f, *g_v, *g_ws;
 #define RUN() hb_sgp_fwd_f32(0, 1, x, 0, z, ell, 1, W, Wf, 0, g_u, g_eps, nullptr, 0, nullptr, nullptr, g_Af, g_f, g_v, 1, n, M, 1, 1, g_ws, 0)
-int main() {
-  setenv("HB_SGP_STRIP_FORM2", "1", 1);   // the per-wave stamps sit in the second strip form (sgp_A_strip2_kernel)
+int main(int argc, char** argv) {
+  const int form2 = argc > 1 && atoi(argv[1]) == 2;   // default: the third strip form (sgp_A_strip2t_kernel, finishing pass inside)
+  hb_debug_set("sgp_strip_form2", form2);
   const int M = 512, n = 8192;
   float *K, *L, *W, *ws, *Wf, *z, *x, *A, *ell;
   int* info;
-  (void)hipMalloc(&K, M * M * 4); (void)hipMalloc(&L, M * M * 4); (void)hipMalloc(&W, M * M * 4); (void)hipMalloc(&ws, M * M * 4);
+  const long wse = hb_cholesky_inverse_ws_elems(1, M, 4);   // exchange area + sync words of the persistent factorisation, zero at entry
+  (void)hipMalloc(&K, M * M * 4); (void)hipMalloc(&L, M * M * 4); (void)hipMalloc(&W, M * M * 4); (void)hipMalloc(&ws, wse * 4);
+  (void)hipMemset(ws, 0, wse * 4);
   (void)hipMalloc(&Wf, 2 * M * M * 4); (void)hipMalloc(&info, 4);
   (void)hipMalloc(&z, M * 4); (void)hipMalloc(&x, n * 4); (void)hipMalloc(&A, (size_t)M * n * 4); (void)hipMalloc(&ell, 4);
   (void)hipMalloc(&g_u, M * 4); (void)hipMalloc(&g_eps, n * 4); (void)hipMalloc(&g_Af, (size_t)M * n * 4); (void)hipMalloc(&g_f, n * 4);
@@ -52,7 +56,7 @@ int main() {
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   if (RUN()) { printf("fwd: %s\n", hb_last_error_string()); return 1; }
-  printf("hb_sgp_fwd_f32 (strip2 + finish, fragment-major W and A): %.2f us per launch (back-to-back stream launches)\n", ms * 1e3 / 50);
+  printf("hb_sgp_fwd_f32 (%s strip form, fragment-major W and A): %.2f us per launch (back-to-back stream launches)\n", form2 ? "second" : "third", ms * 1e3 / 50);
   std::vector<long long> st(256 * 8 * 4), rt(512);
   (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(hb_sstamps), st.size() * 8);
   (void)hipMemcpyFromSymbol(rt.data(), HIP_SYMBOL(hb_srt), rt.size() * 8);
