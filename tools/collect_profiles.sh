@@ -12,14 +12,14 @@ cp $s/cfg4/kernel_stats.csv $p/r04_rocprofv3_kernel_stats_bench_cfg4.csv
 cp $s/cfg4/summary.txt $p/r04_rocprofv3_summary_bench_cfg4.txt
 cp $s/cfg5/kernel_stats.csv $p/r04_rocprofv3_kernel_stats_bench_cfg5.csv
 cp $s/cfg5/summary.txt $p/r04_rocprofv3_summary_bench_cfg5.txt
-cp $s/plan_cfg5.txt $p/r04_plan_cfg5.txt
+for c in 2 4 5; do grep -v "amdgpu.ids\|^compiling\|^finished" $s/plan_cfg$c.txt > $p/r04_plan_cfg$c.txt; done
 grep -v amdgpu.ids $s/bench_fwd_bwd.txt > $p/r04_contractions_fwd_bwd.txt
 cp $s/bw_rows.txt $p/r04_bw_rows.txt
-cp $s/plan_cfg2.txt $p/r04_plan_cfg2.txt
 cp $s/pmc_cfg2/pmc_kernels.txt $p/r04_pmc_cfg2_kernels.txt
 cp $s/pmc_cfg4/pmc_kernels.txt $p/r04_pmc_cfg4_kernels.txt
 python tools/make_traffic_json.py cfg2=$s/pmc_cfg2 cfg4=$s/pmc_cfg4 > $p/r04_pmc_traffic.json
 cp $s/chol_persist_stamps.txt $p/r04_chol_persist_stamps.txt
 cp $s/mlp_stamps.txt $p/r04_mlp_bwd_stamps.txt
+cp $s/strip_stamps.txt $p/r04_strip3_stamps.txt
 cp $s/xlane_cost.txt $p/r04_xlane_cost.txt
 ls -la $p | grep r04

@@ -13,11 +13,12 @@ python bench.py --no-cpu-baseline --config cfg5 --contraction bf16x3 --steps 50 
 python bench.py --no-cpu-baseline --config cfg3 --tri-pack --steps 50 --warmup 5 > $o/bench_cfg3_tripack.json 2>/dev/null
 tools/prof_bench.sh r4final/cfg4 --config cfg4 --steps 100 --warmup 10 > /dev/null
 tools/prof_bench.sh r4final/cfg5 --config cfg5 --steps 20 --warmup 3 > /dev/null
-python tools/dump_plan.py cfg5 > $o/plan_cfg5.txt 2>/dev/null
+python tools/dump_plan.py cfg5 --explain > $o/plan_cfg5.txt 2>/dev/null
+python tools/dump_plan.py cfg4 --explain > $o/plan_cfg4.txt 2>/dev/null
 python tools/bench_fwd.py > $o/bench_fwd_bwd.txt 2>/dev/null
 python tools/bw_rows.py > $o/bw_rows.txt 2>/dev/null
-python tools/dump_plan.py cfg2 > $o/plan_cfg2.txt 2>/dev/null
+python tools/dump_plan.py cfg2 --explain > $o/plan_cfg2.txt 2>/dev/null
 tools/pmc_traffic.sh r4final/pmc_cfg2 > /dev/null 2>&1
 tools/pmc_traffic.sh r4final/pmc_cfg4 --config cfg4 > /dev/null 2>&1
-for t in chol_persist_stamps mlp_stamps xlane_cost; do [ -x tools/_bin/$t ] && (timeout -k 5 60 tools/_bin/$t > $o/$t.txt 2>&1 || true); done
+for t in chol_persist_stamps mlp_stamps xlane_cost strip_stamps; do [ -x tools/_bin/$t ] && (timeout -k 5 60 tools/_bin/$t > $o/$t.txt 2>&1 || true); done
 head -c 300 $o/bench_cfg2.json
