@@ -842,7 +842,9 @@ __device__ __forceinline__ float sgp_ag_load(const float* p) {   // agent-scope 
 // Epilogue of the third strip form (also the early-start form below): fold the per-lane statistics over the 256 (wave,
 // row-lane) contributions of every column, then -- a.fin -- the finishing pass and the likelihood head of the strip.
 // AG: y was written by a side job of the SAME launch (early-start form): read it with agent-scope loads.
-template <bool AG>
+// L16: the sixteen-wave form (sgp_A_strip16_kernel): a lane holds row (lane & 15) of its 16-row sub-tiles and the columns
+// 16 jb + 4 (lane >> 4) + r in csq / cu [4 jb + r]; its upper eight waves leave after handing their statistics over.
+template <bool AG, bool L16 = false>
 __device__ __forceinline__ void sgp_2t_epilogue(const SgpArgs<float>& a, float* lds_raw, const float (&csq)[16], const float (&cu)[16],
                                                 const long e, const int bx, const int col0, const int n, const bool means) {
   typedef float V4 __attribute__((ext_vector_type(4)));
@@ -850,13 +852,23 @@ __device__ __forceinline__ void sgp_2t_epilogue(const SgpArgs<float>& a, float* 
   if (a.part) {
     __syncthreads();  // every wave is done reading the K block
     float* red = lds_raw;   // [2 quantities][32 columns][SGP_RED_LD]
+    if (L16) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
-      red[(0 * SGP_SN + c) * SGP_RED_LD + 32 * w + li] = csq[r];
-      if (means) red[(1 * SGP_SN + c) * SGP_RED_LD + 32 * w + li] = cu[r];
+      for (int r = 0; r < 8; ++r) {
+        const int c = 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
+        red[(0 * SGP_SN + c) * SGP_RED_LD + 16 * w + (lane & 15)] = csq[r];
+        if (means) red[(1 * SGP_SN + c) * SGP_RED_LD + 16 * w + (lane & 15)] = cu[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
+        red[(0 * SGP_SN + c) * SGP_RED_LD + 32 * w + li] = csq[r];
+        if (means) red[(1 * SGP_SN + c) * SGP_RED_LD + 32 * w + li] = cu[r];
+      }
     }
     __syncthreads();
+    if (L16 && tid >= 512) return;   // (the fold, the finishing pass and the head are written for 512 threads)
     // 8 threads per (quantity, column): 32 contributions each in a fixed order, then a fixed 3-level tree
     const int pair = tid >> 3, g = tid & 7;           // pair = quantity * 32 + column
     const float* rp = red + pair * SGP_RED_LD + 32 * g;
@@ -1112,6 +1124,179 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
   HB_SSTAMP(2);
   sgp_2t_epilogue<false>(a, lds_raw, csq, cu, e, bx, col0, n, means);
   HB_SSTAMP(3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sixteen-wave form (round 4): four waves per SIMD where the grid gives every CU exactly ONE strip (cfg 2: 256 strips).
+//
+// At n = 8192 the third form runs one 8-wave workgroup per CU: two waves per SIMD, whose tile-steps (global loads ->
+// LDS reads -> 16 dependent MFMAs) leave the matrix pipe idle for a fifth of the loop (tools/strip_stamps.hip: 43 k
+// cycles for 34.8 k of MFMAs) -- there is no second workgroup to fill the gaps as at cfg-5 size.  Here the SAME strip is
+// cut into 16-row sub-tiles on v_mfma_f32_16x16x4_f32 (same rate per CU) and the workgroup has 16 waves, wave w owning
+// sub-tiles w and 31 - w (17 k-steps each way: balanced).  No new image is needed: a 16x16x4 operand wants lane (n, g)
+// to bring 4 contraction indices of row n, and MFMA e of a batch uses element e of everybody's 16-byte group -- so lane
+// (n, g) of batch b loads group (v = g, lane (n + 16 half, h = b)) of the existing fragment-major block of W, and the
+// K block is read as Ks[16 jb + i][32 Q + 16 b + 4 g .. + 3]: both sides name k = 32 Q + 16 b + 4 g + e.  The
+// accumulator comes out with the ROW on the lane and four consecutive columns in its registers, which IS a 16-byte
+// group of the fragment-major A: no lane swaps at all.  A differs from the other forms in the last place (four products
+// per MFMA instead of two); statistics, finishing pass and head are the shared epilogue.
+// ---------------------------------------------------------------------------------------------------------------
+#define SGP_S16_THREADS 1024
+template <int D>
+__global__ void __launch_bounds__(SGP_S16_THREADS, 4) sgp_A_strip16_kernel(SgpArgs<float> a) {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  constexpr int KS_FLOATS = SGP_SN * SGP_SLD, RED_FLOATS = 2 * SGP_SN * SGP_RED_LD;
+  __shared__ __attribute__((aligned(16))) float lds_raw[KS_FLOATS > RED_FLOATS ? KS_FLOATS : RED_FLOATS];
+  __shared__ __attribute__((aligned(16))) float zs[SGP_SM_MAX * D];
+  float (*Ks)[SGP_SLD] = reinterpret_cast<float (*)[SGP_SLD]>(lds_raw);
+  long e;
+  int bx;
+  sgp_block(a.efast, e, bx);
+  const float* __restrict__ x = a.x + e * a.sx;
+  const float* __restrict__ z = a.z + e * a.M * D;
+  const float* __restrict__ ell = a.ell + e * a.dl;
+  const float* __restrict__ Wf = a.Wf + e * a.M * a.M;
+  float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
+  const int M = (int)a.M, n = (int)a.n;
+  const int col0 = bx * SGP_SN;
+  const int tid = threadIdx.x, lane = tid & 63, m16 = lane & 15, g4 = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nT = M / 32, nS16 = M / 16;
+  const bool means = a.part && a.P > 0;
+  const int nS = (n + SGP_SN - 1) / SGP_SN;
+
+  // ---- K(z, x[strip]) -> LDS (as in the other forms: difference first, then the exp2 scale)
+  {
+    const int c = tid & 31, kq = tid >> 5;
+    const int cc = col0 + c < n ? col0 + c : n - 1;
+    float sc[D], xs[D];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      sc[dd] = float(SGP_EXP2_SCALE) / ell[a.dl == 1 ? 0 : dd];
+      xs[dd] = x[cc * D + dd];
+    }
+    constexpr int NTH = SGP_S16_THREADS;
+    for (int i = tid; i < M * D; i += NTH) zs[i] = z[i];
+    __syncthreads();
+#pragma unroll 4
+    for (int k4 = kq * 4; k4 < M; k4 += NTH / 8) {
+      float zq[4 * D];
+#pragma unroll
+      for (int q = 0; q < 4 * D; q += 4) {
+        const V4 zz = *reinterpret_cast<const V4*>(&zs[k4 * D + q]);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) zq[q + s2] = zz[s2];
+      }
+      V4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float r2 = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          const float tt = (zq[q * D + dd] - xs[dd]) * sc[dd];
+          r2 += tt * tt;
+        }
+        v[q] = hb_exp2_neg<float>(r2);
+      }
+      *reinterpret_cast<V4*>(&Ks[c][k4]) = v;
+    }
+  }
+  __syncthreads();
+
+  float csq[16], cu[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) csq[r] = 0.f, cu[r] = 0.f;
+  V4 acc[2];
+  const V4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  acc[0] = zero4, acc[1] = zero4;
+
+  // sub-tile s (rows 16 s .. 16 s + 15) contracts the 32-wide chunks Q = 0 .. s >> 1
+  auto load = [&](V4 (&f)[2], int s, int Q) {
+    const float* p = Wf + ((long)((s >> 1) * nT + Q) << 10) + (g4 * 64 + 16 * (s & 1) + m16) * 4;
+    f[0] = *reinterpret_cast<const V4*>(p);
+    f[1] = *reinterpret_cast<const V4*>(p + 128);     // batch b = 1: the other half-wave's groups (h = 1)
+  };
+  auto mma_step = [&](const V4 (&f)[2], int Q) {
+    V4 kf[2][2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) kf[jb][b] = *reinterpret_cast<const V4*>(&Ks[16 * jb + m16][32 * Q + 16 * b + 4 * g4]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ee = 0; ee < 4; ++ee) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[0][b][ee], f[b][ee], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[1][b][ee], f[b][ee], acc[1], 0, 0, 0);
+      }
+  };
+  auto retire = [&](int s) {
+    const int T = s >> 1, li = 16 * (s & 1) + m16;
+    if (a.part) {
+      const float um = means ? (a.u + e * a.P * a.M)[16 * s + m16] : 0.f;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          csq[4 * jb + r] += acc[jb][r] * acc[jb][r];
+          cu[4 * jb + r] += um * acc[jb][r];
+        }
+    }
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      V4 q = acc[jb];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col0 + 16 * jb + 4 * g4 + r >= n) q[r] = 0.f;
+      if (a.Af) *reinterpret_cast<V4*>(a.Af + ((((long)e * nT + T) * nS + bx) << 10) + (g4 * 64 + 32 * jb + li) * 4) = q;
+      if (A) {
+        float* ap = A + (long)(32 * T + li) * n + col0 + 16 * jb + 4 * g4;
+        if ((n & 3) == 0 && col0 + SGP_SN <= n) {
+          *reinterpret_cast<V4*>(ap) = q;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (col0 + 16 * jb + 4 * g4 + r < n) ap[r] = q[r];
+        }
+      }
+    }
+    acc[0] = zero4, acc[1] = zero4;
+  };
+  // the wave's two sub-tiles as one flat sequence of k-steps, operands in two register sets used alternately
+#pragma unroll 1
+  for (int pr = w; pr < nS16 / 2; pr += SGP_S16_THREADS / 64) {
+    const int s0 = pr, s1 = nS16 - 1 - pr;
+    const int d0 = (s0 >> 1) + 1, nts = d0 + (s1 >> 1) + 1;
+    auto at = [&](int ts, int& s, int& Q) {
+      const int tc = ts < nts ? ts : nts - 1;          // past the end: re-read the last step (never used)
+      s = tc < d0 ? s0 : s1;
+      Q = tc < d0 ? tc : tc - d0;
+    };
+    V4 fa[2], fb[2];
+    int s, Q;
+    at(0, s, Q);
+    load(fa, s, Q);
+#pragma nounroll
+    for (int ts = 0; ts < nts; ts += 2) {
+      at(ts + 1, s, Q);
+      load(fb, s, Q);
+      __builtin_amdgcn_sched_barrier(0);
+      at(ts, s, Q);
+      mma_step(fa, Q);
+      if (ts == d0 - 1 || ts == nts - 1) retire(s);
+      __builtin_amdgcn_sched_barrier(0);
+      at(ts + 2, s, Q);
+      load(fa, s, Q);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ts + 1 < nts) {
+        at(ts + 1, s, Q);
+        mma_step(fb, Q);
+        if (ts + 1 == d0 - 1 || ts + 1 == nts - 1) retire(s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  sgp_2t_epilogue<false, true>(a, lds_raw, csq, cu, e, bx, col0, n, means);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1698,10 +1883,19 @@ static int sgp_A_strip_launch(SgpArgs<float> a, long E, hipStream_t stream) {
   // third form (transposed accumulators, two workgroups per CU) whenever its one column mean suffices;
   // HB_SGP_STRIP_FORM2=1 keeps the second form (diagnostic: A/B timing, the two forms agree bit for bit in A)
   const bool form3 = (!a.part || a.P <= 1) && hb_debug_get("sgp_strip_form2", 0) == 0;
+  // sixteen-wave form: where every CU gets at most ONE strip, so that the third form could not put two workgroups on it
+  // (M >= 384: at least 12 of the 16 waves own a pair of sub-tiles)
+  static int cus = 0;
+  if (cus == 0 && (hb_device_info(nullptr, 0, &cus) || cus <= 0)) cus = 256;
+  // OFF by default: stand-alone it is 5-7 % faster than the third form at cfg 2 (26.2 / 25.4 against 28.2 / 26.7 us), inside
+  // the step it is 1.2 us SLOWER (201.5 against 200.3 us per step, tools/ab_step.py) -- hb_debug_set("sgp_form16", 1) selects it
+  const bool form16 = a.M >= 384 && a.M % 32 == 0 && E * hb_cdiv(a.n, SGP_SN) <= cus + cus / 4 && hb_debug_get("sgp_form16", 0) != 0;
 #define HB_STRIP(D_)                                                                                          \
   do {                                                                                                        \
     if (a.W3)                                                                                                 \
       hipLaunchKernelGGL((sgp_A_strip3_kernel<D_>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);             \
+    else if (a.Wf && form3 && form16)                                                                         \
+      hipLaunchKernelGGL((sgp_A_strip16_kernel<D_>), grid, dim3(SGP_S16_THREADS), 0, stream, a);              \
     else if (a.Wf && form3)                                                                                   \
       hipLaunchKernelGGL((sgp_A_strip2t_kernel<D_>), grid, dim3(SGP_STRIP_THREADS), 0, stream, a);            \
     else if (a.Wf)                                                                                            \
