@@ -47,6 +47,7 @@ _SIGS = {
     "hb_sgp_head_units": [L, L, L, L, L, I, I, I, L],
     "hb_sgp_rider_supported": [L, L, L, L, L, I, I, I, L],
     "hb_matmul_gauss_units": [L, L, L],
+    "hb_fullrank_one_launch_shape": [L, L],
     "hb_matmul_gauss_f32": [P, L, P, L, P, P, P, P, D, P, P, P, L, L, L, L, P],
     "hb_sgp_rider_begin": [],
     "hb_sgp_rider_pending": [],
@@ -97,6 +98,7 @@ _TYPED = {
     "hb_diag_sample_kl_fwd": [P, P, P, P, L, P, P, P, L, L, L, L, P, P],
     "hb_diag_sample_kl_bwd": [P, P, P, P, P, P, P, L, L, L, L, P],
     "hb_fullrank_sample_kl_fwd": [P, P, P, P, L, P, P, P, L, L, I, P, P],
+    "hb_fullrank_sample_kl_fwd1": [P, P, P, P, L, P, P, P, L, L, I, P, P, P],
     "hb_fullrank_sample_kl_bwd": [P, P, P, P, P, P, P, L, L, I, P],
     "hb_vec_to_tri": [P, P, L, L, P],
     "hb_tri_to_vec": [P, P, L, L, P],

@@ -225,6 +225,143 @@ __global__ void __launch_bounds__(256) fullrank_fwd_thread_kernel(const T* __res
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One launch (round 4): noise, sample and KL of a full-rank block of up to 1024 dimensions (cfg 3: q(u), M = 1024).
+// The three-launch form above (fill u, rows, fold) is 17 us for 2 MB of triangle: launch boundaries, not bytes.  Here
+//   * every workgroup draws the WHOLE u itself into LDS from the unchanged generator states (lane t draws the pairs
+//     t, t + lanes, ... exactly as rng_fill_kernel does: same variates), while the loads of its rows of S -- issued before
+//     the first variate is drawn -- are in flight; workgroup 0 also writes u_out;
+//   * a wave owns the rows k and size - 1 - k of one block (size + 1 elements together: balanced), every lane has all its
+//     elements of both rows in flight at once, and sums them in the order of the three-launch form;
+//   * the workgroups meet at an arrival counter (`sync`: one zero word, left zero): the LAST one folds the partial sums
+//     in a fixed order, writes kl, and advances the generator states -- nobody reads them any more.
+// ---------------------------------------------------------------------------------------------------------------
+#define HB_FR1_MAXSIZE 1024
+#define HB_FR1_MAXN 8192
+template <typename T>
+__global__ void __launch_bounds__(256) fullrank_fwd_one_kernel(const T* __restrict__ mu, const T* __restrict__ S,
+                                                               const T* __restrict__ u_in, uint64_t* rng, long nlanes,
+                                                               T* __restrict__ u_out, T* __restrict__ x, T* partial,
+                                                               T* __restrict__ kl, unsigned* sync, long rows, long size, int packed) {
+  __shared__ T us[HB_FR1_MAXN];
+  __shared__ T smem[16];
+  __shared__ unsigned s_last;
+  constexpr int PER = HB_FR1_MAXSIZE / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long n = rows * size, npairs = (n + 1) / 2;
+  const long half = (size + 1) / 2, units = rows * half;
+  const long unit = (long)blockIdx.x * 4 + w;
+  const bool live = unit < units;
+  const long r = live ? unit / half : 0, kp = live ? unit - r * half : 0;
+  const long ka = kp, kb = size - 1 - kp;                  // (the middle row of an odd size: ka == kb, taken once)
+  const T* Sa = fullrank_row(S, r, ka, size, packed);
+  const T* Sb = fullrank_row(S, r, kb, size, packed);
+  T sa[PER], sb[PER];
+  HbRng gs[HB_FR1_MAXN / 512];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const long j = lane + 64 * i;
+    sa[i] = (live && j <= ka) ? Sa[j] : T(0);
+    sb[i] = (live && j <= kb && kb != ka) ? Sb[j] : T(0);
+  }
+  // ---- u: injected, or drawn (all of it, by every workgroup, from the states as they stand)
+  if (u_in) {
+    for (long i = threadIdx.x; i < n; i += 256) {
+      const T v = u_in[i];
+      us[i] = v;
+      if (blockIdx.x == 0 && u_out && u_out != u_in) u_out[i] = v;
+    }
+  } else {
+    // (a thread keeps the advanced states of its lanes -- at most HB_FR1_MAXN / 2 / 256 = 16 -- for the last workgroup to store)
+#pragma unroll
+    for (int q = 0; q < HB_FR1_MAXN / 512; ++q) {
+      const long t = threadIdx.x + 256L * q;
+      if (t < nlanes && t < npairs) {
+        gs[q] = rng_load(rng, nlanes, t);
+        for (long p = t; p < npairs; p += nlanes) {
+          T z0, z1;
+          gs[q].normal2(z0, z1);
+          us[2 * p] = z0;
+          if (2 * p + 1 < n) us[2 * p + 1] = z1;
+          if (blockIdx.x == 0) {
+            u_out[2 * p] = z0;
+            if (2 * p + 1 < n) u_out[2 * p + 1] = z1;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  T acc = T(0);
+  if (live) {
+    const T* ur = us + r * size;
+    T da = T(0), db = T(0);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const long j = lane + 64 * i;
+      if (j <= ka) da += sa[i] * ur[j];
+      if (j <= kb && kb != ka) db += sb[i] * ur[j];
+    }
+    da = wave_sum(da), db = wave_sum(db);
+    if (lane == 0) {
+      const long oa = r * size + ka, ob = r * size + kb;
+      const T xa = mu[oa] + da;
+      x[oa] = xa;
+      const T ska = Sa[ka], uka = ur[ka];
+      acc += hb_log(ska * ska) + uka * uka - xa * xa;
+      if (kb != ka) {
+        const T xb = mu[ob] + db;
+        x[ob] = xb;
+        const T skb = Sb[kb], ukb = ur[kb];
+        acc += hb_log(skb * skb) + ukb * ukb - xb * xb;
+      }
+    }
+  }
+  acc = block_sum(acc, smem);
+  if (threadIdx.x == 0) {
+    // (write-through store, drained, then the count: the hand-off of cdna_hip_programming.md Guideline 16 R1, no L2 write-back)
+    __hip_atomic_store(partial + blockIdx.x, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last workgroup: fold (fixed order), advance the generator, leave the counter zero
+  T tot = T(0);
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) tot += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot = block_sum(tot, smem);
+  if (threadIdx.x == 0) {
+    kl[0] = T(-0.5) * tot;
+    __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!u_in) {
+#pragma unroll
+    for (int q = 0; q < HB_FR1_MAXN / 512; ++q) {
+      const long t = threadIdx.x + 256L * q;
+      if (t < nlanes && t < npairs) rng_store(rng, nlanes, t, gs[q]);
+    }
+  }
+}
+
+template <typename T>
+static int fullrank_fwd_one(const T* mu, const T* S, const T* u_in, uint64_t* rng, long rng_lanes, T* u_out, T* x, T* kl,
+                            long rows, long size, int packed, T* ws, unsigned* sync, hipStream_t stream) {
+  const long units = rows * ((size + 1) / 2);
+  const int grid = (int)((units + 3) / 4);
+  hipLaunchKernelGGL(fullrank_fwd_one_kernel<T>, dim3(grid), dim3(256), 0, stream, mu, S, u_in, u_in ? (uint64_t*)nullptr : rng,
+                     rng_lanes, u_out, x, ws, kl, sync, rows, size, packed);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+// 1 when hb_fullrank_sample_kl_fwd1 takes its one-launch form for this shape (otherwise it runs the three-launch form)
+extern "C" int hb_fullrank_one_launch_shape(long rows, long size) {
+  return (size > 64 && size <= HB_FR1_MAXSIZE && rows * size <= HB_FR1_MAXN && rows * ((size + 1) / 2) <= 4L * HB_KL_MAX_PARTIALS &&
+          hb_debug_get("fullrank_three_launches", 0) == 0)
+             ? 1
+             : 0;
+}
+
 template <typename T>
 static int fullrank_fwd(const T* mu, const T* S, const T* u_in, uint64_t* rng, long rng_lanes, T* u_out, T* x, T* kl,
                         long rows, long size, int packed, T* ws, hipStream_t stream) {
@@ -270,6 +407,27 @@ extern "C" int hb_fullrank_sample_kl_fwd_f64(const double* mu, const double* S, 
                                              long rng_lanes, double* u_out, double* x, double* kl, long rows,
                                              long size, int packed, double* ws, void* stream) {
   return fullrank_fwd<double>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, packed, ws, (hipStream_t)stream);
+}
+
+// `sync`: ONE zero 32-bit word owned by the caller for this stream (zero at entry, zero at exit); NULL or a shape outside
+// hb_fullrank_one_launch_shape: the three-launch form.
+extern "C" int hb_fullrank_sample_kl_fwd1_f32(const float* mu, const float* S, const float* u_in, uint64_t* rng,
+                                              long rng_lanes, float* u_out, float* x, float* kl, long rows, long size,
+                                              int packed, float* ws, unsigned* sync, void* stream) {
+  if (!sync || !hb_fullrank_one_launch_shape(rows, size))
+    return fullrank_fwd<float>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, packed, ws, (hipStream_t)stream);
+  HB_REQUIRE(mu && S && x && kl && ws, "hb_fullrank_sample_kl_fwd1: NULL pointer");
+  HB_REQUIRE(u_in || (rng && rng_lanes > 0 && u_out), "hb_fullrank_sample_kl_fwd1: need u_in, or rng and u_out");
+  return fullrank_fwd_one<float>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, packed, ws, sync, (hipStream_t)stream);
+}
+extern "C" int hb_fullrank_sample_kl_fwd1_f64(const double* mu, const double* S, const double* u_in, uint64_t* rng,
+                                              long rng_lanes, double* u_out, double* x, double* kl, long rows, long size,
+                                              int packed, double* ws, unsigned* sync, void* stream) {
+  if (!sync || !hb_fullrank_one_launch_shape(rows, size))
+    return fullrank_fwd<double>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, packed, ws, (hipStream_t)stream);
+  HB_REQUIRE(mu && S && x && kl && ws, "hb_fullrank_sample_kl_fwd1: NULL pointer");
+  HB_REQUIRE(u_in || (rng && rng_lanes > 0 && u_out), "hb_fullrank_sample_kl_fwd1: need u_in, or rng and u_out");
+  return fullrank_fwd_one<double>(mu, S, u_in, rng, rng_lanes, u_out, x, kl, rows, size, packed, ws, sync, (hipStream_t)stream);
 }
 
 template <typename T>

@@ -519,9 +519,23 @@ def fullrank_sample_kl_fwd(mu, S, u_in=None, rng=None, out=None, packed=False):
         x, kl, u = out
     ws = workspace(mu.dtype, mu.device)
     rp, rl = _rng_args(rng)
-    _lib.lib().call("hb_fullrank_sample_kl_fwd" + _suf(mu), _p(mu), _p(S), _p(u_in), rp, rl, _p(u), _p(x), _p(kl),
-                    rows, size, int(bool(packed)), _p(ws), stream())
+    # (one launch for a block of up to 1024 dimensions; the entry falls back to the three-launch form by itself)
+    _lib.lib().call("hb_fullrank_sample_kl_fwd1" + _suf(mu), _p(mu), _p(S), _p(u_in), rp, rl, _p(u), _p(x), _p(kl),
+                    rows, size, int(bool(packed)), _p(ws), _p(sync_word(mu.device)), stream())
     return x, kl, u
+
+
+_SYNC_WORDS = {}
+
+
+def sync_word(device):
+    """One zero 32-bit word per (device, stream) for the kernels that meet at an arrival counter (zero at entry, left zero
+    by every call; launches on one stream are ordered, so they can share it)."""
+    key = (str(device), stream())
+    b = _SYNC_WORDS.get(key)
+    if b is None:
+        b = _SYNC_WORDS[key] = torch.zeros(4, dtype=torch.int32, device=device)
+    return b
 
 
 def fullrank_sample_kl_bwd(S, u, x, xbar, klbar, out=None, packed=False):

@@ -284,6 +284,18 @@ int hb_fullrank_sample_kl_fwd_f64(const double* mu, const double* S, const doubl
                                   uint64_t* rng, long rng_lanes, double* u_out, double* x,
                                   double* kl, long rows, long size, int packed, double* ws,
                                   void* stream);
+/* The same in ONE launch for a block of up to 1024 dimensions (rows * size <= 8192; cfg 3's q(u)): every workgroup draws u
+ * itself from the unchanged generator states, a wave owns rows k and size - 1 - k, the last workgroup to arrive folds the
+ * KL partials and advances the generator.  `sync`: one zero 32-bit word owned by the caller for this stream (zero at
+ * entry, left zero).  Shapes outside hb_fullrank_one_launch_shape, or sync == NULL: the three-launch form above.  Same
+ * variates bit for bit; x and kl agree with the three-launch form to rounding. */
+int hb_fullrank_one_launch_shape(long rows, long size);
+int hb_fullrank_sample_kl_fwd1_f32(const float* mu, const float* S, const float* u_in, uint64_t* rng,
+                                   long rng_lanes, float* u_out, float* x, float* kl, long rows, long size,
+                                   int packed, float* ws, unsigned* sync, void* stream);
+int hb_fullrank_sample_kl_fwd1_f64(const double* mu, const double* S, const double* u_in, uint64_t* rng,
+                                   long rng_lanes, double* u_out, double* x, double* kl, long rows, long size,
+                                   int packed, double* ws, unsigned* sync, void* stream);
 /* mubar = xbar + klbar*x ; Sbar = tril(mubar u^T) - klbar*diag(1/S_kk) ; strictly upper = 0
  * (dense) or absent (packed: Sbar has S's packed layout) */
 int hb_fullrank_sample_kl_bwd_f32(const float* S, const float* u, const float* x, const float* xbar,

@@ -214,6 +214,48 @@ def test_fullrank_sample_kl(H, p, rows, size):
     assert np.all(np.triu(host(Sb), 1) == 0)  # masked entries get zero gradient (variationals.py:145)
 
 
+@pytest.mark.parametrize("p", ["f32", "f64"])
+@pytest.mark.parametrize("rows,size,packed", [(1, 1024, False), (1, 1024, True), (3, 200, False), (8, 65, True), (1, 1023, False)])
+def test_fullrank_sampler_in_one_launch(H, p, rows, size, packed):
+    """hb_fullrank_sample_kl_fwd1: noise, sample and KL of a full-rank block (reference variationals.py:138-146,225-230) in ONE
+    launch -- every workgroup draws u itself from the unchanged generator states, the last one to arrive folds the KL and
+    advances the generator -- against the three-launch form (fill u, rows, fold): the same variates bit for bit, x and kl
+    to rounding, the same generator state afterwards (drawn twice in a row), injected noise as well; and against the oracle."""
+    dt = DT[p]
+    rng = np.random.RandomState(size + rows)
+    mu = 0.3 * rng.randn(rows, size)
+    S = np.tril(0.05 * rng.randn(rows, size, size)) + np.eye(size)
+    Sd = dev(S, dt)
+    if packed:
+        il = np.tril_indices(size)
+        Sd = dev(S[:, il[0], il[1]], dt)
+    assert H._lib.lib().raw("hb_fullrank_one_launch_shape")(rows, size) == 1
+    res = {}
+    for three in (0, 1):
+        H.debug_set("fullrank_three_launches", three)
+        try:
+            g = H.Rng(123)
+            a = H.fullrank_sample_kl_fwd(dev(mu, dt), Sd, rng=g, packed=packed)
+            b = H.fullrank_sample_kl_fwd(dev(mu, dt), Sd, rng=g, packed=packed)      # second draw: the advanced states
+            c = H.fullrank_sample_kl_fwd(dev(mu, dt), Sd, u_in=a[2].clone(), packed=packed)
+            torch.cuda.synchronize()
+            res[three] = [t.clone() for t in a + b + c]
+        finally:
+            H.debug_clear()
+    one, thr = res[0], res[1]
+    for i in (2, 5):                 # u of the first and of the second draw: the same variates from the same states
+        assert torch.equal(one[i], thr[i]), i
+    for i in (0, 3, 6):              # x (drawn, drawn again, injected): the same sums up to the contraction of a multiply-add
+        assert float((one[i] - thr[i]).abs().max()) <= (1e-13 if p == "f64" else 2e-6) * float(thr[i].abs().max()), i
+    assert not torch.equal(one[2], one[5])                       # the second draw is a new one
+    for i in (1, 4, 7):              # kl: another (fixed) order of the partial sums
+        assert abs(float(one[i]) - float(thr[i])) <= (1e-12 if p == "f64" else 2e-6) * max(abs(float(thr[i])), float(rows * size))
+    tx = O.sample_fullrank(O.T(mu), O.T(S), O.T(host(one[2])))
+    tkl = O.kl_normal(O.T(S), O.T(host(one[2])), tx, "fullrank")
+    assert_close(one[0], tx, TOL["f64"] if p == "f64" else dict(rtol=1e-4, atol=1e-4))
+    assert abs(float(one[1]) - float(tkl)) <= (1e-10 if p == "f64" else 1e-4) * max(abs(float(tkl)), 1.0)
+
+
 def test_fullrank_golden(H, golden):
     g = golden
     x, kl, _ = H.fullrank_sample_kl_fwd(dev(g["v_mu"], torch.float64), dev(g["v_sq_full"], torch.float64),
