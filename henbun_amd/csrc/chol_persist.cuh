@@ -69,7 +69,7 @@ struct CpArgs {
   float* Wf;         // nullable: the fragment-major images of W and W^T (and the bf16x3 planes behind them)
   int bf16x3;
   int M, B, nb, total;   // total = number of workgroups of the factorisation (side-job blocks come after them)
-  // early-start consumers in the same launch (csrc/sgp.hip: chol_sgp_fwd_kernel).  early != 0: the W image is stored
+  // early-start consumers in the same launch (csrc/sgp.hip: chol_sgp_fwd_kernel).  early & 1 (the other bits are diagnostic switches): the W image is stored
   // write-through and every identity-strip workgroup of column block j raises wready[b][j] behind its stores (row block j
   // of W is final after panel j: j + 1 contributions); `arrive` workgroups take part in the arrival count (the
   // factorisation's plus the consumers'), `nside` side-job workgroups raise sync[3] when their outputs are released.
@@ -455,7 +455,7 @@ __device__ __forceinline__ void chol_persist_body(const CpArgs& a, CpLds& sh, co
         asm volatile("" ::: "memory");
         // the four finished columns ARE k-quad sg of the chunk: on their way to the later column blocks at once (only the
         // last quad's store is still in flight when the chunk's flag is due)
-        if (j < nb - 1) {
+        if (j < nb - 1 && !(a.early & 16)) {
           const CpV4 o = {xx[2 * sg][0], xx[2 * sg][1], xx[2 * sg + 1][0], xx[2 * sg + 1][1]};
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(CpU4, o), xr,
                                                  (j * nb + s) * (CP_NB * CP_NB * 4) + ((q * 4 + sg) * CP_NB + lane) * 16, 0, 16);
@@ -468,6 +468,14 @@ __device__ __forceinline__ void chol_persist_body(const CpArgs& a, CpLds& sh, co
     if (r == 1) {
       // ---- hand the finished chunk to the later column blocks (write-through stores, drained, then its flag)
       if (j < nb - 1) {
+        if (a.early & 16) {   // (diagnostic: the chunk's four stores at the end, as before)
+          const int off = (j * nb + s) * (CP_NB * CP_NB * 4) + ((q * 4) * CP_NB + lane) * 16;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const CpV4 o = {x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(CpU4, o), xr, off + v * CP_NB * 16, 0, 16);
+          }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CP_STAMP(12);
         __hip_atomic_store(flags + ((size_t)j * nb + s) * 4 + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -528,7 +536,7 @@ __device__ __forceinline__ void chol_persist_body(const CpArgs& a, CpLds& sh, co
       }
     }
   } else if (stripY) {
-    if (Wf && a.early) {
+    if (Wf && (a.early & 1)) {
       // Early-start consumers (csrc/sgp.hip) read row block j of the W image as soon as it is final: written first,
       // write-through, drained, then this workgroup's contribution to the row block's counter.
       const __amdgpu_buffer_rsrc_t wfr = __builtin_amdgcn_make_buffer_rsrc(Wf, 0, (int)(mm * sizeof(float)), 0x00020000);
@@ -565,7 +573,7 @@ __device__ __forceinline__ void chol_persist_body(const CpArgs& a, CpLds& sh, co
       for (int idx = tid; idx < 4 * 256; idx += 512) {
         const int sub = idx >> 8, g = idx & 255, v4 = g >> 6, l6 = g & 63, li = l6 & 31, h = l6 >> 5;
         const int tsub = sub >> 1, qsub = sub & 1;
-        if (!a.early) {
+        if (!(a.early & 1)) {
           // W image: row 32 (2j + tsub) + li = column 32 tsub + li of the block; k = 64 i' + 32 qsub + 16 h + 4 v4 + s
           const int c = 32 * tsub + li, r4 = 32 * qsub + 16 * h + 4 * v4;
           CpV4 v = *reinterpret_cast<const CpV4*>(&colbuf[1][c][r4]);
