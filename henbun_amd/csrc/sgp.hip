@@ -1074,11 +1074,17 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
     if (ts == d0 - 1 || ts == nts - 1) {
       // the tile is complete: statistics from the registers as they stand, then the row-per-lane view
       if (a.part) {
+        // (two columns per instruction, v_pk_fma_f32: these run on the pipe the partner wave's fp32 MFMAs use)
+        typedef float V2 __attribute__((ext_vector_type(2)));
         const float um = ts < d0 ? u0 : u1;
+        const V2 um2 = {um, um};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          csq[r] += acc[r] * acc[r];
-          cu[r] += um * acc[r];
+        for (int r = 0; r < 16; r += 2) {
+          const V2 av = {acc[r], acc[r + 1]};
+          const V2 q2 = __builtin_elementwise_fma(av, av, V2{csq[r], csq[r + 1]});
+          const V2 m2 = __builtin_elementwise_fma(um2, av, V2{cu[r], cu[r + 1]});
+          csq[r] = q2[0], csq[r + 1] = q2[1];
+          cu[r] = m2[0], cu[r + 1] = m2[1];
         }
       }
       sgp_acc_t_settle(acc);

@@ -82,14 +82,16 @@ __device__ __forceinline__ void sgp_store_frag_rows(float* __restrict__ Xf, floa
   typedef float V4 __attribute__((ext_vector_type(4)));
   const int h = lane >> 5;
   float* blk = Xf + ((((long)e * nT + tile) * nS + strip) << 10) + 4 * lane;
+  // (only the last strip can hold columns past n: the per-element masks -- 32 vector instructions that compete with the
+  // partner wave's fp32 MFMAs for the SIMD -- stay out of every other strip's way)
+  if (col0 + 32 > n) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (col0 + 16 * h + i >= n) row16[i] = 0.f;
+  }
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
-    V4 q;
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      if (col0 + 16 * h + 4 * v + s2 >= n) row16[4 * v + s2] = 0.f;
-      q[s2] = row16[4 * v + s2];
-    }
+    const V4 q = {row16[4 * v], row16[4 * v + 1], row16[4 * v + 2], row16[4 * v + 3]};
     *reinterpret_cast<V4*>(blk + 256 * v) = q;
   }
 }
