@@ -83,7 +83,7 @@ struct TileGemm {
   __device__ __forceinline__ void run(int kbeg, int kend, LA la, FA fa, LB lb, FB fb, T* __restrict__ lds) {
     if (kbeg >= kend) return;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / WN, wn = w % WN;
     const int am = wm * WTM + (lane % MM::TM), ak = lane / MM::TM;
     const int bn = wn * WTN + (lane % MM::TN), bk = lane / MM::TN;
@@ -216,7 +216,7 @@ struct TileGemm {
     static_assert(BM % VEC == 0 && BN % VEC == 0 && BK % VEC == 0 && LDA % VEC == 0 && LDB % VEC == 0, "alignment");
     if (kbeg >= kend) return;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / WN, wn = w % WN;
     const int am = wm * WTM + (lane % MM::TM), ak = lane / MM::TM;
     const int bn = wn * WTN + (lane % MM::TN), bk = lane / MM::TN;
@@ -368,13 +368,13 @@ struct TileGemm {
 
   // tile-local column of this thread's accumulator fragment j (its columns do not depend on i or r)
   __device__ __forceinline__ int frag_col(int j) const {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     return (w % WN) * WTN + j * MM::TN + MM::acc_col(lane);
   }
   // f(j, row, col, value): as for_each, with the column-fragment index (per-column data can be preloaded per j)
   template <class F>
   __device__ __forceinline__ void for_each_j(F f) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = w / WN, wn = w % WN;
 #pragma unroll
     for (int i = 0; i < RM; ++i)
@@ -391,7 +391,7 @@ struct TileGemm {
   // f(row, col, value&): in-place variant of for_each
   template <class F>
   __device__ __forceinline__ void for_each_ref(F f) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = w / WN, wn = w % WN;
 #pragma unroll
     for (int i = 0; i < RM; ++i)
@@ -410,7 +410,7 @@ struct TileGemm {
   // f(row, col, value) over this thread's accumulator elements (tile-local)
   template <class F>
   __device__ __forceinline__ void for_each(F f) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = w / WN, wn = w % WN;
 #pragma unroll
     for (int i = 0; i < RM; ++i)

@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) matmul_wgk_kernel(MmArgs<float> a, int no
     tj = blockIdx.x - ti * tiles_n;
   }
   const int row0 = ti * 32, col0 = tj * 32;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
   float* Cb = a.C + b * a.sC;
   const bool lower_only = (a.flags & (HB_MM_LOWER_OUT | HB_MM_TRIL_OUT | HB_MM_PHI_OUT | HB_MM_SYMLOW_OUT)) != 0;
   if (!SYM && lower_only && col0 > row0 + 31) {
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) matmul_rows_kernel(M
   const int M = (int)a.M, N = (int)a.N, K = (int)a.K;
   const int lda = (int)a.lda, ldb = (int)a.ldb, ldc = (int)a.ldc;
   const int KLD = K + 4;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
   constexpr int NP = 32 * NT * WC, ROWS = 32 * (NW / WC), NTHR = 64 * NW;
   const int wr = w / WC, wc = w % WC;
   // ---- stage op(B): element (column c, k) = op(B)[k][c]; columns past N are zero
@@ -706,7 +706,7 @@ __global__ void __launch_bounds__(256) matmul_rowsreg_kernel(MmArgs<float> a, Mm
   typedef Mma<float> MM;
   const int M = (int)a.M, N = (int)a.N;
   const int lda = (int)a.lda, ldb = (int)a.ldb, ldc = (int)a.ldc;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, h = lane >> 5;
   const int nct = (N + 31) / 32, nrt = (M + 31) / 32;
   const int gw = blockIdx.x * 4 + w, nw = gridDim.x * 4;
   const int ct = gw % nct;
@@ -1404,7 +1404,7 @@ __global__ void __launch_bounds__(256) chol_rl_kernel(const T* __restrict__ Ain,
     }
   }
   const bool factor = (j == k);
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane % TM, h = lane / TM;
   // entry g of this workgroup's tile list -> (live, is a Y tile, block row)
   auto describe = [&](int g, bool& live_, bool& yt_, int& rb_) {
@@ -1945,7 +1945,7 @@ __global__ void __launch_bounds__(256) chol_rl64_kernel(const float* __restrict_
     }
   }
   const bool factor = (j == k);
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
   // entry g of this workgroup's tile list -> (live, is a Y tile, row tile)
   auto describe = [&](int g, bool& live_, bool& yt_, int& rt_) {

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) mlp2_fwd_kernel(Mlp2FwdArgs a) {
   float* b0s = W1s + HID * MLP_O;     // [HID]
   float* b1s = b0s + HID;             // [32]
   float* red = b1s + MLP_O;           // [4]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, half = lane >> 5;
   constexpr int HT = HID / 32, KH = DIN / 2;   // hidden tiles; contraction entries per lane half
   const long ntiles = a.n / 32;
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256, OCC) mlp2_bwd_kernel(Mlp2BwdArgs a) {
   // per wave: its y tile (row major) and do = [mubar | sbar] of its 32 rows; one array: the final reduction reuses it
   constexpr int YS = 32 * YLD, DS = 32 * MLP_DOLD;
   __shared__ float tiles[4 * (YS + DS)];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hg = blockIdx.x, chunk = blockIdx.y;                       // hidden group (64 units), row chunk
   const int h0 = 64 * hg;
   MLP_STAMP_DECL

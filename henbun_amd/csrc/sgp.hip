@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) sgp_A_kernel(SgpArgs<T> a) {
     }
   }
   if (a.part) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = w / G::WN, wn = w % G::WN;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = w / G::WN, wn = w % G::WN;
     // lanes that share an accumulator column differ in the bits above log2(TN)
 #pragma unroll
     for (int jj = 0; jj < RNc; ++jj)
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip_kernel(SgpArgs<
   float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
   const int M = (int)a.M, n = (int)a.n;
   const int col0 = bx * SGP_SN;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
 
   HB_SSTAMP(0);
   // ---- K(z, x[strip]) -> LDS, [column][k]: thread (c = tid % 32, kq = tid / 32) takes the 16-byte groups kq, kq+16, ...
@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip2_kernel(SgpArgs
   float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
   const int M = (int)a.M, n = (int)a.n;
   const int col0 = bx * SGP_SN;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
 
   HB_SSTAMP(0);
   // ---- K(z, x[strip]) -> LDS (as in the first form)
@@ -848,7 +848,7 @@ template <bool AG, bool L16 = false>
 __device__ __forceinline__ void sgp_2t_epilogue(const SgpArgs<float>& a, float* lds_raw, const float (&csq)[16], const float (&cu)[16],
                                                 const long e, const int bx, const int col0, const int n, const bool means) {
   typedef float V4 __attribute__((ext_vector_type(4)));
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
   if (a.part) {
     __syncthreads();  // every wave is done reading the K block
     float* red = lds_raw;   // [2 quantities][32 columns][SGP_RED_LD]
@@ -980,7 +980,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, 4) sgp_A_strip2t_kernel(Sgp
   float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
   const int M = (int)a.M, n = (int)a.n;
   const int col0 = bx * SGP_SN;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
   const int nT = M / 32;
   const int t1 = nT - 1 - w, t0 = w;
   const int d0 = w < t1 ? w + 1 : 0;      // the middle tile of an odd count is taken once, as t1
@@ -1687,7 +1687,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS) sgp_A_strip3_kernel(SgpArgs
   float* __restrict__ A = a.A ? a.A + e * a.M * a.n : nullptr;
   const int M = (int)a.M, n = (int)a.n;
   const int col0 = bx * SGP_SN;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
 
   // ---- K(z, x[strip]) -> LDS as three bf16 planes [term][column][k]
   {
@@ -2479,7 +2479,7 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, (BF3 || D >= 3) ? 2 : 4) sg
   float* __restrict__ Kbar = a.Kbar ? a.Kbar + e * a.M * a.n : nullptr;
   const int M = (int)a.M, n = (int)a.n, P = (int)a.P;
   const int col0 = bx * SGP_SN, nS = (n + SGP_SN - 1) / SGP_SN;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, h = lane >> 5;
   const int nq = 2 * D + P;
   float* __restrict__ part = a.part + ((e * nS + bx) * (long)nq) * M;   // [2D + P][M] of this strip
 
@@ -2881,7 +2881,7 @@ __global__ void __launch_bounds__(256) sgp_lbar_frag_kernel(const float* __restr
   while ((bi + 1) * (bi + 2) / 2 <= pair) ++bi;
   const int bj = pair - bi * (bi + 1) / 2;
   (void)nB;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int base = nS / S, rem = nS % S;
   const int sb = slab * base + (slab < rem ? slab : rem), se = sb + base + (slab < rem ? 1 : 0);
   const int cnt = se - sb, wq = cnt / 4, wr = cnt % 4;
@@ -3054,7 +3054,7 @@ __global__ void __launch_bounds__(256, 2) sgp_lbar_lds_kernel(const float* __res
   while (bi * (bi + 1) / 2 > pair) --bi;
   while ((bi + 1) * (bi + 2) / 2 <= pair) ++bi;
   const int bj = pair - bi * (bi + 1) / 2;            // block (bi, bj), bj <= bi, 128 rows / columns each
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
   const int base = nS / S, rem = nS % S;
   const int s0 = slab * base + (slab < rem ? slab : rem), s1 = s0 + base + (slab < rem ? 1 : 0);
   const long tstride = (long)nS << 10;
@@ -3199,7 +3199,7 @@ __device__ __forceinline__ void sgp_strip_finish_body(const T* __restrict__ part
     }
     return;
   }
-  const int ml = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int ml = threadIdx.x & 63, sg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long m = (long)bx * 64 + ml;
   T acc = T(0);
   if (m < M) {
