@@ -178,7 +178,9 @@ __device__ __forceinline__ void chol_persist_body(const CpArgs& a, CpLds& sh, co
   const int r = w >> 2;                                   // 0: diagonal block, 1: strip
   // column group.  Wave w runs on SIMD w & 3; the work of a wave grows with q (it follows 16 q columns before its own
   // 16), so the diagonal wave of group q shares its SIMD with the strip wave of group 3 - q: 5 units of 16 columns each
-  const int q = r == 0 ? (w & 3) : 3 - (w & 3);
+  // (a.early & 32, diagnostic: the pairing (q, q - 1 mod 4), in which the strip wave next to the pivot wave of chunk q >= 1 has
+  // finished its own group before that chunk starts -- measured 1.3 us per cfg-2 step SLOWER, 197.5 against 196.1: the balance wins)
+  const int q = r == 0 ? (w & 3) : ((a.early & 32) ? ((w & 3) + 3) & 3 : 3 - (w & 3));
   const int i16 = lane & 15, g4 = lane >> 4;              // MFMA 16x16x4 lane coordinates
   const int M = a.M, nb = a.nb, inv = a.W != nullptr;
 

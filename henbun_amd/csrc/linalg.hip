@@ -2228,7 +2228,7 @@ static int chol_persist_launch(const float* A, const CpGram& g, float* L, float*
   a.info = info;
   a.M = (int)M, a.B = (int)B, a.nb = (int)(M / CP_NB);
   a.total = (int)cp_total(B, a.nb, 1);
-  a.early = hb_debug_get("chol_chunk_stores_late", 0) ? 16 : 0, a.nside = 0, a.arrive = a.total, a.poll_naps = 1;
+  a.early = (hb_debug_get("chol_chunk_stores_late", 0) ? 16 : 0) | (hb_debug_get("chol_pair_prev", 0) ? 32 : 0), a.nside = 0, a.arrive = a.total, a.poll_naps = 1;
 #ifdef HB_CP_STAMPS
   a.stamps = hb_cp_stamps_buffer;   // diagnostic build (tools/chol_persist_stamps.hip)
 #else
