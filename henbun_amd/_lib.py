@@ -47,6 +47,9 @@ _SIGS = {
     "hb_sgp_head_units": [L, L, L, L, L, I, I, I, L],
     "hb_sgp_rider_supported": [L, L, L, L, L, I, I, I, L],
     "hb_matmul_gauss_units": [L, L, L],
+    "hb_matmul_gram_vjp_ok": [L, L, L, L],
+    "hb_matmul_gram_vjp_ws_elems": [L, L, L],
+    "hb_matmul_gram_vjp_f32": [P, P, P, L, L, L, L, L, L, L, L, L, I, I, P, L, P, L, L, L, P, P, P, P, P],
     "hb_fullrank_one_launch_shape": [L, L],
     "hb_matmul_gauss_f32": [P, L, P, L, P, P, P, P, D, P, P, P, L, L, L, L, P],
     "hb_sgp_rider_begin": [],
@@ -75,7 +78,7 @@ _SIGS = {
     "hb_comm_destroy": [P],
 }
 _RESTYPES = {"hb_last_error_string": c_char_p, "hb_sgp_ws_elems": c_long, "hb_ewise_prog_image_bytes": c_long,
-             "hb_sgp_head_units": c_long, "hb_matmul_gauss_units": c_long, "hb_cholesky_inverse_ws_elems": c_long, "hb_mlp2_sample_ws_elems": c_long}
+             "hb_sgp_head_units": c_long, "hb_matmul_gauss_units": c_long, "hb_matmul_gram_vjp_ws_elems": c_long, "hb_cholesky_inverse_ws_elems": c_long, "hb_mlp2_sample_ws_elems": c_long}
 
 # entry points that exist as _f32 and _f64
 _TYPED = {
@@ -104,6 +107,7 @@ _TYPED = {
     "hb_tri_to_vec": [P, P, L, L, P],
     "hb_gram_fwd": [I, P, L, P, L, P, L, L, P, L, L, L, L, D, P],
     "hb_gram_bwd": [I, P, L, P, L, P, L, L, P, P, P, P, L, L, L, L, P, P],
+    "hb_gram_ell_fold": [P, L, L, L, L, P, P],
     "hb_matmul": [P, P, P, L, L, L, L, L, L, L, L, L, L, I, I, D, D, P, L, I, I, P, L, P],
     "hb_matmul_colsum": [P, P, P, P, L, L, L, L, L, L, P, L, P],
     "hb_cholesky": [P, P, L, L, P, P],

@@ -205,6 +205,34 @@ static int gram_bwd(int kind_flags, const T* X, long sX, const T* X2, long sX2, 
   }
   return 0;
 }
+// The lengthscale fold alone: ellbar[c] = sum over the row partials [groups][rows][d] that a Gram VJP left behind (the last
+// launch of hb_gram_bwd; stand-alone for the Gram VJP that ran in a product's epilogue, hb_matmul_gram_vjp).  Chain-aware.
+template <typename T>
+static int gram_ell_fold(const T* partial, long rows, long d, long dl, long groups, T* ellbar, hipStream_t stream) {
+  HB_REQUIRE(partial && ellbar && rows >= 1 && d >= 1 && groups >= 1 && (dl == 1 || dl == d), "hb_gram_ell_fold: bad arguments");
+  if (hb_chain_recording() && rows * d * groups <= HB_CHAIN_ELL_MAX_N && groups * dl <= 16) {
+    HbChainJob j;
+    j.kind = HB_CHAIN_GRAM_ELL;
+    j.is64 = sizeof(T) == 8;
+    j.p[0] = partial, j.p[1] = ellbar;
+    j.l[0] = rows, j.l[1] = d, j.l[2] = dl, j.l[3] = groups;
+    return hb_chain_push(j, stream);
+  }
+  if (hb_chain_recording()) {
+    const int crc = hb_chain_flush(stream);
+    if (crc) return crc;
+  }
+  hipLaunchKernelGGL(gram_ell_finish_kernel<T>, dim3(dl, groups), dim3(256), 0, stream, partial, rows, d, dl, ellbar);
+  HB_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int hb_gram_ell_fold_f32(const float* partial, long rows, long d, long dl, long groups, float* ellbar, void* stream) {
+  return gram_ell_fold<float>(partial, rows, d, dl, groups, ellbar, (hipStream_t)stream);
+}
+extern "C" int hb_gram_ell_fold_f64(const double* partial, long rows, long d, long dl, long groups, double* ellbar, void* stream) {
+  return gram_ell_fold<double>(partial, rows, d, dl, groups, ellbar, (hipStream_t)stream);
+}
+
 extern "C" int hb_gram_bwd_f32(int kind, const float* X, long sX, const float* X2, long sX2, const float* ell,
                                long sEll, long dl, const float* Kbar, float* Xbar, float* X2bar, float* ellbar,
                                long B, long n, long n2, long d, float* ws, void* stream) {

@@ -323,8 +323,24 @@ __global__ void __launch_bounds__(256) matmul_splitk_finish_kernel(MmArgs<T> a) 
 // writes both halves of (X + X^T)/2.
 // ===========================================================================
 #define WGK_LD 33
+// Gram VJP in the epilogue (round 4): when the product IS Kbar -- the symmetric result S = L^-T Phi L^-1 of the Cholesky VJP,
+// whose only reader is the VJP of K(X, X) -- the workgroup of tile (ti, tj) turns its 32 x 32 block of S into the tile's
+// share of the row gradients (reference gp/kernels.py:54-101 under TF autodiff; the formulas of gram_bwd_side_kernel, side 3),
+// leaves it in `part`, and the LAST workgroup of a row of tiles to arrive (counter per (batch, ti): zero at entry, left
+// zero) folds the tiles in a fixed order into Xbar and the lengthscale partials.  One launch less per step.
+struct MmGramVjp {
+  const float* X = nullptr;     // [B][M][d] (sX: batch stride, 0 = shared)
+  long sX = 0;
+  const float* ell = nullptr;   // [B?][dl]
+  long sEll = 0, dl = 1, d = 1;
+  float* Xbar = nullptr;        // [B][M][d]
+  float* ell_partial = nullptr; // [B * M][d]
+  float* part = nullptr;        // [B][tiles_m][tiles_n][32][2 d]
+  unsigned* counters = nullptr; // [B][tiles_m]
+};
+#define HB_MMG_MAXD 4
 template <bool TA, bool TB, bool SYM>
-__global__ void __launch_bounds__(256) matmul_wgk_kernel(MmArgs<float> a, int nown, HbSideJobs side) {
+__global__ void __launch_bounds__(256) matmul_wgk_kernel(MmArgs<float> a, int nown, HbSideJobs side, MmGramVjp gv) {
   if ((int)blockIdx.x >= nown) {   // side jobs riding on this launch (side_jobs.cuh)
     if (blockIdx.y == 0) hb_side_run(side, (int)blockIdx.x - nown);
     return;
@@ -436,10 +452,12 @@ __global__ void __launch_bounds__(256) matmul_wgk_kernel(MmArgs<float> a, int no
   }
   __syncthreads();
   const float* biasb = a.bias ? a.bias + b * a.sBias : nullptr;
+  float gval[4];   // (the Gram VJP epilogue reads the four values this thread stores)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int idx = tid + 256 * e, r = idx >> 5, c = idx & 31;
     float v = ((red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c])) * a.alpha;
+    gval[e] = v;
     const long gr = row0 + r, gcn = col0 + c;
     if (SYM) {
       // (X + X^T)/2: element (r, c) of tile (ti, tj) pairs with element (c, r) of the mirrored tile (tj, ti)
@@ -461,6 +479,69 @@ __global__ void __launch_bounds__(256) matmul_wgk_kernel(MmArgs<float> a, int no
     if ((a.flags & (HB_MM_TRIL_OUT | HB_MM_PHI_OUT)) && gcn > gr) v = 0.f;
     if ((a.flags & HB_MM_PHI_OUT) && gcn == gr) v *= 0.5f;
     Cb[gr * a.ldc + gcn] = v;
+  }
+  if (!SYM && gv.X) {
+    // ---- the tile's share of the Gram VJP: rows (tid >> 5) + 8 e, column tid & 31; 32-lane sums over the columns
+    const int d = (int)gv.d, c = tid & 31;
+    const float* Xb = gv.X + b * gv.sX;
+    const float* eb = gv.ell + b * gv.sEll;
+    float il[HB_MMG_MAXD], xj[HB_MMG_MAXD];
+#pragma unroll
+    for (int k = 0; k < HB_MMG_MAXD; ++k) {
+      il[k] = k < d ? 1.f / eb[gv.dl == 1 ? 0 : k] : 0.f;
+      xj[k] = k < d ? Xb[(long)(col0 + c) * d + k] : 0.f;
+    }
+    const int tiles_m = M / 32;
+    float* pt = gv.part + ((((long)b * tiles_m + ti) * tiles_n + tj) * 32) * 2 * d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = (tid >> 5) + 8 * e;
+      float dm[HB_MMG_MAXD], r2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < HB_MMG_MAXD; ++k) {
+        dm[k] = k < d ? (Xb[(long)(row0 + r) * d + k] * il[k] - xj[k] * il[k]) : 0.f;
+        r2 += dm[k] * dm[k];
+      }
+      const float km = hb_exp(-0.5f * r2), kb = gval[e];
+      const float em = kb * km, gm = (kb + kb) * km;
+#pragma unroll
+      for (int k = 0; k < HB_MMG_MAXD; ++k) {
+        if (k < d) {
+          float ga = (-dm[k] * gm) * il[k], la = (dm[k] * dm[k] * em) * il[k];
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) {
+            ga += __shfl_xor(ga, off, 32);
+            la += __shfl_xor(la, off, 32);
+          }
+          if (c == 0) {
+            __hip_atomic_store(pt + r * 2 * d + k, ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pt + r * 2 * d + d + k, la, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+    // write-through partials, drained, then the row's counter (cdna_hip_programming.md Guideline 16 R1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ unsigned s_lastg;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(gv.counters + b * tiles_m + ti, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_lastg = old == (unsigned)tiles_n - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_lastg) {
+      const float* p0 = gv.part + (((long)b * tiles_m + ti) * tiles_n) * 32 * 2 * d;
+      for (int idx = tid; idx < 32 * 2 * d; idx += 256) {
+        float sum = 0.f;
+        for (int t = 0; t < tiles_n; ++t) sum += __hip_atomic_load(const_cast<float*>(p0) + (long)t * 32 * 2 * d + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int r = idx / (2 * d), q = idx - r * 2 * d;
+        if (q < d)
+          gv.Xbar[((long)b * M + row0 + r) * d + q] = sum;
+        else
+          gv.ell_partial[((long)b * M + row0 + r) * d + q - d] = sum;
+      }
+      if (tid == 0) __hip_atomic_store(gv.counters + b * tiles_m + ti, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (!SYM && (a.flags & HB_MM_SYMLOW_OUT) && ti != tj) {
 #pragma unroll
@@ -496,8 +577,10 @@ bool matmul_wgk_ok<float>(const MmArgs<float>& a, long M, long N, long K, long b
 }
 template <typename T>
 static int matmul_wgk_launch(const MmArgs<T>&, int, int, hipStream_t) { return -1; }
+int matmul_wgk_launch_g(const MmArgs<float>& a, int transA, int transB, hipStream_t stream, const MmGramVjp& gv);
 template <>
-int matmul_wgk_launch<float>(const MmArgs<float>& a, int transA, int transB, hipStream_t stream) {
+int matmul_wgk_launch<float>(const MmArgs<float>& a, int transA, int transB, hipStream_t stream) { return matmul_wgk_launch_g(a, transA, transB, stream, MmGramVjp()); }
+int matmul_wgk_launch_g(const MmArgs<float>& a, int transA, int transB, hipStream_t stream, const MmGramVjp& gv) {
   const bool sym = (a.flags & HB_MM_SYM_OUT) != 0;
   const long nt = a.M / 32;
   const int nown = (int)(sym ? nt * (nt + 1) / 2 : (a.M / 32) * (a.N / 32));
@@ -506,9 +589,9 @@ int matmul_wgk_launch<float>(const MmArgs<float>& a, int transA, int transB, hip
 #define HB_WGK(TA_, TB_)                                                                                   \
   do {                                                                                                     \
     if (sym)                                                                                               \
-      hipLaunchKernelGGL((matmul_wgk_kernel<TA_, TB_, true>), grid, dim3(256), 0, stream, a, nown, sj);    \
+      hipLaunchKernelGGL((matmul_wgk_kernel<TA_, TB_, true>), grid, dim3(256), 0, stream, a, nown, sj, gv);    \
     else                                                                                                   \
-      hipLaunchKernelGGL((matmul_wgk_kernel<TA_, TB_, false>), grid, dim3(256), 0, stream, a, nown, sj);   \
+      hipLaunchKernelGGL((matmul_wgk_kernel<TA_, TB_, false>), grid, dim3(256), 0, stream, a, nown, sj, gv);   \
   } while (0)
   if (!transA && !transB)
     HB_WGK(false, false);
@@ -1173,6 +1256,33 @@ extern "C" int hb_matmul_f32(const float* A, const float* B, float* C, long batc
   return matmul_launch<float>(A, B, C, batch, M, N, K, lda, ldb, ldc, sA, sB, sC, transA, transB, alpha, beta, bias,
                               sBias, act, flags, ws, ws_elems, (hipStream_t)stream);
 }
+// The square product whose result is Kbar of a Gram matrix K(X, X), with that Gram matrix's VJP in its epilogue (MmGramVjp).
+extern "C" int hb_matmul_gram_vjp_ok(long M, long K, long batch, long d) {
+  MmArgs<float> t = {};
+  if (hb_debug_get("mm_no_gram_vjp", 0) != 0 || d < 1 || d > HB_MMG_MAXD) return 0;
+  return matmul_wgk_ok<float>(t, M, M, K, batch, 0, true) ? 1 : 0;
+}
+extern "C" long hb_matmul_gram_vjp_ws_elems(long batch, long M, long d) { return batch * (M / 32) * (M / 32) * 32 * 2 * d; }
+extern "C" int hb_matmul_gram_vjp_f32(const float* A, const float* B, float* C, long batch, long M, long K, long lda, long ldb,
+                                      long ldc, long sA, long sB, long sC, int transA, int transB, const float* X, long sX,
+                                      const float* ell, long sEll, long dl, long d, float* Xbar, float* ell_partial,
+                                      float* part, unsigned* counters, void* stream) {
+  HB_REQUIRE(A && B && C && X && ell && Xbar && ell_partial && part && counters, "hb_matmul_gram_vjp: NULL pointer");
+  HB_REQUIRE(hb_matmul_gram_vjp_ok(M, K, batch, d), "hb_matmul_gram_vjp: shape outside the in-workgroup split-K form (hb_matmul_gram_vjp_ok)");
+  HB_REQUIRE(dl == 1 || dl == d, "hb_matmul_gram_vjp: lengthscales must have 1 or d entries");
+  const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0;
+  HB_REQUIRE(aligned, "hb_matmul_gram_vjp: operands must be 16-byte aligned with leading dimensions %% 4 == 0");
+  HB_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : M) && ldc >= M, "hb_matmul_gram_vjp: leading dimension too small");
+  MmArgs<float> a = {};
+  a.A = A, a.B = B, a.C = C;
+  a.M = M, a.N = M, a.K = K, a.lda = lda, a.ldb = ldb, a.ldc = ldc, a.sA = sA, a.sB = sB, a.sC = sC, a.batch = batch;
+  a.alpha = 1.f, a.beta = 0.f, a.act = HB_ACT_NONE, a.flags = 0;
+  MmGramVjp gv;
+  gv.X = X, gv.sX = sX, gv.ell = ell, gv.sEll = sEll, gv.dl = dl, gv.d = d;
+  gv.Xbar = Xbar, gv.ell_partial = ell_partial, gv.part = part, gv.counters = counters;
+  return matmul_wgk_launch_g(a, transA, transB, (hipStream_t)stream, gv);
+}
+
 // The Gaussian likelihood head of a MatBias layer (reference nn.py:31-32 feeding densities.py:25-27 under tf.reduce_sum):
 // f = A B + bias is consumed in the epilogue of the row-streaming product, never written (EPI 5 above).
 static inline bool matmul_gauss_shape(long n, long K, long N, int& G, int& KC) {

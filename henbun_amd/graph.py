@@ -981,6 +981,32 @@ def _matmul_emit(plan, node):
     wgk_like = (plan.dtype == plan.torch.float32 and bias is None and ysh[-1] % 32 == 0 and ysh[-2] % 32 == 0 and kk % 128 == 0
                 and 128 <= kk <= 4096 and (ysh[-1] // 32) * (ysh[-2] // 32) * int(np.prod(ysh[:-2]) if len(ysh) > 2 else 1) <= 1024)
     host = wgk_like and plan.attach_side(node)
+    # The product whose result is Kbar of a Gram matrix K(X, X) and feeds nothing but that Gram matrix's VJP (the last
+    # product of the Cholesky VJP): the VJP runs in the product's epilogue (hb_matmul_gram_vjp), gram_grad keeps the fold.
+    # settings.runtime.gram_vjp_in_product, OFF by default: one launch less, but the tile partials' way through memory
+    # (write-through, drain, counter, last arriver's loads) is a longer dependent chain than the launch it replaces --
+    # cfg 2: 197.3 -> 202.4 us per step (tools/ab_step.py)
+    gg = cons[0] if (len(cons) == 1 and cons[0].op == "gram_grad") else None
+    gp = "Gram VJP inside the product that computes Kbar (hb_matmul_gram_vjp)"
+    if gg is not None and not epi and bias is None:
+        from ._settings import settings as _st
+        tX, tX2, tell, tg = gg.inputs
+        B, BX, BX2, n, n2, d, sX, sX2, sEll, dl = _gram_layout(tX, tX2, tell)
+        ok = (bool(getattr(_st.runtime, "gram_vjp_in_product", False)) and wgk_like and gg.attrs.get("sym") and tg is y
+              and node.attrs.get("sym_result") and gg.attrs["kind"] == "rbf" and not (BX == 1 and B > 1) and y not in plan.outputs
+              and y not in plan._bind and n == ysh[-1] and H.matmul_gram_vjp_ok(n, kk, B, d, plan.dtype))
+        plan.note(gp, gg, ok, "" if ok else "needs the in-workgroup split-K form, the symmetric one-pass VJP of a UnitRBF Gram and d <= 4")
+        if ok:
+            X, ell = plan.buf(tX), plan.buf(tell)
+            oX = plan.out(gg.outputs[0])
+            lws = plan.scratch((max(B * n * d, 1),))
+            part = plan.scratch((B * (n // 32) * (n // 32) * 32 * 2 * d,))
+            counters = plan.torch.zeros((B * (n // 32),), dtype=plan.torch.int32, device=plan.device)
+            plan._gram_in_mm[gg.id] = (lws, (n if sEll != 0 else B * n), d, dl, (B if sEll != 0 else 1))
+            plan.steps.append(lambda: H.matmul_gram_vjp(a, b, out, at["ta"], at["tb"], X, sX, ell, sEll, dl, d, oX, lws, part, counters))
+            if host:
+                plan.steps.append(lambda: H.side_flush())
+            return
     plan.steps.append(lambda: H.matmul(a, b, transA=at["ta"], transB=at["tb"], bias=bias, act=at["act"], out=out,
                                        epilogue=epi))
     if host:
@@ -1652,6 +1678,16 @@ def _gram_vjp(node, gs):
 
 def _gram_grad_emit(plan, node):
     H = plan.H
+    fused = plan._gram_in_mm.get(node.id)
+    if fused is not None:
+        # the point gradient and the lengthscale row partials came out of the product that computed Kbar (_matmul_emit)
+        lws, rows, d_, dl_, groups = fused
+        oL = plan.out(node.outputs[1])
+        plan.out(node.outputs[0])
+        fold = lambda: H.gram_ell_fold(lws, rows, d_, dl_, groups, oL)
+        plan.steps.append(fold)
+        plan.chain_kind[id(fold)] = "full"
+        return
     tX, tX2, tell, tg = node.inputs
     X, X2, ell, g = (plan.buf(t) for t in node.inputs)
     k = KERN_KINDS[node.attrs["kind"]]
@@ -2431,6 +2467,7 @@ class Plan:
         # X^T G whose right operand is also column-summed (reduce over axis 0) becomes hb_matmul_colsum -- the GEMM folds
         # the columns of G while it streams them, and the stand-alone reduction launches (two per layer) disappear.
         self._gram_for_chol: Dict[int, tuple] = {}   # cholesky node id -> (points, lengthscales, kind, jitter) of its folded Gram
+        self._gram_in_mm: Dict[int, tuple] = {}      # gram_grad node id -> (lengthscale partials, rows, d, dl, groups): set by _matmul_emit
         self._chol_rider: Dict[Tensor, dict] = {}    # inverse tensor -> the persistent factorisation step's rider cell (_cholesky_emit)
         self.step_riders: Dict[int, Node] = {}       # id(step closure) -> node whose work rides in that step's launch
         self._mlp2: Dict[int, dict] = {}             # mlp2_sample_kl node id -> {fused, ws | h}

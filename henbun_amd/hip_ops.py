@@ -913,6 +913,31 @@ def sgp_head_units(x, z, u, prec, has_wfrag, draw, rng):
                                                   rng.nlanes if rng is not None else 0))
 
 
+def matmul_gram_vjp_ok(M, K, batch, d, dtype):
+    """The square product [batch, M, K] x [batch, K, M] can carry the Gram VJP of its result (hb_matmul_gram_vjp_ok)."""
+    if dtype != torch.float32:
+        return False
+    return bool(_lib.lib().raw("hb_matmul_gram_vjp_ok")(int(M), int(K), int(batch), int(d)))
+
+
+def matmul_gram_vjp(a, b, out, transA, transB, X, sX, ell, sEll, dl, d, xbar, ell_partial, part, counters):
+    """out = op(a) op(b) (batched square product) and, from the same launch, the one-pass symmetric Gram VJP of `out` as
+    Kbar: xbar and the lengthscale row partials (hb_matmul_gram_vjp_f32)."""
+    M = out.shape[-1]
+    batch = out.numel() // (M * M)
+    K = a.shape[-2] if transA else a.shape[-1]
+    sA = a.stride(0) if a.dim() == 3 and a.shape[0] > 1 else 0
+    sB = b.stride(0) if b.dim() == 3 and b.shape[0] > 1 else 0
+    _lib.lib().call("hb_matmul_gram_vjp_f32", _p(a), _p(b), _p(out), batch, M, K, a.stride(-2), b.stride(-2), out.stride(-2),
+                    sA, sB, M * M, int(bool(transA)), int(bool(transB)), _p(X), int(sX), _p(ell), int(sEll), int(dl), int(d),
+                    _p(xbar), _p(ell_partial), _p(part), _p(counters), stream())
+
+
+def gram_ell_fold(partial, rows, d, dl, groups, ellbar):
+    """ellbar from the lengthscale row partials of a Gram VJP (hb_gram_ell_fold; chain-aware)."""
+    _lib.lib().call("hb_gram_ell_fold" + _suf(partial), _p(partial), int(rows), int(d), int(dl), int(groups), _p(ellbar), stream())
+
+
 def matmul_gauss_units(n, K, N, dtype):
     """Partial-sum units of hb_matmul_gauss for an [n, K] x [K, N] MatBias layer feeding a Gaussian head (0: not this shape)."""
     if dtype != torch.float32:

@@ -515,6 +515,21 @@ int hb_sgp_rider_supported(long E, long n, long M, long d, long P, int prec, int
 int hb_sgp_rider_begin(void);
 int hb_sgp_rider_pending(void);
 int hb_sgp_rider_flush(void* stream);
+/* The Gram VJP in the epilogue of the product that computes Kbar (round 4).  The Cholesky VJP ends in S = L^-T Phi L^-1
+ * (reference: TF's _CholeskyGrad behind tf.cholesky gp/kernels.py:101), whose only reader is the VJP of K(X, X) + jitter I
+ * (gp/kernels.py:54-101): C[batch, M, M] = op(A) op(B) as hb_matmul computes it (in-workgroup split-K form: fp32, M % 32 == 0,
+ * K % 128 == 0, <= 1024 tiles -- hb_matmul_gram_vjp_ok) AND, from the same launch, Xbar[batch, M, d] and the lengthscale
+ * row partials ell_partial[batch * M, d] of hb_gram_bwd's one-pass symmetric form (UnitRBF, Kbar symmetric).  `part`:
+ * hb_matmul_gram_vjp_ws_elems(batch, M, d) scratch elements; `counters`: batch * M / 32 zero 32-bit words, left zero.
+ * hb_gram_ell_fold_* folds the partials into ellbar (the last launch of hb_gram_bwd on its own; chain-aware). */
+int hb_matmul_gram_vjp_ok(long M, long K, long batch, long d);
+long hb_matmul_gram_vjp_ws_elems(long batch, long M, long d);
+int hb_matmul_gram_vjp_f32(const float* A, const float* B, float* C, long batch, long M, long K, long lda, long ldb,
+                           long ldc, long sA, long sB, long sC, int transA, int transB, const float* X, long sX,
+                           const float* ell, long sEll, long dl, long d, float* Xbar, float* ell_partial,
+                           float* part, unsigned* counters, void* stream);
+int hb_gram_ell_fold_f32(const float* partial, long rows, long d, long dl, long groups, float* ellbar, void* stream);
+int hb_gram_ell_fold_f64(const double* partial, long rows, long d, long dl, long groups, double* ellbar, void* stream);
 /* The Gaussian likelihood head of a MatBias layer in the layer's own launch (round 4; reference nn.py:31-32 feeding
  * densities.py:25-27 under tf.reduce_sum): f = A[n, K] B[K, N] + bias[N] is consumed in the epilogue of the row-streaming
  * product and never written -- dmu[n, N] = (y - f s) / var, fbar = s (post dmu) when fbar != NULL, and one partial triple

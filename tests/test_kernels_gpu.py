@@ -1218,6 +1218,45 @@ def test_likelihood_head_inside_the_forward_contraction(H, M, n):
             assert abs(float(a_) - float(b_)) <= 2e-6 * max(abs(float(a_)), float(n) ** 0.5), (float(a_), float(b_))   # observed <= 3e-7 relative
 
 
+@pytest.mark.parametrize("B,M,d,dl", [(1, 512, 1, 1), (1, 256, 3, 3), (4, 128, 2, 1), (2, 512, 2, 2)])
+def test_gram_vjp_inside_the_product_that_computes_kbar(H, B, M, d, dl):
+    """hb_matmul_gram_vjp + hb_gram_ell_fold: the last product of the Cholesky VJP (S = T W, symmetric) with the VJP of
+    K(X, X) (reference gp/kernels.py:54-101 under TF autodiff) in its epilogue -- against hb_matmul followed by the
+    one-pass symmetric hb_gram_bwd on the product's result: the product keeps its bits, Xbar and ellbar agree to fp32
+    rounding (other fixed summation order), the counters are left zero (called twice)."""
+    dt = torch.float32
+    rng = np.random.RandomState(B * 1000 + M + d)
+    lead = (B,) if B > 1 else ()
+    X = dev(np.sort(rng.uniform(0, 8.0, lead + (M, d)), axis=-2), dt)
+    ell = dev(0.7 + rng.rand(*(lead + (dl,))), dt)
+    Wl = dev(np.tril(rng.randn(*(lead + (M, M)))) / np.sqrt(M), dt)
+    P = rng.randn(*(lead + (M, M)))
+    P = dev(P + np.swapaxes(P, -1, -2), dt)
+    T1 = H.matmul(Wl, P, transA=True)                      # W^T P
+    S0 = H.matmul(T1, Wl)                                  # (W^T P) W : symmetric to rounding
+    xb0, lb0 = torch.empty_like(X), torch.empty_like(ell)
+    sX = M * d if B > 1 else 0
+    sEll = dl if B > 1 else 0
+    ws = torch.empty(max(B * M * d, 1), dtype=dt, device="cuda")
+    H.gram_bwd_raw(H.KERN_RBF | H.KERN_KBAR_SYMMETRIC, X, sX, X, sX, ell, sEll, dl, S0, xb0, xb0, lb0, B, M, M, d, ws)
+    assert H.matmul_gram_vjp_ok(M, M, B, d, dt)
+    S1 = torch.full_like(S0, float("nan"))
+    xb1, lb1 = torch.full_like(X, float("nan")), torch.full_like(ell, float("nan"))
+    lws = torch.full((B * M * d,), float("nan"), dtype=dt, device="cuda")
+    part = torch.full((B * (M // 32) ** 2 * 32 * 2 * d,), float("nan"), dtype=dt, device="cuda")
+    counters = torch.zeros(B * (M // 32), dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        H.matmul_gram_vjp(T1, Wl, S1, False, False, X, sX, ell, sEll, dl, d, xb1, lws, part, counters)
+        H.gram_ell_fold(lws, M if sEll else B * M, d, dl, B if sEll else 1, lb1)
+        torch.cuda.synchronize()
+        assert int(counters.abs().sum()) == 0
+        assert torch.equal(S0, S1)
+        for a_, b_ in ((xb0, xb1), (lb0, lb1)):
+            err = float((a_ - b_).abs().max() / a_.abs().max())
+            assert err <= 2e-5, err       # observed <= 3e-6
+    assert not H.matmul_gram_vjp_ok(M, M, B, 5, dt)
+
+
 @pytest.mark.parametrize("n,K,N", [(32768, 16, 64), (4096, 32, 96), (2048 + 17, 64, 256), (8192, 128, 33)])
 @pytest.mark.parametrize("with_scale,with_bias,post", [(True, True, 3.25), (False, False, None)])
 def test_likelihood_head_inside_the_layer_product(H, n, K, N, with_scale, with_bias, post):
