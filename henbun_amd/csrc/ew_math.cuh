@@ -84,9 +84,11 @@ __device__ __forceinline__ T hb_sigmoid(T x) {
 // per element and dominated the epilogue of the bias+sigmoid GEMMs
 template <>
 __device__ __forceinline__ float hb_sigmoid<float>(float x) {
-  const float e = __expf(-fabsf(x));           // in (0, 1]: no overflow
-  const float r = __builtin_amdgcn_rcpf(1.0f + e);
-  return x >= 0.0f ? r : e * r;
+  // 1 / (1 + e^-x) as it stands: for x < -88 the exponential overflows to +inf and v_rcp_f32 returns 0, which is the
+  // value (6e-39 and below) to fp32 precision; everywhere else both factors are good to 1 ulp.  Four vector instructions
+  // instead of seven (the |x| form needed a compare, a select and a second multiply): in the epilogues of the fp32 MFMA
+  // kernels every vector instruction is paid in full, the matrix instructions share that pipe.
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
 #pragma clang fp contract(fast)
