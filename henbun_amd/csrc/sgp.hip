@@ -2686,9 +2686,11 @@ __global__ void __launch_bounds__(SGP_STRIP_THREADS, (BF3 || D >= 3) ? 2 : 4) sg
     sgp_acc_t_settle(acc);
     float kb[16];
     sgp_acc_t_rows(acc, kb);
+    if (col0 + SGP_SN > n) {   // (only the last strip has columns past n: the masks stay off the vector pipe elsewhere)
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if (col0 + 16 * h + i >= n) kb[i] = 0.f;
+      for (int i = 0; i < 16; ++i)
+        if (col0 + 16 * h + i >= n) kb[i] = 0.f;
+    }
     if (a.Kbar) {   // row-major Kbar (not requested by the fragment-major pipeline): 64 contiguous bytes per lane
       float* kp = Kbar + (long)(32 * tile + li) * n + col0 + 16 * h;
       if ((n & 3) == 0 && col0 + SGP_SN <= n) {
