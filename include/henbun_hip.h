@@ -40,7 +40,9 @@ extern "C" {
 
 /* ABI history: 1 = rounds 1-3 (the round that removed hb_cholesky_inverse_sgp_f32 and hb_sgp_finish_* should have
  * bumped it and did not); 2 = round 4: hb_debug_set / hb_debug_clear, hb_cholesky_inverse_ws_elems and the workspace
- * contract of hb_cholesky_inverse_f32 (exchange + sync area, zero-filled once by its owner). */
+ * contract of hb_cholesky_inverse_f32 (exchange + sync area, zero-filled once by its owner); added without changing an
+ * existing signature: hb_cholesky_persistent_shape, hb_gram_cholesky_inverse_f32, hb_mlp2_sample_*, hb_matmul_gauss_*,
+ * hb_matmul_gram_vjp_*, hb_gram_ell_fold_*, hb_sgp_rider_*, hb_fullrank_sample_kl_fwd1_* / hb_fullrank_one_launch_shape. */
 #define HB_ABI_VERSION 2
 
 /* ---- runtime ----------------------------------------------------------- */
